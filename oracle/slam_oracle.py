@@ -1,0 +1,459 @@
+"""CPU oracle: NumPy/SciPy restatement of the SLAM template-optimizer hot path.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  Every function cites
+the reference file:line it follows (paths relative to ``/root/reference``).
+Third-party conventions (qiskit ``U`` gate, little-endian ``Operator``,
+``weylchamber.c1c2c3``, ``random_unitary``) are restated from their published
+definitions and pinned by the reference's recorded
+notebook outputs (KAT-1..5), not by importing those packages.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.optimize as opt
+from scipy.stats import unitary_group
+
+TWO_PI = 2.0 * math.pi
+
+# --------------------------------------------------------------------------
+# Gate matrices (reference: src/slam/utils/gates/custom_gates.py, hamiltonian.py)
+# --------------------------------------------------------------------------
+
+
+def u3(theta: float, phi: float, lam: float) -> np.ndarray:
+    """qiskit ``UGate(theta, phi, lam)`` matrix, as appended by
+    ``circuit.u(...)`` at src/slam/basis.py:157,168."""
+    c, s = math.cos(theta / 2.0), math.sin(theta / 2.0)
+    return np.array(
+        [
+            [c, -np.exp(1j * lam) * s],
+            [np.exp(1j * phi) * s, np.exp(1j * (phi + lam)) * c],
+        ],
+        dtype=np.complex128,
+    )
+
+
+def cx_matrix() -> np.ndarray:
+    """qiskit ``CXGate().to_matrix()`` (control q0, target q1, little-endian);
+    star-imported at src/slam/basis.py:10."""
+    return np.array(
+        [[1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0], [0, 1, 0, 0]], dtype=np.complex128
+    )
+
+
+def riswap_matrix(alpha: float) -> np.ndarray:
+    """``RiSwapGate.__array__`` src/slam/utils/gates/custom_gates.py:582-595."""
+    a = float(alpha) / 2.0
+    c = math.cos(math.pi * a)
+    isin = 1j * math.sin(math.pi * a)
+    return np.array(
+        [[1, 0, 0, 0], [0, c, isin, 0], [0, isin, c, 0], [0, 0, 0, 1]],
+        dtype=np.complex128,
+    )
+
+
+_SX = np.array([[0, 1], [1, 0]], dtype=np.complex128)
+_SY = np.array([[0, -1j], [1j, 0]], dtype=np.complex128)
+_SZ = np.array([[1, 0], [0, -1]], dtype=np.complex128)
+
+
+def canonical_matrix(c1: float, c2: float, c3: float) -> np.ndarray:
+    """``weylchamber.canonical_gate(c1,c2,c3)`` (units of pi):
+    exp(i pi/2 (c1 XX + c2 YY + c3 ZZ)).  XX, YY, ZZ commute, so the
+    exponential is the product of three closed-form factors."""
+    out = np.eye(4, dtype=np.complex128)
+    for c, s in ((c1, _SX), (c2, _SY), (c3, _SZ)):
+        ss = np.kron(s, s)
+        ang = math.pi / 2.0 * c
+        out = out @ (math.cos(ang) * np.eye(4) + 1j * math.sin(ang) * ss)
+    return out
+
+
+def berkeley_matrix() -> np.ndarray:
+    """``BerkeleyGate`` = ``CanonicalGate(pi/4, pi/8, 0)`` which rescales by
+    2/pi (src/slam/utils/gates/custom_gates.py:384-400)."""
+    return canonical_matrix(0.5, 0.25, 0.0)
+
+
+def conversion_gain_matrix(
+    phi_c: float, phi_g: float, gc: float, gg: float, t: float = 1.0
+) -> np.ndarray:
+    """Closed form of ``ConversionGainPhaseHamiltonian.construct_U``
+    (src/slam/hamiltonian.py:84-111) as used by ``ConversionGainGate.__array__``
+    (src/slam/utils/gates/custom_gates.py:180-184; argument plumbing per
+    SURVEY.md Appendix A-6: p1=phi_c, p2=phi_g, g1=gc, g2=gg).
+
+    H = gc (e^{i phi_c} A B^+ + h.c.) + gg (e^{i phi_g} A B + h.c.),
+    A = a (x) I, B = I (x) a, a = qutip ``create(2)`` = [[0,0],[1,0]].
+    The {|01>,|10>} and {|00>,|11>} blocks decouple into 2x2 rotations.
+    """
+    U = np.zeros((4, 4), dtype=np.complex128)
+    cc, sc = math.cos(gc * t), math.sin(gc * t)
+    cg, sg = math.cos(gg * t), math.sin(gg * t)
+    # conversion block, basis order (|01>=1, |10>=2)
+    U[1, 1] = cc
+    U[2, 2] = cc
+    U[2, 1] = -1j * np.exp(1j * phi_c) * sc
+    U[1, 2] = -1j * np.exp(-1j * phi_c) * sc
+    # gain block (|00>=0, |11>=3)
+    U[0, 0] = cg
+    U[3, 3] = cg
+    U[3, 0] = -1j * np.exp(1j * phi_g) * sg
+    U[0, 3] = -1j * np.exp(-1j * phi_g) * sg
+    return U
+
+
+def conversion_gain_matrix_expm(phi_c, phi_g, gc, gg, t=1.0) -> np.ndarray:
+    """Direct ``expm`` restatement of src/slam/hamiltonian.py:84-111 used to
+    validate the closed form above."""
+    from scipy.linalg import expm
+
+    a = np.array([[0, 0], [1, 0]], dtype=np.complex128)  # qutip create(2)
+    I2 = np.eye(2, dtype=np.complex128)
+    A = np.kron(a, I2)
+    B = np.kron(I2, a)
+    Hc = np.exp(1j * phi_c) * A @ B.conj().T + np.exp(-1j * phi_c) * A.conj().T @ B
+    Hg = np.exp(1j * phi_g) * A @ B + np.exp(-1j * phi_g) * A.conj().T @ B.conj().T
+    return expm(-1j * t * (gc * Hc + gg * Hg))
+
+
+# --------------------------------------------------------------------------
+# Template forward chain, loss, gradient
+# --------------------------------------------------------------------------
+
+
+def n_params(k: int) -> int:
+    """6(k+1): src/slam/basis.py:152-169 adds U(q0),U(q1) first and after
+    every 2Q gate."""
+    return 6 * (k + 1)
+
+
+def layer_matrix(x6: Sequence[float]) -> np.ndarray:
+    """K_j = U3(q1 params) (x) U3(q0 params): qiskit little-endian
+    ``Operator`` ordering, qubit 0 is the right Kronecker factor."""
+    return np.kron(u3(*x6[3:6]), u3(*x6[0:3]))
+
+
+def template_eval(x: Sequence[float], gate_seq: Sequence[np.ndarray]) -> np.ndarray:
+    """``CircuitTemplate.eval`` src/slam/basis.py:102-104 for the circuit built
+    by ``build(k)`` src/slam/basis.py:124-169:
+    W = K_k G_k ... G_1 K_0,  x in index order P0..P{n-1}."""
+    k = len(gate_seq)
+    x = np.asarray(x, dtype=np.float64)
+    assert x.shape == (n_params(k),)
+    W = layer_matrix(x[0:6])
+    for j in range(1, k + 1):
+        W = gate_seq[j - 1] @ W
+        W = layer_matrix(x[6 * j : 6 * j + 6]) @ W
+    return W
+
+
+def basic_cost(current_u: np.ndarray, target_u: np.ndarray) -> float:
+    """``BasicCost.unitary_fidelity`` src/slam/cost_function.py:140-145."""
+    h = np.asarray(target_u).conj().T
+    return float(1.0 - np.abs(np.trace(h @ current_u)) / current_u.shape[0])
+
+
+def square_cost(current_u: np.ndarray, target_u: np.ndarray) -> float:
+    """``SquareCost.unitary_fidelity`` src/slam/cost_function.py:169-173 (used
+    only to pin KAT-1's recorded loss)."""
+    h = np.asarray(target_u).conj().T
+    d = target_u.shape[0]
+    return float(1.0 - (np.abs(np.trace(h @ current_u)) ** 2 + d) / (d * (d + 1)))
+
+
+def loss(x, gate_seq, target) -> float:
+    """``objective_func`` src/slam/optimizer.py:191-214 with BasicCost
+    (normalization = 1, src/slam/cost_function.py:123)."""
+    return basic_cost(template_eval(x, gate_seq), target)
+
+
+def _du3(theta, phi, lam):
+    c, s = math.cos(theta / 2.0), math.sin(theta / 2.0)
+    ep, el = np.exp(1j * phi), np.exp(1j * lam)
+    d_theta = 0.5 * np.array([[-s, -el * c], [ep * c, -ep * el * s]])
+    d_phi = np.array([[0, 0], [1j * ep * s, 1j * ep * el * c]])
+    d_lam = np.array([[0, -1j * el * s], [0, 1j * ep * el * c]])
+    return d_theta, d_phi, d_lam
+
+
+def loss_and_grad(x, gate_seq, target) -> Tuple[float, np.ndarray]:
+    """Loss and its analytic gradient.  The reference has no analytic
+    gradient (SciPy finite-differences ``objective_func``,
+    src/slam/optimizer.py:270-278); this is the formula SURVEY.md §8(a) A5
+    states: dL/dx_i = -Re(conj(t) Tr(T^+ d_i W)) / (4|t|), t = Tr(T^+ W).
+    It is validated against central differences of :func:`loss` in tests.
+    """
+    k = len(gate_seq)
+    x = np.asarray(x, dtype=np.float64)
+    n = n_params(k)
+    Ks = [layer_matrix(x[6 * j : 6 * j + 6]) for j in range(k + 1)]
+    # right[j] = G_j K_{j-1} ... K_0  (right[0] = I); left[j] = K_k G_k ... G_{j+1}
+    right = [np.eye(4, dtype=np.complex128)]
+    for j in range(1, k + 1):
+        right.append(gate_seq[j - 1] @ Ks[j - 1] @ right[j - 1])
+    left = [None] * (k + 1)
+    left[k] = np.eye(4, dtype=np.complex128)
+    for j in range(k - 1, -1, -1):
+        left[j] = left[j + 1] @ Ks[j + 1] @ gate_seq[j]
+    W = Ks[k] @ right[k]
+    Th = np.asarray(target).conj().T
+    t = np.trace(Th @ W)
+    at = abs(t)
+    val = 1.0 - at / 4.0
+    grad = np.zeros(n)
+    for j in range(k + 1):
+        E = right[j] @ Th @ left[j]  # Tr(T^+ L dK R) = Tr(E dK)
+        A = u3(*x[6 * j + 3 : 6 * j + 6])
+        B = u3(*x[6 * j : 6 * j + 3])
+        dB = _du3(*x[6 * j : 6 * j + 3])
+        dA = _du3(*x[6 * j + 3 : 6 * j + 6])
+        for m in range(3):
+            dt = np.trace(E @ np.kron(A, dB[m]))
+            grad[6 * j + m] = -np.real(np.conj(t) * dt) / (4.0 * at)
+            dt = np.trace(E @ np.kron(dA[m], B))
+            grad[6 * j + 3 + m] = -np.real(np.conj(t) * dt) / (4.0 * at)
+    return float(val), grad
+
+
+def fd_grad(x, gate_seq, target, h: float = 1e-6) -> np.ndarray:
+    """Central-difference gradient of :func:`loss` (oracle for A5)."""
+    x = np.asarray(x, dtype=np.float64)
+    g = np.zeros_like(x)
+    for i in range(x.size):
+        e = np.zeros_like(x)
+        e[i] = h
+        g[i] = (loss(x + e, gate_seq, target) - loss(x - e, gate_seq, target)) / (2 * h)
+    return g
+
+
+# --------------------------------------------------------------------------
+# Weyl-chamber coordinates
+# --------------------------------------------------------------------------
+
+_YY = np.kron(_SY, _SY)
+
+
+def c1c2c3(U: np.ndarray, ndigits: int = 8) -> Tuple[float, float, float]:
+    """``weylchamber.c1c2c3`` as called at src/slam/basis_abc.py:80-84 and
+    src/slam/optimizer.py:85,103,224 (algorithm: SURVEY.md Appendix A-4,
+    pinned by KAT-1/KAT-5)."""
+    U = np.asarray(U, dtype=np.complex128)
+    Ut = _YY @ U.T @ _YY
+    ev = np.linalg.eigvals(U @ Ut / np.sqrt(complex(np.linalg.det(U))))
+    two_S = np.angle(ev) / np.pi
+    for i in range(4):
+        if two_S[i] <= -0.5:
+            two_S[i] += 2.0
+    S = np.sort(two_S / 2.0)[::-1]
+    n = int(round(float(sum(S))))
+    S = S - np.r_[np.ones(n), np.zeros(4 - n)]
+    S = np.roll(S, -n)
+    M = np.array([[1, 1, 0], [1, 0, 1], [0, 1, 1]])
+    c1, c2, c3 = np.dot(M, S[:3])
+    if c3 < 0:
+        c1 = 1 - c1
+        c3 = -c3
+    return (round(c1 + 0.0, ndigits) + 0.0, round(c2 + 0.0, ndigits) + 0.0, round(c3 + 0.0, ndigits) + 0.0)
+
+
+def c1c2c3_raw(U: np.ndarray) -> np.ndarray:
+    """Unrounded Weyl coordinates (for 1e-6 parity comparisons)."""
+    return np.array(c1c2c3(U, ndigits=15))
+
+
+# --------------------------------------------------------------------------
+# Target sampling and multi-start seeds
+# --------------------------------------------------------------------------
+
+
+def haar_unitary(seed: int, dim: int = 4) -> np.ndarray:
+    """qiskit ``random_unitary(dim, seed)`` recipe (src/slam/sampler.py:67-71):
+    ``scipy.stats.unitary_group.rvs(dim, random_state=default_rng(seed))``."""
+    return unitary_group.rvs(dim, random_state=np.random.default_rng(seed))
+
+
+def haar_sample_reference(seed: Optional[int], n_samples: int) -> List[np.ndarray]:
+    """``HaarSample.__iter__`` semantics, src/slam/sampler.py:25-27,62-71:
+    Python's ``random`` is re-seeded with ``self.seed`` on every draw, so an
+    integer seed yields ``n_samples`` identical unitaries."""
+    import random
+    from sys import maxsize
+
+    out = []
+    for _ in range(n_samples):
+        random.seed(seed)
+        out.append(haar_unitary(random.randint(0, maxsize)))
+    return out
+
+
+BENCH_TARGET_SEED0 = 20260000
+
+
+def haar_batch(n: int, seed0: int = BENCH_TARGET_SEED0, start: int = 0) -> np.ndarray:
+    """T_i = haar_unitary(seed0 + i) for i in [start, start+n) -- the synthetic
+    target set of SURVEY.md §8(d)."""
+    return np.stack([haar_unitary(seed0 + start + i) for i in range(n)])
+
+
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = 0x9E3779B9
+_PHILOX_W1 = 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32(ctr: np.ndarray, key: Tuple[int, int]) -> np.ndarray:
+    """Philox4x32-10 (Salmon et al., SC'11).  ctr: uint32[..., 4]; returns
+    uint32[..., 4].  Counter-based so CPU oracle and HIP kernel generate
+    identical multi-start seeds."""
+    c = [ctr[..., i].astype(np.uint64) for i in range(4)]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _PHILOX_M0 * c[0]
+        p1 = _PHILOX_M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0 = (k0 + _PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def x0_philox(seed: int, target_index: int, restart: int, k: int) -> np.ndarray:
+    """Multi-start seed x0 ~ U[0, 2pi)^n, the distribution of
+    ``CircuitTemplate.parameter_guess`` (src/slam/basis.py:106-111), drawn
+    from Philox4x32-10 keyed on ``seed`` with counter
+    (pair index, restart, target index, span k)."""
+    n = n_params(k)
+    pairs = n // 2
+    ctr = np.zeros((pairs, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(pairs, dtype=np.uint32)
+    ctr[:, 1] = np.uint32(restart)
+    ctr[:, 2] = np.uint32(target_index & 0xFFFFFFFF)
+    ctr[:, 3] = np.uint32(k)
+    w = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).astype(np.uint64)
+    u0 = ((w[:, 0] >> np.uint64(5)) * np.uint64(1 << 26) + (w[:, 1] >> np.uint64(6))).astype(
+        np.float64
+    ) * (1.0 / 9007199254740992.0)
+    u1 = ((w[:, 2] >> np.uint64(5)) * np.uint64(1 << 26) + (w[:, 3] >> np.uint64(6))).astype(
+        np.float64
+    ) * (1.0 / 9007199254740992.0)
+    x = np.empty(n)
+    x[0::2] = u0 * TWO_PI
+    x[1::2] = u1 * TWO_PI
+    return x
+
+
+# --------------------------------------------------------------------------
+# The optimizer loop
+# --------------------------------------------------------------------------
+
+SUCCESS_THRESHOLD = 1e-10  # src/slam/optimizer.py:18
+TRAINING_RESTARTS = 5  # src/slam/optimizer.py:19
+
+
+@dataclass
+class DataDictEntry:
+    """src/slam/basis_abc.py:93-98."""
+
+    success_label: int
+    loss_result: float
+    Xk: list
+    cycles: int
+
+
+def gate_sequence(base_gates: Sequence[np.ndarray], k: int) -> List[np.ndarray]:
+    """2Q gates of span k.  Deviation: the reference's
+    ``cycle(base_gates)`` (src/slam/basis.py:69,160) is never reset between
+    ``build`` calls; here the cycle restarts at every build:
+    [g0, g1, g0, ...][:k]."""
+    return [base_gates[i % len(base_gates)] for i in range(k)]
+
+
+def run_reference(
+    target: np.ndarray,
+    base_gates: Sequence[np.ndarray],
+    spanning_range: Iterable[int],
+    training_restarts: int = TRAINING_RESTARTS,
+    success_threshold: float = SUCCESS_THRESHOLD,
+    x0_fn: Optional[Callable[[int, int], np.ndarray]] = None,
+    analytic_jac: bool = False,
+    override_fail: bool = True,
+) -> Tuple[float, np.ndarray, int, dict]:
+    """``TemplateOptimizer._run`` src/slam/optimizer.py:188-313: spans x
+    restarts x ``scipy.optimize.minimize(method="BFGS", maxiter=2500)`` with no
+    ``jac`` (finite differences) unless ``analytic_jac``; best tracking
+    :281-284, early breaks :287-303.  ``x0_fn(k, r)`` replaces the unseeded
+    ``np.random.random(n)*2pi`` of src/slam/basis.py:111."""
+    best_result, best_Xk, best_cycles = None, None, -1
+    stats = {"nfev": 0, "nit": 0, "restarts": 0}
+    for k in spanning_range:
+        gs = gate_sequence(base_gates, k)
+        for r_i in range(training_restarts):
+            if x0_fn is None:
+                x0 = np.random.random(n_params(k)) * 2 * np.pi
+            else:
+                x0 = x0_fn(k, r_i)
+            if analytic_jac:
+                res = opt.minimize(
+                    fun=lambda xx: loss_and_grad(xx, gs, target),
+                    jac=True,
+                    method="BFGS",
+                    x0=x0,
+                    options={"maxiter": 2500},
+                )
+            else:
+                res = opt.minimize(
+                    fun=lambda xx: loss(xx, gs, target),
+                    method="BFGS",
+                    x0=x0,
+                    options={"maxiter": 2500},
+                )
+            stats["nfev"] += int(res.nfev)
+            stats["nit"] += int(res.nit)
+            stats["restarts"] += 1
+            if best_result is None or res.fun < best_result:
+                best_result, best_Xk, best_cycles = float(res.fun), res.x, k
+            if best_result < success_threshold:
+                break
+        if best_result < success_threshold:
+            break
+    return best_result, best_Xk, best_cycles, stats
+
+
+def approximate_target_U(
+    target: np.ndarray,
+    base_gates: Sequence[np.ndarray],
+    maximum_span_guess: int = 5,
+    training_restarts: int = TRAINING_RESTARTS,
+    success_threshold: float = SUCCESS_THRESHOLD,
+    override_fail: bool = False,
+    x0_fn=None,
+    analytic_jac: bool = False,
+) -> DataDictEntry:
+    """``TemplateOptimizer.approximate_target_U`` src/slam/optimizer.py:65-119
+    (no preseed path): success label uses ``<=`` (:80), failure raises
+    ``ValueError`` unless ``override_fail`` (:89-93)."""
+    best_result, best_Xk, best_cycles, _ = run_reference(
+        target,
+        base_gates,
+        range(1, maximum_span_guess + 1),
+        training_restarts,
+        success_threshold,
+        x0_fn=x0_fn,
+        analytic_jac=analytic_jac,
+    )
+    if best_result <= success_threshold:
+        label = 1
+    else:
+        if not override_fail:
+            raise ValueError(
+                "Failed to converge within error threshold. Try increasing restart attempts or increasing temperature scaling on preseed."
+            )
+        label = 0
+    return DataDictEntry(label, best_result, best_Xk, best_cycles)
