@@ -1,0 +1,19 @@
+# Build libslamhip.so (gfx950 only) and keep compiler temporaries under build/.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+SRC   := slam_decomposition_amd/csrc/slam_hip.hip
+HDRS  := slam_decomposition_amd/csrc/slam_device.hpp slam_decomposition_amd/csrc/slam_kernels.hpp include/slam_hip.h
+OUT   := slam_decomposition_amd/lib/libslamhip.so
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function
+
+all: $(OUT)
+
+$(OUT): $(SRC) $(HDRS)
+	mkdir -p build slam_decomposition_amd/lib
+	$(HIPCC) $(FLAGS) -save-temps=obj -Rpass-analysis=kernel-resource-usage -o build/libslamhip.so $(SRC) 2> build/resource_usage.txt || (cat build/resource_usage.txt; exit 1)
+	cp build/libslamhip.so $(OUT)
+
+clean:
+	rm -rf build $(OUT)
+
+.PHONY: all clean

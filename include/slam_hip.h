@@ -1,0 +1,185 @@
+/*
+ * slam_hip.h -- C ABI of libslamhip.so, the MI355X (gfx950) implementation of the
+ * SLAM template-optimizer inner loop.
+ *
+ * The reference (Pitt-JonesLab/slam_decomposition) is pure Python: there is no FFI
+ * today.  Each entry point below states the reference code it replaces
+ * (paths relative to the reference checkout).  Python binds these with ctypes
+ * (slam_decomposition_amd/_ffi.py); INTEGRATION.md shows the stub a maintainer of
+ * the reference would add to src/slam/optimizer.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-allocated, C-contiguous,
+ *     8-byte aligned host memory; the library never keeps a caller pointer after
+ *     the call returns.  Device buffers are owned by the context.
+ *   - complex matrices are row-major interleaved (re, im) doubles: a 4x4 matrix is
+ *     double[4][4][2] = 32 doubles.
+ *   - template parameters x are in index order P0..P{n-1}, n = 6(k+1): layer-major,
+ *     within a layer (theta, phi, lambda) of the qubit-0 U gate then of the qubit-1
+ *     U gate  (reference: src/slam/basis.py:152-169).
+ *   - functions return 0 on success or a negative SLAM_ERR_* code;
+ *     slam_last_error() gives the message for the calling thread.
+ *   - one context = one GPU = one host thread at a time.  Multi-GPU = one context
+ *     per device (one process per GPU in bench.py).
+ */
+#ifndef SLAM_HIP_H
+#define SLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_OK 0
+#define SLAM_ERR_INVALID (-1)     /* bad argument */
+#define SLAM_ERR_HIP (-2)         /* HIP runtime error (message has the HIP string) */
+#define SLAM_ERR_UNSUPPORTED (-3) /* e.g. span outside [1, SLAM_MAX_SPAN_MINIMIZE] */
+#define SLAM_ERR_NOMEM (-4)
+#define SLAM_ERR_STATE (-5)       /* call order: targets / basis not set */
+
+#define SLAM_MAX_SPAN_EVAL 5     /* reference default maximum_span_guess, src/slam/basis.py:59 */
+#define SLAM_MAX_SPAN_MINIMIZE 3 /* spans the in-register quasi-Newton kernel supports */
+#define SLAM_MAX_GATES 256
+
+/* per-item optimizer status (slam_minimize_stage: item_status) */
+#define SLAM_ST_CONVERGED 0 /* loss < stop_loss or |g|_inf < gtol */
+#define SLAM_ST_MAXITER 1   /* reference: options={"maxiter": 2500}, src/slam/optimizer.py:275 */
+#define SLAM_ST_LINESEARCH 2
+#define SLAM_ST_NONFINITE 3
+#define SLAM_ST_STALLED 4   /* no representable decrease (fp64 noise floor at a non-zero minimum) */
+#define SLAM_ST_PREEMPTED 5 /* a sibling restart of the same target reached stop_loss first
+                               (reference: break over restarts, src/slam/optimizer.py:287-295) */
+
+/* flags for slam_minimize_stage / slam_decompose */
+#define SLAM_FLAG_EARLY_EXIT 1u /* stop a target's other restarts once one reaches stop_loss */
+
+typedef struct slam_ctx slam_ctx;
+
+typedef struct slam_opt_params {
+    int32_t restarts;     /* R: multi-start seeds per target per span (TRAINING_RESTARTS, optimizer.py:19) */
+    int32_t maxiter;      /* per-restart iteration cap (optimizer.py:275: 2500) */
+    double gtol;          /* stop when |g|_inf < gtol (SciPy BFGS default 1e-5; we default 1e-9) */
+    double stop_loss;     /* stop when loss < stop_loss */
+    uint64_t seed;        /* Philox key for x0 ~ U[0,2pi)^n (basis.py:106-111) */
+    uint32_t flags;       /* SLAM_FLAG_* */
+    uint32_t reserved;
+} slam_opt_params;
+
+typedef struct slam_stats {
+    double kernel_ms;         /* sum of HIP-event durations of the minimize kernel launches */
+    int64_t kernel_launches;  /* number of minimize kernel launches */
+    int64_t evals[SLAM_MAX_SPAN_EVAL + 1]; /* fused loss+grad evaluations per span k (index k) */
+    int64_t items[SLAM_MAX_SPAN_EVAL + 1]; /* (target, seed) work items per span k */
+    double total_ms;          /* HIP-event time of the last slam_decompose / slam_minimize_stage */
+} slam_stats;
+
+/* Thread-local message of the last failing call on this thread. */
+const char* slam_last_error(void);
+
+/* Number of visible HIP devices. */
+int slam_device_count(int* count);
+
+/* Create / destroy a context bound to one device.  Creates a private HIP stream. */
+int slam_ctx_create(int device, slam_ctx** out);
+int slam_ctx_destroy(slam_ctx* ctx);
+
+/* Name and CU count of the context's device (name buffer >= 256 bytes). */
+int slam_ctx_device_info(slam_ctx* ctx, char* name, int name_len, int* compute_units, int* clock_khz);
+
+/*
+ * Upload the batch of target unitaries (resident in HBM until replaced).
+ * Replaces iterating the sampler one target at a time:
+ *   src/slam/optimizer.py:180-186 (approximate_from_distribution), src/slam/sampler.py:25-27.
+ * targets: double[n_targets][4][4][2].
+ */
+int slam_set_targets(slam_ctx* ctx, const double* targets, int64_t n_targets);
+
+/*
+ * Upload the table of 2Q basis-gate matrices (CircuitTemplate(base_gates=...),
+ * src/slam/basis.py:52-69; matrices from src/slam/utils/gates/custom_gates.py).
+ * gates: double[n_gates][4][4][2].
+ */
+int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates);
+
+/*
+ * Fused forward chain + BasicCost + analytic gradient for M independent items.
+ * Replaces objective_func (src/slam/optimizer.py:191-214) = CircuitTemplate.eval
+ * (src/slam/basis.py:102-104) + BasicCost.unitary_fidelity
+ * (src/slam/cost_function.py:140-145), and SciPy's finite-difference gradient
+ * (src/slam/optimizer.py:270-278, no jac) with the analytic one.
+ *   k          span (number of 2Q gates), 1..SLAM_MAX_SPAN_EVAL
+ *   gate_seq   int32[k]: index into the gate table for G_1..G_k
+ *   x          double[M][6(k+1)]
+ *   target_of  int32[M]: target index of each item
+ *   loss       double[M]           (out)
+ *   grad       double[M][6(k+1)]   (out, may be NULL)
+ */
+int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x,
+                        const int32_t* target_of, int64_t M, double* loss, double* grad);
+
+/*
+ * One span stage of TemplateOptimizer._run (src/slam/optimizer.py:233-303) for a
+ * batch: for every active target run `restarts` independent quasi-Newton (BFGS)
+ * minimisations from different seeds and return the best.
+ * Replaces the `for r_i in range(training_restarts): opt.minimize(...)` loop
+ * (optimizer.py:253-295) and parameter_guess (basis.py:106-111).
+ *   active        int32[n_active] target indices (NULL = all targets 0..n_targets-1)
+ *   x0            optional double[n_active][R][n] explicit seeds (NULL = Philox from params->seed,
+ *                 counter = (pair index, restart, target index, k))
+ *   best_loss     double[n_active]      (out)
+ *   best_x        double[n_active][n]   (out)
+ *   best_restart  int32[n_active]       (out, may be NULL)
+ *   item_loss     double[n_active][R]   (out, may be NULL)  per-restart final loss
+ *   item_iters    int32[n_active][R]    (out, may be NULL)
+ *   item_status   int32[n_active][R]    (out, may be NULL)  SLAM_ST_*
+ *   item_evals    int32[n_active][R]    (out, may be NULL)  loss+grad evaluations used
+ */
+int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active,
+                        int64_t n_active, const double* x0, const slam_opt_params* params,
+                        double* best_loss, double* best_x, int32_t* best_restart,
+                        double* item_loss, int32_t* item_iters, int32_t* item_status,
+                        int32_t* item_evals);
+
+/*
+ * The whole span loop of TemplateOptimizer._run for the resident batch
+ * (src/slam/optimizer.py:233-303): spans k = k_min..k_max; after each span the targets
+ * whose best loss is < success_threshold leave the batch (optimizer.py:301-303), the
+ * rest continue with the next span.  Compaction stays on the device; only the final
+ * per-target results return.
+ *   gate_seqs   int32[(k_max)(k_max+1)/2 ...] concatenated sequences for k = k_min..k_max
+ *               (k_min entries, then k_min+1, ...)
+ *   best_loss   double[n_targets]            (out)
+ *   best_x      double[n_targets][6(k_max+1)] (out; first 6(best_cycles+1) entries valid)
+ *   best_cycles int32[n_targets]             (out) span of the best result (optimizer.py:284)
+ */
+int slam_decompose(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs,
+                   const slam_opt_params* params, double success_threshold, double* best_loss,
+                   double* best_x, int32_t* best_cycles);
+
+/* Same as slam_decompose but leaves the results on the device (bench timing without D2H).
+ * Fetch them afterwards with slam_fetch_results. */
+int slam_decompose_resident(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs,
+                            const slam_opt_params* params, double success_threshold);
+int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best_x,
+                       int32_t* best_cycles);
+
+/* Block until all work queued on the context's stream has finished. */
+int slam_synchronize(slam_ctx* ctx);
+
+/* Accumulated kernel statistics since the last reset. */
+int slam_get_stats(slam_ctx* ctx, slam_stats* out);
+int slam_reset_stats(slam_ctx* ctx);
+
+/* Device pointer + byte size of the resident per-target best-loss array
+ * (double[n_targets]); used by the multi-GPU merge to hand the buffer to RCCL
+ * without a host round trip. */
+int slam_best_loss_device_ptr(slam_ctx* ctx, void** ptr, int64_t* n);
+
+/* Library version string. */
+const char* slam_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_HIP_H */

@@ -22,7 +22,8 @@ import numpy as np
 from . import slam_oracle as o
 
 ARMIJO_C1 = 1e-4
-MAX_BACKTRACK = 12
+MAX_BACKTRACK = 20
+STEP_MAX = 2.0  # cap on |alpha p|_2 of the first trial step (parameters are angles)
 CURV_EPS = 1e-10
 STALL_DF = 1e-15
 STALL_GNORM = 1e-5
@@ -41,6 +42,7 @@ def minimize_port(x0, gate_seq, target, maxiter=2500, gtol=1e-9, stop_loss=1e-13
     it = 0
     nback = 0
     nstall = 0
+    scaled = False
     status = 1
     if not np.isfinite(f):
         return f, x, 0, 3, nev
@@ -64,9 +66,11 @@ def minimize_port(x0, gate_seq, target, maxiter=2500, gtol=1e-9, stop_loss=1e-13
             sy = s @ y
             if sy > CURV_EPS * np.sqrt((s @ s) * (y @ y)):
                 rho = 1.0 / sy
-                if it == 0:
-                    # scale the initial inverse Hessian (Nocedal & Wright eq. 6.20)
+                if not scaled:
+                    # scale the initial inverse Hessian before its first update
+                    # (Nocedal & Wright eq. 6.20)
                     H = H * (sy / (y @ y))
+                    scaled = True
                 u = H @ y
                 c = rho * (1.0 + rho * (y @ u))
                 H = H + c * np.outer(s, s) - rho * (np.outer(s, u) + np.outer(u, s))
@@ -84,7 +88,7 @@ def minimize_port(x0, gate_seq, target, maxiter=2500, gtol=1e-9, stop_loss=1e-13
                 status = 4
                 break
             p = -(H @ g)
-            alpha = 1.0
+            alpha = min(1.0, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
         else:
             # safeguarded quadratic interpolation backtrack
             denom = 2.0 * (ft - f - gp * alpha)

@@ -1,0 +1,296 @@
+"""ctypes binding of ``libslamhip.so`` (C ABI: ``include/slam_hip.h``).
+
+No torch, no NumPy-on-CPU fallback: if the shared library is missing or no GPU
+is usable every entry point raises -- the product path never computes on the
+host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libslamhip.so")
+
+MAX_SPAN_EVAL = 5
+MAX_SPAN_MINIMIZE = 3
+
+ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED = range(6)
+FLAG_EARLY_EXIT = 1
+
+# every symbol include/slam_hip.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = (
+    "slam_last_error",
+    "slam_version",
+    "slam_device_count",
+    "slam_ctx_create",
+    "slam_ctx_destroy",
+    "slam_ctx_device_info",
+    "slam_set_targets",
+    "slam_set_gates",
+    "slam_eval_loss_grad",
+    "slam_minimize_stage",
+    "slam_decompose",
+    "slam_decompose_resident",
+    "slam_fetch_results",
+    "slam_synchronize",
+    "slam_get_stats",
+    "slam_reset_stats",
+    "slam_best_loss_device_ptr",
+)
+
+
+class SlamHipError(RuntimeError):
+    """A libslamhip call returned a negative SLAM_ERR_* code."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libslamhip error {code}: {message}")
+        self.code = code
+
+
+class OptParams(C.Structure):
+    _fields_ = [
+        ("restarts", C.c_int32),
+        ("maxiter", C.c_int32),
+        ("gtol", C.c_double),
+        ("stop_loss", C.c_double),
+        ("seed", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("kernel_ms", C.c_double),
+        ("kernel_launches", C.c_int64),
+        ("evals", C.c_int64 * (MAX_SPAN_EVAL + 1)),
+        ("items", C.c_int64 * (MAX_SPAN_EVAL + 1)),
+        ("total_ms", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libslamhip.so (built in-tree by ``__graft_entry__.build()`` / ``make``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make` (hipcc --offload-arch=gfx950); "
+            "slam_decomposition_amd has no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    dp = np.ctypeslib.ndpointer
+    lib.slam_last_error.restype = C.c_char_p
+    lib.slam_version.restype = C.c_char_p
+    lib.slam_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.slam_ctx_create.argtypes = [C.c_int, C.POINTER(P)]
+    lib.slam_ctx_destroy.argtypes = [P]
+    lib.slam_ctx_device_info.argtypes = [P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.slam_set_targets.argtypes = [P, P, C.c_int64]
+    lib.slam_set_gates.argtypes = [P, P, C.c_int32]
+    lib.slam_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P]
+    lib.slam_minimize_stage.argtypes = [P, C.c_int, P, P, C.c_int64, P, C.POINTER(OptParams)] + [P] * 7
+    lib.slam_decompose.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P, P]
+    lib.slam_decompose_resident.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
+    lib.slam_fetch_results.argtypes = [P, C.c_int, P, P, P]
+    lib.slam_synchronize.argtypes = [P]
+    lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
+    lib.slam_reset_stats.argtypes = [P]
+    lib.slam_best_loss_device_ptr.argtypes = [P, C.POINTER(P), C.POINTER(C.c_int64)]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("slam_last_error", "slam_version"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise SlamHipError(rc, load_library().slam_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _mat_to_ri(mats: np.ndarray) -> np.ndarray:
+    """complex128[..., 4, 4] -> float64[..., 4, 4, 2] (row-major re, im), contiguous."""
+    m = np.ascontiguousarray(np.asarray(mats, dtype=np.complex128))
+    if m.shape[-2:] != (4, 4):
+        raise ValueError(f"expected 4x4 matrices, got shape {m.shape}")
+    return m.view(np.float64).reshape(m.shape + (2,))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(load_library().slam_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    """One GPU: resident targets + gate table + work buffers (``slam_ctx``)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _check(self._lib.slam_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self.n_targets = 0
+        self.n_gates = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.slam_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- residency -------------------------------------------------------
+    def device_info(self) -> Tuple[str, int, int]:
+        buf = C.create_string_buffer(256)
+        cu, khz = C.c_int(0), C.c_int(0)
+        _check(self._lib.slam_ctx_device_info(self._h, buf, 256, C.byref(cu), C.byref(khz)))
+        return buf.value.decode(), cu.value, khz.value
+
+    def set_targets(self, targets: np.ndarray) -> None:
+        t = _mat_to_ri(targets)
+        if t.ndim != 4:
+            raise ValueError("targets must have shape [N, 4, 4]")
+        _check(self._lib.slam_set_targets(self._h, _ptr(t), t.shape[0]))
+        self.n_targets = t.shape[0]
+
+    def set_gates(self, gates: np.ndarray) -> None:
+        g = _mat_to_ri(gates)
+        if g.ndim != 4:
+            raise ValueError("gates must have shape [G, 4, 4]")
+        _check(self._lib.slam_set_gates(self._h, _ptr(g), g.shape[0]))
+        self.n_gates = g.shape[0]
+
+    # -- fused loss + gradient -------------------------------------------
+    def eval_loss_grad(self, gate_seq: Sequence[int], x: np.ndarray, target_of: np.ndarray, want_grad=True):
+        k = len(gate_seq)
+        n = 6 * (k + 1)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != n:
+            raise ValueError(f"x must have shape [M, {n}]")
+        M = x.shape[0]
+        tof = np.ascontiguousarray(target_of, dtype=np.int32)
+        if tof.shape != (M,):
+            raise ValueError("target_of must have shape [M]")
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        loss = np.empty(M, dtype=np.float64)
+        grad = np.empty((M, n), dtype=np.float64) if want_grad else None
+        _check(self._lib.slam_eval_loss_grad(self._h, k, _ptr(gs), _ptr(x), _ptr(tof), M, _ptr(loss), _ptr(grad)))
+        return loss, grad
+
+    # -- one span stage ----------------------------------------------------
+    def minimize_stage(
+        self,
+        gate_seq: Sequence[int],
+        params: OptParams,
+        active: Optional[np.ndarray] = None,
+        x0: Optional[np.ndarray] = None,
+        want_items: bool = True,
+    ) -> dict:
+        k = len(gate_seq)
+        n = 6 * (k + 1)
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        if active is not None:
+            active = np.ascontiguousarray(active, dtype=np.int32)
+            na = active.shape[0]
+        else:
+            na = self.n_targets
+        R = int(params.restarts)
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            if x0.shape != (na, R, n):
+                raise ValueError(f"x0 must have shape [{na}, {R}, {n}]")
+        out = {
+            "best_loss": np.empty(na, dtype=np.float64),
+            "best_x": np.empty((na, n), dtype=np.float64),
+            "best_restart": np.empty(na, dtype=np.int32),
+        }
+        if want_items:
+            out["item_loss"] = np.empty((na, R), dtype=np.float64)
+            out["item_iters"] = np.empty((na, R), dtype=np.int32)
+            out["item_status"] = np.empty((na, R), dtype=np.int32)
+            out["item_evals"] = np.empty((na, R), dtype=np.int32)
+        _check(
+            self._lib.slam_minimize_stage(
+                self._h, k, _ptr(gs), _ptr(active), na, _ptr(x0), C.byref(params),
+                _ptr(out["best_loss"]), _ptr(out["best_x"]), _ptr(out["best_restart"]),
+                _ptr(out.get("item_loss")), _ptr(out.get("item_iters")), _ptr(out.get("item_status")),
+                _ptr(out.get("item_evals")),
+            )
+        )
+        return out
+
+    # -- the whole span loop -------------------------------------------------
+    @staticmethod
+    def _flat_gate_seqs(gate_seqs: Sequence[Sequence[int]], k_min: int, k_max: int) -> np.ndarray:
+        if len(gate_seqs) != k_max - k_min + 1:
+            raise ValueError("need one gate sequence per span")
+        flat = []
+        for k, gs in zip(range(k_min, k_max + 1), gate_seqs):
+            if len(gs) != k:
+                raise ValueError(f"gate sequence for span {k} has length {len(gs)}")
+            flat.extend(int(g) for g in gs)
+        return np.asarray(flat, dtype=np.int32)
+
+    def decompose(self, k_min, k_max, gate_seqs, params: OptParams, success_threshold: float, fetch=True):
+        flat = self._flat_gate_seqs(gate_seqs, k_min, k_max)
+        _check(self._lib.slam_decompose_resident(self._h, k_min, k_max, _ptr(flat), C.byref(params), float(success_threshold)))
+        if fetch:
+            return self.fetch_results(k_max)
+        return None
+
+    def fetch_results(self, k_max: int):
+        nmax = 6 * (k_max + 1)
+        N = self.n_targets
+        best_loss = np.empty(N, dtype=np.float64)
+        best_x = np.zeros((N, nmax), dtype=np.float64)
+        best_cycles = np.empty(N, dtype=np.int32)
+        _check(self._lib.slam_fetch_results(self._h, k_max, _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
+        return best_loss, best_x, best_cycles
+
+    def synchronize(self) -> None:
+        _check(self._lib.slam_synchronize(self._h))
+
+    def stats(self) -> dict:
+        s = Stats()
+        _check(self._lib.slam_get_stats(self._h, C.byref(s)))
+        return {
+            "kernel_ms": s.kernel_ms,
+            "kernel_launches": s.kernel_launches,
+            "evals": list(s.evals),
+            "items": list(s.items),
+            "total_ms": s.total_ms,
+        }
+
+    def reset_stats(self) -> None:
+        _check(self._lib.slam_reset_stats(self._h))
+
+    def best_loss_device_ptr(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_int64(0)
+        _check(self._lib.slam_best_loss_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)

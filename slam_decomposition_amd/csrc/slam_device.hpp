@@ -1,0 +1,431 @@
+// slam_device.hpp -- device-side building blocks of the SLAM template optimizer for gfx950.
+//
+// Work decomposition:
+//   * a QUAD (4 adjacent lanes) owns one (target, seed) work item; a 64-lane wavefront
+//     carries 16 quads -- with R = 16 restarts that is exactly one target per wavefront;
+//   * lane c of the quad owns COLUMN c of the running 4x4 product: columns of
+//     W = K_k G_k ... G_1 K_0 evolve independently under left multiplication, so the
+//     forward chain needs no cross-lane traffic; rows of (z T^+)(suffix) evolve
+//     independently under right multiplication, so the backward chain needs none either;
+//   * the only exchanges are quad reductions (DPP quad_perm shuffles) and small
+//     transposes through an LDS exchange area;
+//   * the n x n inverse-Hessian approximation lives in registers as packed symmetric
+//     4x4 blocks: lane q holds row q of every upper-triangle block.
+//
+// Reference behaviour being computed (paths relative to the reference checkout):
+//   CircuitTemplate.eval            src/slam/basis.py:102-104,124-169
+//   BasicCost.unitary_fidelity      src/slam/cost_function.py:140-145
+//   scipy BFGS restart loop         src/slam/optimizer.py:253-295
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slamdev {
+
+constexpr int kQuadsPerWave = 16;
+constexpr int kWave = 64;
+
+template <int K>
+struct Cfg {
+    static constexpr int L = K + 1;                    // 1Q layers
+    static constexpr int N = 6 * L;                    // parameters (basis.py:152-169)
+    static constexpr int NA = (N + 3) / 4;             // parameter slots per lane
+    static constexpr int NP = NA * 4;                  // padded parameter count
+    static constexpr int NBLK = NA * (NA + 1) / 2;     // upper-triangle 4x4 blocks of H
+    static constexpr int XSTRIDE = NP * 4 + 4;         // doubles per quad in the exchange area
+    static constexpr int LDS_GATES = K * 32;           // doubles
+    static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
+    static constexpr int LDS_FH = 2 * K * 4 * kWave * 2;  // 2K column vectors x 4 rows x 64 lanes x (re,im)
+    static constexpr int LDS_DOUBLES = LDS_GATES + LDS_XCHG + LDS_FH;
+};
+
+// ---------------------------------------------------------------------------------
+// quad (4-lane) cross-lane primitives: DPP quad_perm on the two 32-bit halves
+// ---------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2)
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ double quad_max(double v) {
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    return v;
+}
+
+// All LDS traffic is wave-private (one wavefront per workgroup); LDS instructions of a
+// wave execute in order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void lds_fence() { __syncthreads(); }
+
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 (must match oracle/slam_oracle.py:philox4x32 / x0_philox bit for bit)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// x0[i] ~ U[0, 2pi): parameter i of (seed, target index, restart, span k)
+__device__ __forceinline__ double x0_philox(uint64_t seed, uint32_t target, uint32_t restart, uint32_t k,
+                                            uint32_t i) {
+    uint32_t w[4];
+    philox4x32_10(i >> 1, restart, target, k, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    const uint32_t a = (i & 1) ? w[2] : w[0];
+    const uint32_t b = (i & 1) ? w[3] : w[1];
+    const uint64_t m = ((uint64_t)(a >> 5) << 26) + (uint64_t)(b >> 6);
+    return (double)m * (1.0 / 9007199254740992.0) * 6.283185307179586476925286766559;
+}
+
+// ---------------------------------------------------------------------------------
+// U3 action on a pair of complex amplitudes
+// U3 = diag(1, e^{i phi}) R(theta/2) diag(1, e^{i lam}),  R = [[c, -s], [s, c]]
+// ---------------------------------------------------------------------------------
+struct U3t {
+    double c, s;    // cos(theta/2), sin(theta/2)
+    double cp, sp;  // cos(phi), sin(phi)
+    double cl, sl;  // cos(lam), sin(lam)
+};
+
+// trig table entry i of this quad: (cos, sin) of the (half-)angle of parameter i
+__device__ __forceinline__ U3t load_u3(const double* xq, int base_param) {
+    const double2* t = reinterpret_cast<const double2*>(xq) + base_param;
+    const double2 a = t[0], b = t[1], c = t[2];
+    U3t u;
+    u.c = a.x; u.s = a.y; u.cp = b.x; u.sp = b.y; u.cl = c.x; u.sl = c.y;
+    return u;
+}
+
+// column action: (f0, f1)^T <- U3 (f0, f1)^T
+__device__ __forceinline__ void u3_col(const U3t& t, double& f0r, double& f0i, double& f1r, double& f1i) {
+    const double g1r = t.cl * f1r - t.sl * f1i;
+    const double g1i = t.cl * f1i + t.sl * f1r;
+    const double y0r = t.c * f0r - t.s * g1r;
+    const double y0i = t.c * f0i - t.s * g1i;
+    const double tr = t.s * f0r + t.c * g1r;
+    const double ti = t.s * f0i + t.c * g1i;
+    f0r = y0r; f0i = y0i;
+    f1r = t.cp * tr - t.sp * ti;
+    f1i = t.cp * ti + t.sp * tr;
+}
+
+// row action: (u0, u1) <- (u0, u1) U3
+__device__ __forceinline__ void u3_row(const U3t& t, double& u0r, double& u0i, double& u1r, double& u1i) {
+    const double g1r = t.cp * u1r - t.sp * u1i;
+    const double g1i = t.cp * u1i + t.sp * u1r;
+    const double n0r = t.c * u0r + t.s * g1r;
+    const double n0i = t.c * u0i + t.s * g1i;
+    const double tr = t.c * g1r - t.s * u0r;
+    const double ti = t.c * g1i - t.s * u0i;
+    u0r = n0r; u0i = n0i;
+    u1r = t.cl * tr - t.sl * ti;
+    u1i = t.cl * ti + t.sl * tr;
+}
+
+// d/dtheta contribution: 1/2 Re( ut1 e^{-i lam} f0 - ut0 e^{i lam} f1 )
+// (dU/dtheta = 1/2 U M, M = [[0, -e^{i lam}], [e^{-i lam}, 0]])
+__device__ __forceinline__ double dtheta_pair(const U3t& t, double ut0r, double ut0i, double ut1r, double ut1i,
+                                              double f0r, double f0i, double f1r, double f1i) {
+    // a = ut1 * f0, b = ut0 * f1
+    const double ar = ut1r * f0r - ut1i * f0i, ai = ut1r * f0i + ut1i * f0r;
+    const double br = ut0r * f1r - ut0i * f1i, bi = ut0r * f1i + ut0i * f1r;
+    // Re(e^{-i lam} a) = cl*ar + sl*ai ; Re(e^{i lam} b) = cl*br - sl*bi
+    return 0.5 * ((t.cl * ar + t.sl * ai) - (t.cl * br - t.sl * bi));
+}
+
+__device__ __forceinline__ double im_mul(double ar, double ai, double br, double bi) { return ar * bi + ai * br; }
+
+// ---------------------------------------------------------------------------------
+// Fused forward chain + BasicCost + analytic gradient for the quad's item.
+//   xd    this lane's parameter slots: xd[a] = x[4a + q]
+//   tre/tim  column c = q of the target: T[r][c], r = 0..3
+//   gl    LDS: gate matrices G_1..G_K, row-major (re, im)
+//   xq    LDS: this quad's exchange area (trig table, then gradient transpose)
+//   fh    LDS: this lane's slice of the stored column vectors (stride 64 double2 per row)
+// Returns loss (replicated over the quad) and gd[a] = dloss/dx[4a + q].
+// ---------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double (&tre)[4],
+                                          const double (&tim)[4], const double* gl, double* xq, double2* fh,
+                                          int q, double& fout, double (&gd)[Cfg<K>::NA]) {
+    using C = Cfg<K>;
+    // ---- 1. trig table: each lane handles its own parameter slots
+    {
+        double2* t2 = reinterpret_cast<double2*>(xq);
+#pragma unroll
+        for (int a = 0; a < C::NA; ++a) {
+            const int i = 4 * a + q;
+            const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
+            const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
+            double s, c;
+            sincos(arg, &s, &c);
+            t2[i] = make_double2(c, s);
+        }
+    }
+    lds_fence();
+
+    // ---- 2. forward: F = column q of the running product
+    double Fr[4], Fi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Fr[r] = (r == q) ? 1.0 : 0.0;
+        Fi[r] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j <= K; ++j) {
+        if (j > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fh[((2 * (j - 1)) * 4 + r) * kWave] = make_double2(Fr[r], Fi[r]);
+        }
+        const U3t B = load_u3(xq, 6 * j);      // qubit 0 gate
+        const U3t A = load_u3(xq, 6 * j + 3);  // qubit 1 gate
+        u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
+        u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
+        u3_col(A, Fr[0], Fi[0], Fr[2], Fi[2]);
+        u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
+        if (j < K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fh[((2 * j + 1) * 4 + r) * kWave] = make_double2(Fr[r], Fi[r]);
+            // F <- G_{j+1} F
+            const double2* G = reinterpret_cast<const double2*>(gl) + j * 16;
+            double nr[4], ni[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double ar = 0.0, ai = 0.0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double2 g = G[r * 4 + s];
+                    ar = fma(g.x, Fr[s], fma(-g.y, Fi[s], ar));
+                    ai = fma(g.x, Fi[s], fma(g.y, Fr[s], ai));
+                }
+                nr[r] = ar; ni[r] = ai;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Fr[r] = nr[r]; Fi[r] = ni[r]; }
+        }
+    }
+
+    // ---- 3. t = Tr(T^+ W), loss, z = -conj(t) / (4|t|)
+    double pr = 0.0, pi = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pr = fma(tre[r], Fr[r], fma(tim[r], Fi[r], pr));
+        pi = fma(tre[r], Fi[r], fma(-tim[r], Fr[r], pi));
+    }
+    pr = quad_sum(pr);
+    pi = quad_sum(pi);
+    const double at = sqrt(pr * pr + pi * pi);
+    fout = 1.0 - 0.25 * at;
+    const double inv = (at > 1e-300) ? 0.25 / at : 0.0;
+    const double zr = -pr * inv, zi = pi * inv;
+
+    // ---- 4. backward: u = row q of (z T^+)(suffix); accumulate this column's partials
+    double Ur[4], Ui[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Ur[r] = zr * tre[r] + zi * tim[r];
+        Ui[r] = zi * tre[r] - zr * tim[r];
+    }
+    double part[C::N];
+    // h = output of the current layer (registers for j = K)
+    double Hr[4], Hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Hr[r] = Fr[r]; Hi[r] = Fi[r]; }
+#pragma unroll
+    for (int j = K; j >= 0; --j) {
+        if (j < K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 v = fh[((2 * j + 1) * 4 + r) * kWave];
+                Hr[r] = v.x; Hi[r] = v.y;
+            }
+        }
+        const U3t B = load_u3(xq, 6 * j);
+        const U3t A = load_u3(xq, 6 * j + 3);
+        // phi: dU/dphi = i diag(0,1) U  ->  -Im( sum over rows with that qubit's bit set of u*h )
+        const double m1 = im_mul(Ur[1], Ui[1], Hr[1], Hi[1]);
+        const double m2 = im_mul(Ur[2], Ui[2], Hr[2], Hi[2]);
+        const double m3 = im_mul(Ur[3], Ui[3], Hr[3], Hi[3]);
+        part[6 * j + 1] = -(m1 + m3);  // qubit 0: rows 1, 3
+        part[6 * j + 4] = -(m2 + m3);  // qubit 1: rows 2, 3
+        // u~ = u K_j
+        u3_row(A, Ur[0], Ui[0], Ur[2], Ui[2]);
+        u3_row(A, Ur[1], Ui[1], Ur[3], Ui[3]);
+        u3_row(B, Ur[0], Ui[0], Ur[1], Ui[1]);
+        u3_row(B, Ur[2], Ui[2], Ur[3], Ui[3]);
+        // f = input of layer j
+        double fr[4], fi[4];
+        if (j > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 v = fh[((2 * (j - 1)) * 4 + r) * kWave];
+                fr[r] = v.x; fi[r] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { fr[r] = (r == q) ? 1.0 : 0.0; fi[r] = 0.0; }
+        }
+        // lambda: dU/dlam = U i diag(0,1)
+        const double l1 = im_mul(Ur[1], Ui[1], fr[1], fi[1]);
+        const double l2 = im_mul(Ur[2], Ui[2], fr[2], fi[2]);
+        const double l3 = im_mul(Ur[3], Ui[3], fr[3], fi[3]);
+        part[6 * j + 2] = -(l1 + l3);
+        part[6 * j + 5] = -(l2 + l3);
+        // theta
+        part[6 * j + 0] = dtheta_pair(B, Ur[0], Ui[0], Ur[1], Ui[1], fr[0], fi[0], fr[1], fi[1]) +
+                          dtheta_pair(B, Ur[2], Ui[2], Ur[3], Ui[3], fr[2], fi[2], fr[3], fi[3]);
+        part[6 * j + 3] = dtheta_pair(A, Ur[0], Ui[0], Ur[2], Ui[2], fr[0], fi[0], fr[2], fi[2]) +
+                          dtheta_pair(A, Ur[1], Ui[1], Ur[3], Ui[3], fr[1], fi[1], fr[3], fi[3]);
+        if (j > 0) {
+            // u <- u~ G_j
+            const double2* G = reinterpret_cast<const double2*>(gl) + (j - 1) * 16;
+            double nr[4], ni[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { nr[s] = 0.0; ni[s] = 0.0; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double2 g = G[r * 4 + s];
+                    nr[s] = fma(Ur[r], g.x, fma(-Ui[r], g.y, nr[s]));
+                    ni[s] = fma(Ur[r], g.y, fma(Ui[r], g.x, ni[s]));
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { Ur[s] = nr[s]; Ui[s] = ni[s]; }
+        }
+    }
+
+    // ---- 5. sum the 4 columns' partials and hand parameter i to lane i & 3
+    lds_fence();
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) xq[4 * i + q] = part[i];
+    lds_fence();
+#pragma unroll
+    for (int a = 0; a < C::NA; ++a) {
+        const int i = 4 * a + q;
+        const double2* p2 = reinterpret_cast<const double2*>(xq + 4 * i);
+        const double2 v0 = p2[0], v1 = p2[1];
+        const double sum = (v0.x + v0.y) + (v1.x + v1.y);
+        gd[a] = (i < C::N) ? sum : 0.0;
+    }
+    lds_fence();
+}
+
+// ---------------------------------------------------------------------------------
+// Packed symmetric inverse Hessian in registers: block (a, b), a <= b, index b(b+1)/2 + a;
+// lane q holds H[4a + q][4b + beta], beta = 0..3.
+// ---------------------------------------------------------------------------------
+__host__ __device__ constexpr int blk(int a, int b) { return b * (b + 1) / 2 + a; }
+
+template <int NA>
+__device__ __forceinline__ void h_set_identity(double (&H)[NA * (NA + 1) / 2][4], int q) {
+#pragma unroll
+    for (int b = 0; b < NA; ++b)
+#pragma unroll
+        for (int a = 0; a <= b; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) H[blk(a, b)][e] = (a == b && e == q) ? 1.0 : 0.0;
+}
+
+// out = H v  (v, out distributed: slot a of lane q = component 4a + q)
+template <int NA>
+__device__ __forceinline__ void h_matvec(const double (&H)[NA * (NA + 1) / 2][4], const double (&vd)[NA],
+                                         double* xq, int q, double (&out)[NA]) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) xq[4 * a + q] = vd[a];
+    lds_fence();
+    double accT[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        out[a] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accT[a][e] = 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b < NA; ++b) {
+        const double2* p2 = reinterpret_cast<const double2*>(xq + 4 * b);
+        const double2 v01 = p2[0], v23 = p2[1];
+        const double vb[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+        for (int a = 0; a <= b; ++a) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[a] = fma(H[blk(a, b)][e], vb[e], out[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < b; ++a) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accT[b][e] = fma(H[blk(a, b)][e], vd[a], accT[b][e]);
+        }
+    }
+    lds_fence();
+    // transpose-reduce accT[b][e] (held by lane q) into lane e, slot b
+#pragma unroll
+    for (int b = 1; b < NA; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xq[(4 * b + e) * 4 + q] = accT[b][e];
+    lds_fence();
+#pragma unroll
+    for (int b = 1; b < NA; ++b) {
+        const double2* p2 = reinterpret_cast<const double2*>(xq + (4 * b + q) * 4);
+        const double2 v0 = p2[0], v1 = p2[1];
+        out[b] += (v0.x + v0.y) + (v1.x + v1.y);
+    }
+    lds_fence();
+}
+
+// H += s w^T + v s^T  (rank-2 BFGS inverse update), s, w, v distributed
+template <int NA>
+__device__ __forceinline__ void h_update(double (&H)[NA * (NA + 1) / 2][4], const double (&sd)[NA],
+                                         const double (&wd)[NA], const double (&vd)[NA], double* xq, int q) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        xq[4 * a + q] = wd[a];
+        xq[4 * NA + 4 * a + q] = sd[a];
+    }
+    lds_fence();
+#pragma unroll
+    for (int b = 0; b < NA; ++b) {
+        const double2* pw = reinterpret_cast<const double2*>(xq + 4 * b);
+        const double2* ps = reinterpret_cast<const double2*>(xq + 4 * NA + 4 * b);
+        const double2 w01 = pw[0], w23 = pw[1], s01 = ps[0], s23 = ps[1];
+        const double wb[4] = {w01.x, w01.y, w23.x, w23.y};
+        const double sb[4] = {s01.x, s01.y, s23.x, s23.y};
+#pragma unroll
+        for (int a = 0; a <= b; ++a) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                H[blk(a, b)][e] = fma(sd[a], wb[e], fma(vd[a], sb[e], H[blk(a, b)][e]));
+        }
+    }
+    lds_fence();
+}
+
+template <int NA>
+__device__ __forceinline__ double qdot(const double (&a)[NA], const double (&b)[NA]) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s = fma(a[i], b[i], s);
+    return quad_sum(s);
+}
+
+}  // namespace slamdev

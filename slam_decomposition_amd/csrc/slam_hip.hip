@@ -1,0 +1,551 @@
+// slam_hip.hip -- host side of libslamhip.so: the C ABI declared in include/slam_hip.h.
+// gfx950 only; no torch, no CUDA compatibility layer.
+#include "../../include/slam_hip.h"
+#include "slam_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace slamdev;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(SLAM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct slam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;   // kernel bracket
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; // whole-call bracket
+    int64_t n_targets = 0;
+    int32_t n_gates = 0;
+    DevBuf targets, gates;
+    // stage work buffers
+    DevBuf active, active2, x0;
+    DevBuf item_loss, item_x, item_iters, item_status, item_evals;
+    DevBuf stage_loss, stage_x, stage_restart;
+    // decompose results
+    DevBuf best_loss, best_x, best_cycles;
+    int32_t result_nmax = 0;
+    DevBuf counters;  // [0]: eval counter (u64), [1]: n_out (i32)
+    // eval buffers
+    DevBuf ev_x, ev_tof, ev_loss, ev_grad;
+    slam_stats stats{};
+    bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][2] = {};
+
+    ~slam_ctx() {
+        DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
+                         &item_status, &item_evals, &stage_loss, &stage_x, &stage_restart, &best_loss,
+                         &best_x, &best_cycles, &counters, &ev_x, &ev_tof, &ev_loss, &ev_grad};
+        for (DevBuf* b : all) b->release();
+        if (ev_a) (void)hipEventDestroy(ev_a);
+        if (ev_b) (void)hipEventDestroy(ev_b);
+        if (ev_t0) (void)hipEventDestroy(ev_t0);
+        if (ev_t1) (void)hipEventDestroy(ev_t1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+template <int K>
+constexpr size_t lds_bytes() { return sizeof(double) * Cfg<K>::LDS_DOUBLES; }
+
+template <int K>
+int launch_eval(slam_ctx* c, const EvalArgs& a) {
+    const size_t lds = lds_bytes<K>();
+    if (!c->max_lds_set[K][0]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_kernel<K>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->max_lds_set[K][0] = true;
+    }
+    const int64_t blocks = (a.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    hipLaunchKernelGGL(eval_kernel<K>, dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+template <int K>
+int launch_minimize(slam_ctx* c, const MinimizeArgs& a) {
+    const size_t lds = lds_bytes<K>();
+    if (!c->max_lds_set[K][1]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_kernel<K>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->max_lds_set[K][1] = true;
+    }
+    const int64_t blocks = (a.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    HIP_TRY(hipEventRecord(c->ev_a, c->stream));
+    hipLaunchKernelGGL(minimize_kernel<K>, dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_b, c->stream));
+    return SLAM_OK;
+}
+
+int check_gate_seq(slam_ctx* c, int k, const int32_t* gate_seq) {
+    if (!gate_seq) return fail(SLAM_ERR_INVALID, "gate_seq is NULL");
+    for (int j = 0; j < k; ++j)
+        if (gate_seq[j] < 0 || gate_seq[j] >= c->n_gates)
+            return fail(SLAM_ERR_INVALID, "gate_seq[%d] = %d outside the gate table (n_gates = %d)", j,
+                        gate_seq[j], c->n_gates);
+    return SLAM_OK;
+}
+
+int check_params(const slam_opt_params* p) {
+    if (!p) return fail(SLAM_ERR_INVALID, "params is NULL");
+    if (p->restarts <= 0) return fail(SLAM_ERR_INVALID, "restarts must be > 0 (got %d)", p->restarts);
+    if (p->maxiter < 0) return fail(SLAM_ERR_INVALID, "maxiter must be >= 0 (got %d)", p->maxiter);
+    return SLAM_OK;
+}
+
+// Runs one span stage for the device-resident active list (d_active may be nullptr = identity).
+// Leaves per-slot results in ctx->stage_loss / stage_x / stage_restart and per-item arrays.
+int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_active, int64_t n_active,
+              const double* d_x0, const slam_opt_params* prm) {
+    const int n = 6 * (k + 1);
+    const int64_t M = n_active * (int64_t)prm->restarts;
+    if (M <= 0) return SLAM_OK;
+    if (M / kQuadsPerWave + 1 > 0x7fffffffLL) return fail(SLAM_ERR_INVALID, "too many work items (%lld)", (long long)M);
+    HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
+    HIP_TRY(c->item_x.reserve(M * n * sizeof(double)));
+    HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->stage_loss.reserve(n_active * sizeof(double)));
+    HIP_TRY(c->stage_x.reserve(n_active * n * sizeof(double)));
+    HIP_TRY(c->stage_restart.reserve(n_active * sizeof(int32_t)));
+
+    MinimizeArgs a{};
+    a.targets = c->targets.as<double>();
+    a.gates = c->gates.as<double>();
+    a.active = d_active;
+    a.x0 = d_x0;
+    a.n_items = M;
+    a.restarts = prm->restarts;
+    a.maxiter = prm->maxiter;
+    a.gtol = prm->gtol;
+    a.stop_loss = prm->stop_loss;
+    a.seed = prm->seed;
+    a.flags = prm->flags;
+    for (int j = 0; j < k; ++j) a.gate_seq[j] = gate_seq[j];
+    a.item_loss = c->item_loss.as<double>();
+    a.item_x = c->item_x.as<double>();
+    a.item_iters = c->item_iters.as<int32_t>();
+    a.item_status = c->item_status.as<int32_t>();
+    a.item_evals = c->item_evals.as<int32_t>();
+
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8, c->stream));
+    int rc;
+    switch (k) {
+        case 1: rc = launch_minimize<1>(c, a); break;
+        case 2: rc = launch_minimize<2>(c, a); break;
+        case 3: rc = launch_minimize<3>(c, a); break;
+        default: return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
+    }
+    if (rc != SLAM_OK) return rc;
+
+    ReduceArgs r{};
+    r.item_loss = a.item_loss;
+    r.item_x = a.item_x;
+    r.item_evals = a.item_evals;
+    r.n_active = n_active;
+    r.restarts = prm->restarts;
+    r.n = n;
+    r.best_loss = c->stage_loss.as<double>();
+    r.best_x = c->stage_x.as<double>();
+    r.best_restart = c->stage_restart.as<int32_t>();
+    r.eval_counter = c->counters.as<unsigned long long>();
+    const int rb = 256;
+    hipLaunchKernelGGL(reduce_best_kernel, dim3((unsigned)((n_active + rb - 1) / rb)), dim3(rb), 0, c->stream, r);
+    HIP_TRY(hipGetLastError());
+
+    // statistics need the kernel to be finished: callers synchronise right after anyway
+    unsigned long long evals = 0;
+    HIP_TRY(hipMemcpyAsync(&evals, c->counters.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+    c->stats.kernel_ms += ms;
+    c->stats.kernel_launches += 1;
+    c->stats.evals[k] += (int64_t)evals;
+    c->stats.items[k] += M;
+    return SLAM_OK;
+}
+
+int ensure_results(slam_ctx* c, int k_max) {
+    const int nmax = 6 * (k_max + 1);
+    HIP_TRY(c->best_loss.reserve(c->n_targets * sizeof(double)));
+    HIP_TRY(c->best_x.reserve(c->n_targets * (size_t)nmax * sizeof(double)));
+    HIP_TRY(c->best_cycles.reserve(c->n_targets * sizeof(int32_t)));
+    c->result_nmax = nmax;
+    return SLAM_OK;
+}
+
+int decompose_impl(slam_ctx* c, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* prm,
+                   double success_threshold) {
+    if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
+    if (c->n_gates <= 0) return fail(SLAM_ERR_STATE, "no gates: call slam_set_gates first");
+    if (k_min < 1 || k_max < k_min) return fail(SLAM_ERR_INVALID, "bad span range [%d, %d]", k_min, k_max);
+    if (k_max > SLAM_MAX_SPAN_MINIMIZE)
+        return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got k_max = %d)", SLAM_MAX_SPAN_MINIMIZE, k_max);
+    int rc = check_params(prm);
+    if (rc) return rc;
+    {
+        const int32_t* gs = gate_seqs;
+        for (int k = k_min; k <= k_max; ++k) {
+            rc = check_gate_seq(c, k, gs);
+            if (rc) return rc;
+            gs += k;
+        }
+    }
+    rc = ensure_results(c, k_max);
+    if (rc) return rc;
+    const int64_t N = c->n_targets;
+    HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
+    HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));
+    HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+    hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream,
+                       c->best_loss.as<double>(), c->best_cycles.as<int32_t>(), N);
+    HIP_TRY(hipGetLastError());
+
+    const int32_t* d_active = nullptr;  // identity for the first span
+    int64_t n_active = N;
+    DevBuf* cur = &c->active;
+    DevBuf* nxt = &c->active2;
+    const int32_t* gs = gate_seqs;
+    for (int k = k_min; k <= k_max && n_active > 0; ++k) {
+        rc = run_stage(c, k, gs, d_active, n_active, nullptr, prm);
+        if (rc) return rc;
+        gs += k;
+        MergeArgs m{};
+        m.active = d_active;
+        m.stage_loss = c->stage_loss.as<double>();
+        m.stage_x = c->stage_x.as<double>();
+        m.n_active = n_active;
+        m.n = 6 * (k + 1);
+        m.nmax = c->result_nmax;
+        m.k = k;
+        m.best_loss = c->best_loss.as<double>();
+        m.best_x = c->best_x.as<double>();
+        m.best_cycles = c->best_cycles.as<int32_t>();
+        hipLaunchKernelGGL(merge_stage_kernel, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, c->stream, m);
+        HIP_TRY(hipGetLastError());
+        if (k < k_max) {
+            int32_t* d_nout = reinterpret_cast<int32_t*>(c->counters.as<char>() + 8);
+            hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, c->stream, d_active, n_active,
+                               c->best_loss.as<double>(), success_threshold, nxt->as<int32_t>(), d_nout);
+            HIP_TRY(hipGetLastError());
+            int32_t n_out = 0;
+            HIP_TRY(hipMemcpyAsync(&n_out, d_nout, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            n_active = n_out;
+            d_active = nxt->as<int32_t>();
+            DevBuf* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    c->stats.total_ms = ms;
+    return SLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* slam_last_error(void) { return g_err.c_str(); }
+
+const char* slam_version(void) { return "slamhip 0.1.0 (gfx950)"; }
+
+int slam_device_count(int* count) {
+    if (!count) return fail(SLAM_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(SLAM_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SLAM_OK;
+}
+
+int slam_ctx_create(int device, slam_ctx** out) {
+    if (!out) return fail(SLAM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(SLAM_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    slam_ctx* c = new (std::nothrow) slam_ctx();
+    if (!c) return fail(SLAM_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_a);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_b);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
+    if (e == hipSuccess) e = c->counters.reserve(64);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(SLAM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SLAM_OK;
+}
+
+int slam_ctx_destroy(slam_ctx* ctx) {
+    if (!ctx) return SLAM_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+    return SLAM_OK;
+}
+
+int slam_ctx_device_info(slam_ctx* ctx, char* name, int name_len, int* compute_units, int* clock_khz) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    return SLAM_OK;
+}
+
+int slam_set_targets(slam_ctx* ctx, const double* targets, int64_t n_targets) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (!targets || n_targets <= 0) return fail(SLAM_ERR_INVALID, "targets must be non-empty");
+    if (n_targets > 0x7fffffffLL) return fail(SLAM_ERR_INVALID, "too many targets");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n_targets * 32 * sizeof(double);
+    HIP_TRY(ctx->targets.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(ctx->targets.p, targets, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n_targets = n_targets;
+    return SLAM_OK;
+}
+
+int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (!gates || n_gates <= 0 || n_gates > SLAM_MAX_GATES)
+        return fail(SLAM_ERR_INVALID, "n_gates must be in 1..%d", SLAM_MAX_GATES);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n_gates * 32 * sizeof(double);
+    HIP_TRY(ctx->gates.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(ctx->gates.p, gates, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n_gates = n_gates;
+    return SLAM_OK;
+}
+
+int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
+                        int64_t M, double* loss, double* grad) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
+    if (ctx->n_gates <= 0) return fail(SLAM_ERR_STATE, "no gates: call slam_set_gates first");
+    if (k < 1 || k > SLAM_MAX_SPAN_EVAL) return fail(SLAM_ERR_UNSUPPORTED, "span must be in 1..%d (got %d)", SLAM_MAX_SPAN_EVAL, k);
+    if (M < 0) return fail(SLAM_ERR_INVALID, "M < 0");
+    if (M == 0) return SLAM_OK;
+    if (!x || !target_of || !loss) return fail(SLAM_ERR_INVALID, "x, target_of and loss must be non-NULL");
+    int rc = check_gate_seq(ctx, k, gate_seq);
+    if (rc) return rc;
+    for (int64_t m = 0; m < M; ++m)
+        if (target_of[m] < 0 || target_of[m] >= ctx->n_targets)
+            return fail(SLAM_ERR_INVALID, "target_of[%lld] = %d outside [0, %lld)", (long long)m, target_of[m], (long long)ctx->n_targets);
+    const int n = 6 * (k + 1);
+    HIP_TRY(ctx->ev_x.reserve((size_t)M * n * sizeof(double)));
+    HIP_TRY(ctx->ev_tof.reserve((size_t)M * sizeof(int32_t)));
+    HIP_TRY(ctx->ev_loss.reserve((size_t)M * sizeof(double)));
+    if (grad) HIP_TRY(ctx->ev_grad.reserve((size_t)M * n * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(ctx->ev_x.p, x, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->ev_tof.p, target_of, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    EvalArgs a{};
+    a.targets = ctx->targets.as<double>();
+    a.gates = ctx->gates.as<double>();
+    a.x = ctx->ev_x.as<double>();
+    a.target_of = ctx->ev_tof.as<int32_t>();
+    a.n_items = M;
+    for (int j = 0; j < k; ++j) a.gate_seq[j] = gate_seq[j];
+    a.loss = ctx->ev_loss.as<double>();
+    a.grad = grad ? ctx->ev_grad.as<double>() : nullptr;
+    switch (k) {
+        case 1: rc = launch_eval<1>(ctx, a); break;
+        case 2: rc = launch_eval<2>(ctx, a); break;
+        case 3: rc = launch_eval<3>(ctx, a); break;
+        case 4: rc = launch_eval<4>(ctx, a); break;
+        default: rc = launch_eval<5>(ctx, a); break;
+    }
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(loss, ctx->ev_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (grad) HIP_TRY(hipMemcpyAsync(grad, ctx->ev_grad.p, (size_t)M * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
+                        const double* x0, const slam_opt_params* params, double* best_loss, double* best_x,
+                        int32_t* best_restart, double* item_loss, int32_t* item_iters, int32_t* item_status,
+                        int32_t* item_evals) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
+    if (ctx->n_gates <= 0) return fail(SLAM_ERR_STATE, "no gates: call slam_set_gates first");
+    if (k < 1 || k > SLAM_MAX_SPAN_MINIMIZE)
+        return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
+    int rc = check_params(params);
+    if (rc) return rc;
+    rc = check_gate_seq(ctx, k, gate_seq);
+    if (rc) return rc;
+    if (!active) n_active = ctx->n_targets;
+    if (n_active < 0) return fail(SLAM_ERR_INVALID, "n_active < 0");
+    if (n_active == 0) return SLAM_OK;
+    if (!best_loss || !best_x) return fail(SLAM_ERR_INVALID, "best_loss and best_x must be non-NULL");
+    const int n = 6 * (k + 1);
+    const int64_t M = n_active * (int64_t)params->restarts;
+    const int32_t* d_active = nullptr;
+    if (active) {
+        for (int64_t s = 0; s < n_active; ++s)
+            if (active[s] < 0 || active[s] >= ctx->n_targets)
+                return fail(SLAM_ERR_INVALID, "active[%lld] = %d outside [0, %lld)", (long long)s, active[s], (long long)ctx->n_targets);
+        HIP_TRY(ctx->active.reserve((size_t)n_active * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(ctx->active.p, active, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        d_active = ctx->active.as<int32_t>();
+    }
+    const double* d_x0 = nullptr;
+    if (x0) {
+        HIP_TRY(ctx->x0.reserve((size_t)M * n * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(ctx->x0.p, x0, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        d_x0 = ctx->x0.as<double>();
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_t0, ctx->stream));
+    rc = run_stage(ctx, k, gate_seq, d_active, n_active, d_x0, params);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(best_loss, ctx->stage_loss.p, (size_t)n_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(best_x, ctx->stage_x.p, (size_t)n_active * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (best_restart) HIP_TRY(hipMemcpyAsync(best_restart, ctx->stage_restart.p, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (item_loss) HIP_TRY(hipMemcpyAsync(item_loss, ctx->item_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (item_iters) HIP_TRY(hipMemcpyAsync(item_iters, ctx->item_iters.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (item_status) HIP_TRY(hipMemcpyAsync(item_status, ctx->item_status.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (item_evals) HIP_TRY(hipMemcpyAsync(item_evals, ctx->item_evals.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+    ctx->stats.total_ms = ms;
+    return SLAM_OK;
+}
+
+int slam_decompose_resident(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs,
+                            const slam_opt_params* params, double success_threshold) {
+    return decompose_impl(ctx, k_min, k_max, gate_seqs, params, success_threshold);
+}
+
+int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best_x, int32_t* best_cycles) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int nmax = 6 * (k_max + 1);
+    if (ctx->result_nmax != nmax || ctx->n_targets <= 0)
+        return fail(SLAM_ERR_STATE, "no resident results for k_max = %d", k_max);
+    const size_t N = (size_t)ctx->n_targets;
+    if (best_loss) HIP_TRY(hipMemcpyAsync(best_loss, ctx->best_loss.p, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (best_x) HIP_TRY(hipMemcpyAsync(best_x, ctx->best_x.p, N * nmax * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (best_cycles) HIP_TRY(hipMemcpyAsync(best_cycles, ctx->best_cycles.p, N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_decompose(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* params,
+                   double success_threshold, double* best_loss, double* best_x, int32_t* best_cycles) {
+    int rc = decompose_impl(ctx, k_min, k_max, gate_seqs, params, success_threshold);
+    if (rc) return rc;
+    return slam_fetch_results(ctx, k_max, best_loss, best_x, best_cycles);
+}
+
+int slam_synchronize(slam_ctx* ctx) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_get_stats(slam_ctx* ctx, slam_stats* out) {
+    if (!ctx || !out) return fail(SLAM_ERR_INVALID, "NULL argument");
+    *out = ctx->stats;
+    return SLAM_OK;
+}
+
+int slam_reset_stats(slam_ctx* ctx) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    ctx->stats = slam_stats{};
+    return SLAM_OK;
+}
+
+int slam_best_loss_device_ptr(slam_ctx* ctx, void** ptr, int64_t* n) {
+    if (!ctx || !ptr || !n) return fail(SLAM_ERR_INVALID, "NULL argument");
+    if (!ctx->best_loss.p || ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no resident results");
+    *ptr = ctx->best_loss.p;
+    *n = ctx->n_targets;
+    return SLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_ctx():
+    """One libslamhip context on device 0 for the whole GPU test session."""
+    from slam_decomposition_amd import _ffi
+
+    ctx = _ffi.Context(0)
+    yield ctx
+    ctx.close()
