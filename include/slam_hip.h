@@ -119,6 +119,15 @@ int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const dou
                         const int32_t* target_of, int64_t M, double* loss, double* grad);
 
 /*
+ * CircuitTemplate.eval (src/slam/basis.py:102-104) for M parameter vectors: the 4x4 template
+ * unitary W(x) = K_k G_k ... G_1 K_0, as qiskit's Operator(circuit).data returns it.
+ *   unitary    double[M][4][4][2]  (out)
+ *   loss       double[M]           (out, may be NULL) BasicCost against target_of[m]
+ */
+int slam_eval_unitary(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x,
+                      const int32_t* target_of, int64_t M, double* unitary, double* loss);
+
+/*
  * One span stage of TemplateOptimizer._run (src/slam/optimizer.py:233-303) for a
  * batch: for every active target run `restarts` independent quasi-Newton (BFGS)
  * minimisations from different seeds and return the best.

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "slam_set_targets",
     "slam_set_gates",
     "slam_eval_loss_grad",
+    "slam_eval_unitary",
     "slam_minimize_stage",
     "slam_decompose",
     "slam_decompose_resident",
@@ -98,6 +99,7 @@ def load_library() -> C.CDLL:
     lib.slam_set_targets.argtypes = [P, P, C.c_int64]
     lib.slam_set_gates.argtypes = [P, P, C.c_int32]
     lib.slam_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P]
+    lib.slam_eval_unitary.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P]
     lib.slam_minimize_stage.argtypes = [P, C.c_int, P, P, C.c_int64, P, C.POINTER(OptParams)] + [P] * 7
     lib.slam_decompose.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P, P]
     lib.slam_decompose_resident.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
@@ -202,6 +204,21 @@ class Context:
         grad = np.empty((M, n), dtype=np.float64) if want_grad else None
         _check(self._lib.slam_eval_loss_grad(self._h, k, _ptr(gs), _ptr(x), _ptr(tof), M, _ptr(loss), _ptr(grad)))
         return loss, grad
+
+    def eval_unitary(self, gate_seq: Sequence[int], x: np.ndarray, target_of: Optional[np.ndarray] = None):
+        """W(x) for each row of x: complex128[M, 4, 4] (and BasicCost vs target_of if given)."""
+        k = len(gate_seq)
+        n = 6 * (k + 1)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != n:
+            raise ValueError(f"x must have shape [M, {n}]")
+        M = x.shape[0]
+        tof = np.zeros(M, np.int32) if target_of is None else np.ascontiguousarray(target_of, dtype=np.int32)
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        w = np.empty((M, 4, 4, 2), dtype=np.float64)
+        loss = np.empty(M, dtype=np.float64)
+        _check(self._lib.slam_eval_unitary(self._h, k, _ptr(gs), _ptr(x), _ptr(tof), M, _ptr(w), _ptr(loss)))
+        return w.view(np.complex128).reshape(M, 4, 4), loss
 
     # -- one span stage ----------------------------------------------------
     def minimize_stage(

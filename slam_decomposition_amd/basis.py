@@ -1,0 +1,150 @@
+"""``CircuitTemplate`` (reference: src/slam/basis.py:52-169) without qiskit.
+
+The template is the alternating circuit  [U(q0) U(q1)] (G [U(q0) U(q1)])^k  on two qubits;
+its unitary is W(x) = K_k G_k ... G_1 K_0 with K_j = U3(x[6j+3:6j+6]) (x) U3(x[6j:6j+3])
+(qiskit little-endian).  ``eval`` and everything the optimizer does with the template run in the
+HIP library; this class only carries the structure (which 2Q gate at which position).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+from . import runtime
+from .basis_abc import VariationalTemplate
+from .gates import RiSwapGate, gate_matrix
+
+
+class CircuitTemplate(VariationalTemplate):
+    def __init__(
+        self,
+        n_qubits=2,
+        base_gates=None,
+        edge_params=None,
+        no_exterior_1q=False,
+        use_polytopes=False,
+        maximum_span_guess=5,
+        preseed=False,
+        device=0,
+    ):
+        # reference defaults are the mutable literals [RiSwapGate(1/2)], [[(0, 1)]] (basis.py:55-56)
+        if base_gates is None:
+            base_gates = [RiSwapGate(1 / 2)]
+        if edge_params is None:
+            edge_params = [[(0, 1)]]
+        if n_qubits != 2:
+            raise NotImplementedError("the HIP template optimizer handles 2-qubit templates only")
+        if use_polytopes:
+            raise NotImplementedError(
+                "use_polytopes needs the monodromy package (reference: utils/polytopes/polytope_wrap.py); "
+                "out of scope, see SURVEY.md §8(f) row 4"
+            )
+        if no_exterior_1q:
+            raise NotImplementedError("no_exterior_1q=True is not implemented on the HIP path")
+        for el in edge_params:
+            for e in el:
+                if tuple(e) != (0, 1):
+                    raise NotImplementedError("only edge (0, 1) is implemented on the HIP path")
+        self.filename = None
+        self.n_qubits = n_qubits
+        self.no_exterior_1q = no_exterior_1q
+        self.base_gates = list(base_gates)
+        self.gate_matrices = np.stack([gate_matrix(g) for g in self.base_gates])
+        self.edge_params = edge_params
+        self.device = device
+        # compliant with the reference's optimizer (basis.py:77-80)
+        self.using_bounds = False
+        self.bounds_list = None
+        self.using_constraints = False
+        self.constraint_func = None
+        self.spanning_range = range(1, maximum_span_guess + 1)  # basis.py:84-85
+        self.coverage = None
+        super().__init__(preseed=preseed, use_polytopes=use_polytopes)
+        self._reset()
+        self.trotter = False
+
+    # ---- structure ---------------------------------------------------------------------------
+    def _reset(self):
+        self.cycles = 0
+
+    def build(self, n_repetitions):
+        """basis.py:124-134.  Deviation: the reference's
+        ``cycle(base_gates)`` is never reset, so with several base gates its gate order depends on
+        the call history; here every build restarts the cycle: [g0, g1, g0, ...][:k]."""
+        self._reset()
+        if n_repetitions <= 0:
+            raise ValueError()
+        self.cycles = int(n_repetitions)
+
+    def gate_sequence(self, k=None) -> List[int]:
+        """Indices into ``base_gates`` of the k two-qubit gates, in circuit order."""
+        k = self.cycles if k is None else k
+        return [i % len(self.base_gates) for i in range(k)]
+
+    @property
+    def n_params(self) -> int:
+        return 6 * (self.cycles + 1)
+
+    def get_spanning_range(self, target_u):
+        return self.spanning_range  # basis.py:95-97 (no polytopes)
+
+    # ---- numerics -----------------------------------------------------------------------------
+    def eval(self, Xk):
+        """4x4 unitary of the bound template (basis.py:102-104), computed by libslamhip."""
+        if self.cycles <= 0:
+            raise ValueError("build() the template first")
+        Xk = np.asarray(Xk, dtype=np.float64).reshape(1, -1)
+        if Xk.shape[1] != self.n_params:
+            raise ValueError(f"expected {self.n_params} parameters, got {Xk.shape[1]}")
+        ctx = runtime.get_context(self.device)
+        ctx.set_gates(self.gate_matrices)
+        if ctx.n_targets == 0:
+            ctx.set_targets(np.eye(4, dtype=np.complex128)[None])
+        w, _ = ctx.eval_unitary(self.gate_sequence(), Xk)
+        return w[0]
+
+    def parameter_guess(self, t=0):
+        """basis.py:106-111: uniform in [0, 2pi) from NumPy's global generator."""
+        parent = super().parameter_guess(t)
+        if parent is not None:
+            return parent
+        return np.random.random(self.n_params) * 2 * np.pi
+
+    # ---- qiskit-free replacements for assign_Xk / .circuit -------------------------------------
+    def to_gate_list(self, Xk) -> list:
+        """The bound circuit as a list of instructions, in time order:
+        ("u", qubit, (theta, phi, lam)) and ("gate", gate_object, (0, 1)).  Replaces
+        ``assign_Xk`` (basis.py:113-116), which returns a qiskit ``QuantumCircuit``."""
+        Xk = list(np.asarray(Xk, dtype=np.float64))
+        if len(Xk) != self.n_params:
+            raise ValueError(f"expected {self.n_params} parameters, got {len(Xk)}")
+        out = []
+        seq = self.gate_sequence()
+        for j in range(self.cycles + 1):
+            if j > 0:
+                out.append(("gate", self.base_gates[seq[j - 1]], (0, 1)))
+            out.append(("u", 0, tuple(Xk[6 * j : 6 * j + 3])))
+            out.append(("u", 1, tuple(Xk[6 * j + 3 : 6 * j + 6])))
+        return out
+
+    @staticmethod
+    def qiskit_parameter_order(n: int) -> List[int]:
+        """qiskit returns ``circuit.parameters`` sorted by name, so the reference zips ``Xk`` with
+        P0, P1, P10, P11, ..., P2, ... (basis.py:113-116).  ``order[j]`` is the index (P-number) of
+        the j-th parameter in that order."""
+        return sorted(range(n), key=lambda i: f"P{i}")
+
+    @classmethod
+    def from_qiskit_order(cls, Xk_sorted: Sequence[float]) -> np.ndarray:
+        """Reference-order vector (zipped with name-sorted parameters) -> index order P0..P{n-1}."""
+        n = len(Xk_sorted)
+        out = np.empty(n)
+        for j, i in enumerate(cls.qiskit_parameter_order(n)):
+            out[i] = Xk_sorted[j]
+        return out
+
+    @classmethod
+    def to_qiskit_order(cls, Xk: Sequence[float]) -> np.ndarray:
+        n = len(Xk)
+        return np.array([Xk[i] for i in cls.qiskit_parameter_order(n)])

@@ -1,0 +1,29 @@
+"""Cost functions (reference: src/slam/cost_function.py:117-145).
+
+``BasicCost`` is the only objective the HIP optimizer implements.  The class keeps the
+reference's interface; ``unitary_fidelity`` on two single matrices is the reference's own
+one-line NumPy expression (used for spot checks and logging, never inside the optimizer loop --
+there the loss is fused into the HIP kernel).
+"""
+from __future__ import annotations
+
+from abc import ABC
+
+import numpy as np
+
+
+class UnitaryCostFunction(ABC):
+    def __init__(self):
+        self.normalization = 1  # src/slam/cost_function.py:123
+
+    def unitary_fidelity(self, current_u, target_u):
+        raise NotImplementedError
+
+
+class BasicCost(UnitaryCostFunction):
+    """1 - |Tr(T^dagger U)| / d  (src/slam/cost_function.py:140-145)."""
+
+    def unitary_fidelity(self, current_u, target_u):
+        h = np.asarray(target_u).conj().T
+        cur = np.asarray(current_u)
+        return 1 - np.abs(np.trace(h @ cur)) / cur.shape[0]

@@ -161,12 +161,13 @@ __device__ __forceinline__ double im_mul(double ar, double ai, double br, double
 //   gl    LDS: gate matrices G_1..G_K, row-major (re, im)
 //   xq    LDS: this quad's exchange area (trig table, then gradient transpose)
 //   fh    LDS: this lane's slice of the stored column vectors (stride 64 double2 per row)
-// Returns loss (replicated over the quad) and gd[a] = dloss/dx[4a + q].
+// Returns loss (replicated over the quad), gd[a] = dloss/dx[4a + q] and column q of W.
 // ---------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double (&tre)[4],
                                           const double (&tim)[4], const double* gl, double* xq, double2* fh,
-                                          int q, double& fout, double (&gd)[Cfg<K>::NA]) {
+                                          int q, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
+                                          double (&Wi)[4]) {
     using C = Cfg<K>;
     // ---- 1. trig table: each lane handles its own parameter slots
     {
@@ -223,6 +224,10 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             for (int r = 0; r < 4; ++r) { Fr[r] = nr[r]; Fi[r] = ni[r]; }
         }
     }
+
+    // column q of W = template unitary (CircuitTemplate.eval)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Wr[r] = Fr[r]; Wi[r] = Fi[r]; }
 
     // ---- 3. t = Tr(T^+ W), loss, z = -conj(t) / (4|t|)
     double pr = 0.0, pi = 0.0;

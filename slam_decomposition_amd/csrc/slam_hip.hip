@@ -84,14 +84,14 @@ struct slam_ctx {
     int32_t result_nmax = 0;
     DevBuf counters;  // [0]: eval counter (u64), [1]: n_out (i32)
     // eval buffers
-    DevBuf ev_x, ev_tof, ev_loss, ev_grad;
+    DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary;
     slam_stats stats{};
     bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][2] = {};
 
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &counters, &ev_x, &ev_tof, &ev_loss, &ev_grad};
+                         &best_x, &best_cycles, &counters, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary};
         for (DevBuf* b : all) b->release();
         if (ev_a) (void)hipEventDestroy(ev_a);
         if (ev_b) (void)hipEventDestroy(ev_b);
@@ -397,8 +397,8 @@ int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates) {
     return SLAM_OK;
 }
 
-int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
-                        int64_t M, double* loss, double* grad) {
+static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
+                     int64_t M, double* loss, double* grad, double* unitary) {
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
@@ -417,6 +417,7 @@ int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const dou
     HIP_TRY(ctx->ev_tof.reserve((size_t)M * sizeof(int32_t)));
     HIP_TRY(ctx->ev_loss.reserve((size_t)M * sizeof(double)));
     if (grad) HIP_TRY(ctx->ev_grad.reserve((size_t)M * n * sizeof(double)));
+    if (unitary) HIP_TRY(ctx->ev_unitary.reserve((size_t)M * 32 * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(ctx->ev_x.p, x, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->ev_tof.p, target_of, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     EvalArgs a{};
@@ -428,6 +429,7 @@ int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const dou
     for (int j = 0; j < k; ++j) a.gate_seq[j] = gate_seq[j];
     a.loss = ctx->ev_loss.as<double>();
     a.grad = grad ? ctx->ev_grad.as<double>() : nullptr;
+    a.unitary = unitary ? ctx->ev_unitary.as<double>() : nullptr;
     switch (k) {
         case 1: rc = launch_eval<1>(ctx, a); break;
         case 2: rc = launch_eval<2>(ctx, a); break;
@@ -438,8 +440,25 @@ int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const dou
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(loss, ctx->ev_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (grad) HIP_TRY(hipMemcpyAsync(grad, ctx->ev_grad.p, (size_t)M * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (unitary) HIP_TRY(hipMemcpyAsync(unitary, ctx->ev_unitary.p, (size_t)M * 32 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
+}
+
+int slam_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
+                        int64_t M, double* loss, double* grad) {
+    return eval_impl(ctx, k, gate_seq, x, target_of, M, loss, grad, nullptr);
+}
+
+int slam_eval_unitary(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
+                      int64_t M, double* unitary, double* loss) {
+    if (!unitary) return fail(SLAM_ERR_INVALID, "unitary is NULL");
+    std::vector<double> tmp;
+    if (!loss && M > 0) {
+        tmp.resize((size_t)M);
+        loss = tmp.data();
+    }
+    return eval_impl(ctx, k, gate_seq, x, target_of, M, loss, nullptr, unitary);
 }
 
 int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,

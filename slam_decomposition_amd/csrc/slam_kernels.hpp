@@ -43,6 +43,7 @@ struct EvalArgs {
     int32_t gate_seq[8];
     double* loss;             // [M]
     double* grad;             // [M][n] or nullptr
+    double* unitary;          // [M][4][4][2] or nullptr: W = CircuitTemplate.eval(x)
 };
 
 template <int K>
@@ -85,10 +86,17 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs args) {
         const int i = 4 * a + q;
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
-    double f;
-    eval_quad<K>(xd, tre, tim, gl, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd);
+    double f, Wr[4], Wi[4];
+    eval_quad<K>(xd, tre, tim, gl, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
+        if (args.unitary) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                args.unitary[item * 32 + (r * 4 + q) * 2] = Wr[r];
+                args.unitary[item * 32 + (r * 4 + q) * 2 + 1] = Wi[r];
+            }
+        }
         if (args.grad) {
 #pragma unroll
             for (int a = 0; a < C::NA; ++a) {
@@ -147,8 +155,8 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs args) {
     double H[C::NBLK][4];
     h_set_identity<NA>(H, q);
 
-    double f;
-    eval_quad<K>(x, tre, tim, gl, xq, fh, q, f, g);
+    double f, Wr[4], Wi[4];
+    eval_quad<K>(x, tre, tim, gl, xq, fh, q, f, g, Wr, Wi);
     int nev = 1, iters = 0, nback = 0, nstall = 0;
     bool scaled = false;
     int status = ST_MAXITER;
@@ -176,7 +184,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs args) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
         double ft;
-        eval_quad<K>(xt, tre, tim, gl, xq, fh, q, ft, gt);
+        eval_quad<K>(xt, tre, tim, gl, xq, fh, q, ft, gt, Wr, Wi);
         const bool active = !done;
         if (active) ++nev;
         const bool finite = isfinite(ft);

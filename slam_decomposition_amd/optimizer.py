@@ -1,0 +1,175 @@
+"""``TemplateOptimizer`` (reference: src/slam/optimizer.py) on the HIP library.
+
+Same constructor, same ``approximate_target_U`` / ``approximate_from_distribution`` results
+(``training_loss``, ``coordinate_list``, ``[DataDictEntry]``), same log lines and the same
+``ValueError`` on failure -- but the triple loop of ``_run`` (spans x restarts x BFGS iterations,
+optimizer.py:233-303) runs for the whole batch of targets at once inside libslamhip:
+every (target, restart) pair is one quasi-Newton minimisation owned by a quad of GPU lanes.
+
+Differences a caller can observe:
+  * restarts of one target run concurrently; the reference stops at the first restart below
+    the threshold, so ``loss_result`` may come from a different (equally successful) restart;
+  * multi-start seeds come from Philox keyed on ``seed`` instead of NumPy's global generator
+    (``seed=None`` draws the key from that generator, keeping "unseeded" behaviour);
+  * gradients are analytic, so converged losses sit near 1e-14 instead of the reference's
+    finite-difference floor of about 1e-10.
+"""
+from __future__ import annotations
+
+import logging
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _ffi, runtime
+from .basis import CircuitTemplate
+from .basis_abc import DataDictEntry, VariationalTemplate
+from .cost_function import BasicCost, UnitaryCostFunction
+from .sampler import SampleFunction
+from .weyl import c1c2c3
+
+SUCCESS_THRESHOLD = 1e-10  # optimizer.py:18
+TRAINING_RESTARTS = 5  # optimizer.py:19
+MAXITER = 2500  # optimizer.py:275
+DEFAULT_GTOL = 1e-9
+DEFAULT_STOP_LOSS = 1e-13
+
+_FAIL_MSG = (
+    "Failed to converge within error threshold. Try increasing restart attempts or increasing "
+    "temperature scaling on preseed."
+)
+
+
+class TemplateOptimizer:
+    def __init__(
+        self,
+        basis: VariationalTemplate,
+        objective: UnitaryCostFunction,
+        use_callback=False,
+        override_fail=False,
+        success_threshold=None,
+        training_restarts=None,
+        override_method=None,
+        device=None,
+        seed=None,
+        gtol=DEFAULT_GTOL,
+        stop_loss=None,
+    ):
+        self.basis = basis
+        self.objective = objective
+        self.preseeding = self.basis.preseeded
+        self.use_callback = use_callback
+        self.training_loss = []  # per target: final loss (optimizer.py:307-309)
+        self.coordinate_list = []
+        self.best_cycle_list = []
+        self.override_fail = override_fail
+        self.override_method = override_method
+        self.success_threshold = SUCCESS_THRESHOLD if success_threshold is None else success_threshold
+        self.training_restarts = TRAINING_RESTARTS if training_restarts is None else training_restarts
+        assert not (self.preseeding and self.override_fail)
+        assert not (self.preseeding and self.basis.n_qubits != 2)
+
+        if not isinstance(basis, CircuitTemplate):
+            raise NotImplementedError("the HIP optimizer needs a slam_decomposition_amd CircuitTemplate")
+        if not isinstance(self.objective, BasicCost):
+            # the reference raises this for objectives its objective_func does not know (optimizer.py:211)
+            raise ValueError("Unrecognized Cost Function")
+        if use_callback:
+            raise NotImplementedError(
+                "use_callback=True (per-iteration loss / coordinate trajectories, optimizer.py:217-224) "
+                "is not available on the HIP path: only final values leave the GPU"
+            )
+        if override_method not in (None, "BFGS"):
+            raise NotImplementedError(f"override_method={override_method!r}: the HIP path implements BFGS only")
+        if self.training_restarts <= 0:
+            raise ValueError("training_restarts must be positive")
+        self.device = basis.device if device is None else device
+        self.seed = seed
+        self.gtol = float(gtol)
+        if stop_loss is None:
+            stop_loss = min(DEFAULT_STOP_LOSS, 0.1 * self.success_threshold)
+        self.stop_loss = float(stop_loss)
+        self.last_stats = None
+
+    # ------------------------------------------------------------------------------------------
+    def _opt_params(self) -> "_ffi.OptParams":
+        seed = self.seed
+        if seed is None:
+            # reference: unseeded np.random.random (basis.py:111) -> draw the Philox key from it
+            seed = int(np.random.randint(0, 2**63 - 1, dtype=np.int64))
+        return _ffi.OptParams(
+            restarts=int(self.training_restarts),
+            maxiter=MAXITER,
+            gtol=self.gtol,
+            stop_loss=self.stop_loss,
+            seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
+            flags=_ffi.FLAG_EARLY_EXIT,
+        )
+
+    def _run_batch(self, targets: np.ndarray, spanning_range: Sequence[int]):
+        """``_run`` (optimizer.py:188-313) for all targets at once.  Returns
+        (best_result[N], best_Xk list, best_cycles[N])."""
+        ks = list(spanning_range)
+        if not ks:
+            raise ValueError("empty spanning range")
+        if ks != list(range(ks[0], ks[-1] + 1)):
+            raise NotImplementedError("spanning range must be contiguous")
+        if ks[-1] > _ffi.MAX_SPAN_MINIMIZE:
+            raise NotImplementedError(
+                f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path "
+                f"(got maximum_span_guess = {ks[-1]})"
+            )
+        ctx = runtime.get_context(self.device)
+        ctx.set_targets(targets)
+        ctx.set_gates(self.basis.gate_matrices)
+        gate_seqs = [self.basis.gate_sequence(k) for k in ks]
+        ctx.reset_stats()
+        best_loss, best_x, best_cycles = ctx.decompose(ks[0], ks[-1], gate_seqs, self._opt_params(), self.success_threshold)
+        self.last_stats = ctx.stats()
+        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(len(targets))]
+        return best_loss, xs, best_cycles
+
+    def _finish_target(self, target_U, target_coordinates, best_result, best_Xk, best_cycles) -> DataDictEntry:
+        """Labelling / logging / exception of approximate_target_U (optimizer.py:80-119)."""
+        logging.info(f"Overall Best Loss={best_result}")
+        self.training_loss.append(best_result)  # optimizer.py:307-309 (no callback)
+        self.best_cycle_list.append(best_cycles)
+        self.basis.build(n_repetitions=best_cycles)
+        if best_result <= self.success_threshold:
+            success_label = 1
+            alternative_coordinate = c1c2c3(self.basis.eval(best_Xk))
+            logging.info(f"Success: {target_coordinates}, Found: {alternative_coordinate}")
+        else:
+            if not self.override_fail:
+                raise ValueError(_FAIL_MSG)
+            success_label = 0
+            alternative_coordinate = c1c2c3(self.basis.eval(best_Xk))
+            logging.info(f"Fail: {target_coordinates}, Found: {alternative_coordinate}")
+        return DataDictEntry(success_label, best_result, best_Xk, best_cycles)
+
+    # ------------------------------------------------------------------------------------------
+    def approximate_target_U(self, target_U) -> DataDictEntry:
+        """Atomic training function (optimizer.py:65-119)."""
+        return self._approximate_batch([np.asarray(target_U, dtype=np.complex128)], log_index=False)[0]
+
+    def approximate_from_distribution(self, sampler: SampleFunction):
+        """optimizer.py:180-186; all targets of the sampler are optimised as one GPU batch."""
+        targets = [np.asarray(t, dtype=np.complex128) for t in sampler]
+        target_data = self._approximate_batch(targets, log_index=True) if targets else []
+        return self.training_loss, self.coordinate_list, target_data
+
+    def _approximate_batch(self, targets: List[np.ndarray], log_index: bool) -> List[DataDictEntry]:
+        for t in targets:
+            if t.shape != (4, 4):
+                raise ValueError("targets must be 4x4 unitaries")
+        coords = [self.basis.target_invariant(t) for t in targets]
+        self.basis.assign_seed(None)  # optimizer.py:150-152
+        spanning_range = self.basis.get_spanning_range(targets[0])
+        best_loss, best_xs, best_cycles = self._run_batch(np.stack(targets), spanning_range)
+        out = []
+        for i, t in enumerate(targets):
+            if log_index:
+                logging.info(f"Starting sample iter {i}")
+            logging.info(f"Begin search: {coords[i]}")
+            out.append(self._finish_target(t, coords[i], float(best_loss[i]), best_xs[i], int(best_cycles[i])))
+        return out

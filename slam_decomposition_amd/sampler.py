@@ -1,0 +1,73 @@
+"""Target distributions (reference: src/slam/sampler.py:20-71)."""
+from __future__ import annotations
+
+import random
+from abc import ABC
+from sys import maxsize
+
+import numpy as np
+from scipy.stats import unitary_group
+
+from .gates import gate_matrix
+
+
+def random_unitary(dims: int, seed=None) -> np.ndarray:
+    """qiskit ``random_unitary(dims, seed).data`` recipe: SciPy's Haar ``unitary_group`` driven by
+    ``np.random.default_rng(seed)``."""
+    return unitary_group.rvs(dims, random_state=np.random.default_rng(seed))
+
+
+class SampleFunction(ABC):
+    def __init__(self, n_qubits=2, n_samples=1):
+        self.n_qubits = n_qubits
+        self.n_samples = n_samples
+
+    def __iter__(self):
+        for _ in range(self.n_samples):
+            yield self._get_unitary()
+
+    def _get_unitary(self):
+        raise NotImplementedError
+
+
+class GateSample(SampleFunction):
+    """src/slam/sampler.py:33-39."""
+
+    def __init__(self, gate, n_samples=1):
+        self.gate = gate
+        super().__init__(getattr(gate, "num_qubits", 2), n_samples)
+
+    def _get_unitary(self):
+        return gate_matrix(self.gate)
+
+
+class HaarSample(SampleFunction):
+    """src/slam/sampler.py:62-71.  Faithful to the reference: Python's ``random`` is re-seeded
+    with ``self.seed`` on *every* draw, so an integer seed yields ``n_samples`` identical
+    unitaries and ``seed=None`` yields fresh OS entropy each time.
+    Use :class:`HaarBatch` for distinct reproducible targets."""
+
+    def __init__(self, seed=None, n_samples=1, n_qubits=2):
+        self.seed = seed
+        super().__init__(n_samples=n_samples, n_qubits=n_qubits)
+
+    def _get_unitary(self):
+        random.seed(self.seed)
+        return random_unitary(dims=2**self.n_qubits, seed=random.randint(0, maxsize))
+
+
+class HaarBatch(SampleFunction):
+    """``n_samples`` distinct Haar targets, T_i = random_unitary(4, seed0 + start + i): the
+    synthetic benchmark set of SURVEY.md §8(d) (not in the reference)."""
+
+    def __init__(self, seed0: int = 20260000, n_samples: int = 1, start: int = 0, n_qubits=2):
+        self.seed0 = int(seed0)
+        self.start = int(start)
+        super().__init__(n_samples=n_samples, n_qubits=n_qubits)
+
+    def __iter__(self):
+        for i in range(self.n_samples):
+            yield random_unitary(2**self.n_qubits, seed=self.seed0 + self.start + i)
+
+    def as_array(self) -> np.ndarray:
+        return np.stack(list(self))

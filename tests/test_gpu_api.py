@@ -1,0 +1,128 @@
+"""GPU: the reference's Python surface (TemplateOptimizer / CircuitTemplate / BasicCost /
+HaarSample) driven end to end on the HIP path, checked against the oracle.
+
+Mirrors the reference's README usage (README.md:32-52) and BASELINE.json configs[0]
+(CNOT basis, maximum_span_guess=2, 1 Haar target, 1 restart).
+"""
+import logging
+
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as o
+from slam_decomposition_amd.basis import CircuitTemplate
+from slam_decomposition_amd.basis_abc import DataDictEntry
+from slam_decomposition_amd.cost_function import BasicCost
+from slam_decomposition_amd.gates import BerkeleyGate, CXGate, RiSwapGate
+from slam_decomposition_amd.optimizer import TemplateOptimizer
+from slam_decomposition_amd.sampler import GateSample, HaarBatch, HaarSample
+
+pytestmark = pytest.mark.gpu
+
+
+def test_readme_usage_sqrt_iswap(caplog):
+    """README.md:32-62: one Haar target, sqrt(iSWAP) basis -> success, k in {2, 3}."""
+    basis = CircuitTemplate(n_qubits=2, base_gates=[RiSwapGate(1 / 2)], edge_params=[[(0, 1)]], maximum_span_guess=3)
+    objective = BasicCost()
+    optimizer = TemplateOptimizer(basis=basis, objective=objective, use_callback=False, override_fail=True, seed=3)
+    sampler = HaarSample(seed=0, n_samples=1)
+    with caplog.at_level(logging.INFO):
+        training_loss, coordinate_list, target_data = optimizer.approximate_from_distribution(sampler)
+    (td,) = target_data
+    assert isinstance(td, DataDictEntry)
+    assert td.success_label == 1 and td.loss_result <= 1e-10
+    assert training_loss == [td.loss_result] and coordinate_list == []
+    assert optimizer.best_cycle_list == [td.cycles]
+    (target,) = list(HaarSample(seed=0, n_samples=1))
+    g = o.riswap_matrix(0.5)
+    W = o.template_eval(td.Xk, [g] * td.cycles)
+    assert abs(o.basic_cost(W, target) - td.loss_result) < 1e-12
+    assert np.max(np.abs(o.c1c2c3_raw(W) - o.c1c2c3_raw(target))) < 1e-6
+    msgs = [r.getMessage() for r in caplog.records]
+    assert any(m.startswith("Starting sample iter 0") for m in msgs)
+    assert any(m.startswith("Begin search:") for m in msgs)
+    assert any(m.startswith("Success:") for m in msgs)
+    # template.eval on the GPU == oracle chain
+    basis.build(td.cycles)
+    assert np.max(np.abs(basis.eval(td.Xk) - W)) < 1e-13
+
+
+def test_config0_cnot_span2_fails_like_reference():
+    """BASELINE.json configs[0]: CNOT, maximum_span_guess=2, 1 Haar target, 1 restart.  A Haar
+    target is unreachable with <= 2 CNOTs: ValueError unless override_fail (optimizer.py:89-93);
+    with override_fail the converged non-zero loss equals the reference path's (oracle: SciPy BFGS
+    with finite differences, exactly optimizer.py:270-278) from the same x0."""
+    seed = 12
+    (target,) = list(HaarSample(seed=5, n_samples=1))
+    basis = CircuitTemplate(base_gates=[CXGate()], maximum_span_guess=2)
+    with pytest.raises(ValueError, match="Failed to converge within error threshold"):
+        TemplateOptimizer(basis, BasicCost(), training_restarts=1, seed=seed).approximate_target_U(target)
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=1, seed=seed, override_fail=True)
+    td = opt.approximate_target_U(target)
+    assert td.success_label == 0 and td.loss_result > 1e-6
+    ref_loss, ref_x, ref_k, _ = o.run_reference(
+        target, [o.cx_matrix()], range(1, 3), 1, 1e-10, x0_fn=lambda k, r: o.x0_philox(seed, 0, r, k)
+    )
+    assert td.cycles == ref_k
+    assert abs(td.loss_result - ref_loss) < 1e-6
+    assert len(td.Xk) == 6 * (td.cycles + 1)
+
+
+@pytest.mark.parametrize(
+    "gates,kmax,mats",
+    [
+        ([CXGate()], 3, [o.cx_matrix()]),
+        ([BerkeleyGate()], 2, [o.berkeley_matrix()]),
+        ([RiSwapGate(1.0), BerkeleyGate()], 3, [o.riswap_matrix(1.0), o.berkeley_matrix()]),
+    ],
+)
+def test_batch_of_haar_targets(gates, kmax, mats):
+    N = 24
+    basis = CircuitTemplate(base_gates=gates, maximum_span_guess=kmax)
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=16, seed=99)
+    sampler = HaarBatch(seed0=777, n_samples=N)
+    losses, _, data = opt.approximate_from_distribution(sampler)
+    targets = sampler.as_array()
+    assert len(data) == N and len(losses) == N
+    for t, td in enumerate(data):
+        assert td.success_label == 1
+        seq = o.gate_sequence(mats, td.cycles)
+        W = o.template_eval(td.Xk, seq)
+        assert abs(o.basic_cost(W, targets[t]) - td.loss_result) < 1e-12
+        assert np.max(np.abs(o.c1c2c3_raw(W) - o.c1c2c3_raw(targets[t]))) < 1e-6
+    if len(gates) == 1 and isinstance(gates[0], CXGate):
+        assert all(td.cycles == 3 for td in data)  # Haar-generic targets need 3 CNOTs
+    if isinstance(gates[0], BerkeleyGate):
+        assert all(td.cycles == 2 for td in data)  # B gate reaches everything in 2
+
+
+def test_gate_sample_target_swap():
+    """KAT-2/KAT-5 setting: target SWAP with sqrt(iSWAP) needs k = 3 (coordinates (.5,.5,.5))."""
+    from slam_decomposition_amd.gates import SwapGate
+
+    basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=16, seed=4)
+    _, _, (td,) = opt.approximate_from_distribution(GateSample(SwapGate()))
+    assert td.success_label == 1 and td.cycles == 3
+    basis.build(3)
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    assert np.max(np.abs(np.array(c1c2c3(basis.eval(td.Xk))) - 0.5)) < 1e-6
+
+
+def test_unsupported_arguments_raise():
+    basis = CircuitTemplate(maximum_span_guess=3)
+    with pytest.raises(NotImplementedError):
+        TemplateOptimizer(basis, BasicCost(), use_callback=True)
+    with pytest.raises(NotImplementedError):
+        TemplateOptimizer(basis, BasicCost(), override_method="Nelder-Mead")
+
+    class Other:
+        normalization = 1
+
+    with pytest.raises(ValueError, match="Unrecognized Cost Function"):
+        TemplateOptimizer(basis, Other())
+    with pytest.raises(NotImplementedError):
+        TemplateOptimizer(CircuitTemplate(maximum_span_guess=5), BasicCost()).approximate_target_U(np.eye(4))
+    with pytest.raises(ValueError):
+        basis.build(0)
