@@ -173,6 +173,15 @@ int slam_decompose_resident(slam_ctx* ctx, int k_min, int k_max, const int32_t* 
 int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best_x,
                        int32_t* best_cycles);
 
+/* The same span loop restricted to the window [first, first + count) of the resident targets
+ * (results of other targets are left untouched): lets a caller keep many batches resident and
+ * process them one after the other, or overlap batches from several host threads' contexts. */
+int slam_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max,
+                         const int32_t* gate_seqs, const slam_opt_params* params,
+                         double success_threshold);
+int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t count,
+                             double* best_loss, double* best_x, int32_t* best_cycles);
+
 /* Block until all work queued on the context's stream has finished. */
 int slam_synchronize(slam_ctx* ctx);
 

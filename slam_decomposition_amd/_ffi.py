@@ -37,6 +37,8 @@ EXPORTED_SYMBOLS = (
     "slam_decompose",
     "slam_decompose_resident",
     "slam_fetch_results",
+    "slam_decompose_range",
+    "slam_fetch_results_range",
     "slam_synchronize",
     "slam_get_stats",
     "slam_reset_stats",
@@ -104,6 +106,8 @@ def load_library() -> C.CDLL:
     lib.slam_decompose.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P, P]
     lib.slam_decompose_resident.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results.argtypes = [P, C.c_int, P, P, P]
+    lib.slam_decompose_range.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
+    lib.slam_fetch_results_range.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, P, P]
     lib.slam_synchronize.argtypes = [P]
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.slam_reset_stats.argtypes = [P]
@@ -288,6 +292,21 @@ class Context:
         best_x = np.zeros((N, nmax), dtype=np.float64)
         best_cycles = np.empty(N, dtype=np.int32)
         _check(self._lib.slam_fetch_results(self._h, k_max, _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
+        return best_loss, best_x, best_cycles
+
+    def decompose_range(self, first, count, k_min, k_max, gate_seqs, params: OptParams, success_threshold: float, fetch=True):
+        flat = self._flat_gate_seqs(gate_seqs, k_min, k_max)
+        _check(self._lib.slam_decompose_range(self._h, int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params), float(success_threshold)))
+        if fetch:
+            return self.fetch_results_range(k_max, first, count)
+        return None
+
+    def fetch_results_range(self, k_max: int, first: int, count: int):
+        nmax = 6 * (k_max + 1)
+        best_loss = np.empty(count, dtype=np.float64)
+        best_x = np.zeros((count, nmax), dtype=np.float64)
+        best_cycles = np.empty(count, dtype=np.int32)
+        _check(self._lib.slam_fetch_results_range(self._h, k_max, int(first), int(count), _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
         return best_loss, best_x, best_cycles
 
     def synchronize(self) -> None:

@@ -235,8 +235,8 @@ int ensure_results(slam_ctx* c, int k_max) {
     return SLAM_OK;
 }
 
-int decompose_impl(slam_ctx* c, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* prm,
-                   double success_threshold) {
+int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                   const slam_opt_params* prm, double success_threshold) {
     if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
@@ -254,17 +254,24 @@ int decompose_impl(slam_ctx* c, int k_min, int k_max, const int32_t* gate_seqs, 
             gs += k;
         }
     }
+    if (first < 0 || count <= 0 || first + count > c->n_targets)
+        return fail(SLAM_ERR_INVALID, "target window [%lld, %lld) outside [0, %lld)", (long long)first,
+                    (long long)(first + count), (long long)c->n_targets);
+    if (c->result_nmax != 0 && c->result_nmax != 6 * (k_max + 1) && !(first == 0 && count == c->n_targets))
+        return fail(SLAM_ERR_STATE, "resident results were produced with a different k_max");
     rc = ensure_results(c, k_max);
     if (rc) return rc;
-    const int64_t N = c->n_targets;
+    const int64_t N = count;
     HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
     HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+    const bool whole = (first == 0 && count == c->n_targets);
     hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream,
-                       c->best_loss.as<double>(), c->best_cycles.as<int32_t>(), N);
+                       c->best_loss.as<double>(), c->best_cycles.as<int32_t>(),
+                       whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N);
     HIP_TRY(hipGetLastError());
 
-    const int32_t* d_active = nullptr;  // identity for the first span
+    const int32_t* d_active = whole ? nullptr : c->active.as<int32_t>();  // nullptr = identity
     int64_t n_active = N;
     DevBuf* cur = &c->active;
     DevBuf* nxt = &c->active2;
@@ -381,6 +388,7 @@ int slam_set_targets(slam_ctx* ctx, const double* targets, int64_t n_targets) {
     HIP_TRY(hipMemcpyAsync(ctx->targets.p, targets, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->n_targets = n_targets;
+    ctx->result_nmax = 0;
     return SLAM_OK;
 }
 
@@ -516,26 +524,43 @@ int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int
 
 int slam_decompose_resident(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs,
                             const slam_opt_params* params, double success_threshold) {
-    return decompose_impl(ctx, k_min, k_max, gate_seqs, params, success_threshold);
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    return decompose_impl(ctx, 0, ctx->n_targets, k_min, k_max, gate_seqs, params, success_threshold);
 }
 
-int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best_x, int32_t* best_cycles) {
+int slam_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max,
+                         const int32_t* gate_seqs, const slam_opt_params* params, double success_threshold) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    return decompose_impl(ctx, first, count, k_min, k_max, gate_seqs, params, success_threshold);
+}
+
+int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t count, double* best_loss,
+                             double* best_x, int32_t* best_cycles) {
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     const int nmax = 6 * (k_max + 1);
     if (ctx->result_nmax != nmax || ctx->n_targets <= 0)
         return fail(SLAM_ERR_STATE, "no resident results for k_max = %d", k_max);
-    const size_t N = (size_t)ctx->n_targets;
-    if (best_loss) HIP_TRY(hipMemcpyAsync(best_loss, ctx->best_loss.p, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (best_x) HIP_TRY(hipMemcpyAsync(best_x, ctx->best_x.p, N * nmax * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (best_cycles) HIP_TRY(hipMemcpyAsync(best_cycles, ctx->best_cycles.p, N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (first < 0 || count < 0 || first + count > ctx->n_targets)
+        return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    const size_t N = (size_t)count;
+    const size_t o = (size_t)first;
+    if (best_loss) HIP_TRY(hipMemcpyAsync(best_loss, ctx->best_loss.as<double>() + o, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (best_x) HIP_TRY(hipMemcpyAsync(best_x, ctx->best_x.as<double>() + o * nmax, N * nmax * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (best_cycles) HIP_TRY(hipMemcpyAsync(best_cycles, ctx->best_cycles.as<int32_t>() + o, N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
 }
 
+int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best_x, int32_t* best_cycles) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    return slam_fetch_results_range(ctx, k_max, 0, ctx->n_targets, best_loss, best_x, best_cycles);
+}
+
 int slam_decompose(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* params,
                    double success_threshold, double* best_loss, double* best_x, int32_t* best_cycles) {
-    int rc = decompose_impl(ctx, k_min, k_max, gate_seqs, params, success_threshold);
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    int rc = decompose_impl(ctx, 0, ctx->n_targets, k_min, k_max, gate_seqs, params, success_threshold);
     if (rc) return rc;
     return slam_fetch_results(ctx, k_max, best_loss, best_x, best_cycles);
 }

@@ -378,9 +378,16 @@ __global__ void merge_stage_kernel(MergeArgs a) {
     }
 }
 
-__global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int64_t n) {
+// reset the results of targets [first, first + n) and (optionally) write their indices as the
+// initial active list
+__global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int32_t* active, int64_t first,
+                                    int64_t n) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) { best_loss[t] = INFINITY; best_cycles[t] = -1; }
+    if (t < n) {
+        best_loss[first + t] = INFINITY;
+        best_cycles[first + t] = -1;
+        if (active) active[t] = (int32_t)(first + t);
+    }
 }
 
 // Ordered compaction of the targets that still need a longer template:
