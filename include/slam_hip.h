@@ -64,6 +64,10 @@ typedef struct slam_opt_params {
     uint64_t seed;        /* Philox key for x0 ~ U[0,2pi)^n (basis.py:106-111) */
     uint32_t flags;       /* SLAM_FLAG_* */
     uint32_t reserved;
+    double gtol_far;      /* with far_loss: also stop when |g|_inf < gtol_far and loss > far_loss, i.e. at a */
+    double far_loss;      /* stationary point that is clearly not a zero of the loss.  gtol_far = 1e-5 is SciPy's
+                             default gtol, which is what the reference runs with (optimizer.py:270-278);
+                             set gtol_far = 0 to disable */
 } slam_opt_params;
 
 typedef struct slam_stats {

@@ -9,11 +9,14 @@ over a wavefront.  This file restates that exact iteration in NumPy so tests
 can compare the kernel step by step on a CPU, and so its convergence can be
 compared with SciPy's BFGS on the same targets and seeds.
 
+Like the kernel, the inverse-Hessian approximation H (a preconditioner) is
+stored and applied in float32; loss, gradient, parameters, steps and all
+scalars are float64.
+
 Status codes mirror the C-ABI (include/slam_hip.h):
-0 converged (loss < stop_loss or |g|_inf < gtol), 1 maxiter, 2 line-search
-failure, 3 non-finite, 4 stalled at the fp64 noise floor (no representable
-decrease of the loss; happens at non-zero local minima where |g|_inf ~ 1e-9
-while loss differences fall under one ulp).
+0 converged (loss < stop_loss, or |g|_inf < gtol, or |g|_inf < gtol_far at a
+loss > far_loss), 1 maxiter, 2 line-search failure, 3 non-finite, 4 stalled at
+the fp64 noise floor (no representable decrease of the loss).
 """
 from __future__ import annotations
 
@@ -29,51 +32,68 @@ STALL_DF = 1e-15
 STALL_GNORM = 1e-5
 
 
-def minimize_port(x0, gate_seq, target, maxiter=2500, gtol=1e-9, stop_loss=1e-13, trace=None):
+def minimize_port(
+    x0, gate_seq, target, maxiter=2500, gtol=1e-9, stop_loss=1e-13, gtol_far=1e-5, far_loss=1e-6, trace=None,
+    h_dtype=np.float32,
+):
     """Returns (loss, x, iters, status, n_evals)."""
     n = len(x0)
     x = np.array(x0, dtype=np.float64)
     f, g = o.loss_and_grad(x, gate_seq, target)
     nev = 1
-    H = np.eye(n)
-    p = -g
+    if not np.isfinite(f):
+        return f, x, 0, 3, nev
+    H = np.eye(n, dtype=h_dtype)
+    p = -(H @ g.astype(h_dtype)).astype(np.float64)  # the kernel's first direction is -H g in float32 too
     gnorm = np.abs(g).max()
-    alpha = min(1.0, 1.0 / max(np.sqrt(g @ g), 1e-300))
+
+    def converged():
+        return f < stop_loss or gnorm < gtol or (gnorm < gtol_far and f > far_loss)
+
+    if converged():
+        return f, x, 0, 0, nev
+    if maxiter <= 0:
+        return f, x, 0, 1, nev
+    alpha = min(1.0, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
     it = 0
     nback = 0
     nstall = 0
     scaled = False
     status = 1
-    if not np.isfinite(f):
-        return f, x, 0, 3, nev
-    if f < stop_loss or gnorm < gtol:
-        return f, x, 0, 0, nev
     while it < maxiter:
         gp = g @ p
         if not (gp < 0):
             # not a descent direction (H lost positive-definiteness numerically): reset
-            H = np.eye(n)
+            H = np.eye(n, dtype=h_dtype)
             p = -g
             gp = g @ p
-        xt = x + alpha * p
+        s = alpha * p
+        xt = x + s
         ft, gt = o.loss_and_grad(xt, gate_seq, target)
         nev += 1
         if not np.isfinite(ft):
             ft = np.inf
         if ft <= f + ARMIJO_C1 * alpha * gp:
-            s = xt - x
             y = gt - g
             sy = s @ y
+            q = (H @ gt.astype(h_dtype)).astype(np.float64)
             if sy > CURV_EPS * np.sqrt((s @ s) * (y @ y)):
                 rho = 1.0 / sy
+                fac = 1.0
                 if not scaled:
-                    # scale the initial inverse Hessian before its first update
-                    # (Nocedal & Wright eq. 6.20)
-                    H = H * (sy / (y @ y))
+                    # scale the initial inverse Hessian before its first update (Nocedal & Wright eq. 6.20)
+                    fac = sy / (y @ y)
+                    H = H * h_dtype(fac)
                     scaled = True
-                u = H @ y
+                q = q * fac
+                u = q + fac * p  # H y = H g' - H g,  p = -H g
                 c = rho * (1.0 + rho * (y @ u))
-                H = H + c * np.outer(s, s) - rho * (np.outer(s, u) + np.outer(u, s))
+                w = c * s - rho * u
+                v = -rho * u
+                H = H + np.outer(s.astype(h_dtype), w.astype(h_dtype)) + np.outer(v.astype(h_dtype), s.astype(h_dtype))
+                pn = -(q + s * (w @ gt) + v * (s @ gt))
+            else:
+                pn = -q
             nstall = nstall + 1 if (f - ft) <= STALL_DF else 0
             x, f, g = xt, ft, gt
             it += 1
@@ -81,13 +101,13 @@ def minimize_port(x0, gate_seq, target, maxiter=2500, gtol=1e-9, stop_loss=1e-13
             if trace is not None:
                 trace.append(f)
             gnorm = np.abs(g).max()
-            if f < stop_loss or gnorm < gtol:
+            if converged():
                 status = 0
                 break
             if nstall >= 2:
                 status = 4
                 break
-            p = -(H @ g)
+            p = pn
             alpha = min(1.0, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
         else:
             # safeguarded quadratic interpolation backtrack

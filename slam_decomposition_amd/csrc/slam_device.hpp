@@ -2,15 +2,19 @@
 //
 // Work decomposition:
 //   * a QUAD (4 adjacent lanes) owns one (target, seed) work item; a 64-lane wavefront
-//     carries 16 quads -- with R = 16 restarts that is exactly one target per wavefront;
+//     carries 16 quads -- with R = 16 restarts that is one target per wavefront;
 //   * lane c of the quad owns COLUMN c of the running 4x4 product: columns of
 //     W = K_k G_k ... G_1 K_0 evolve independently under left multiplication, so the
 //     forward chain needs no cross-lane traffic; rows of (z T^+)(suffix) evolve
 //     independently under right multiplication, so the backward chain needs none either;
 //   * the only exchanges are quad reductions (DPP quad_perm shuffles) and small
-//     transposes through an LDS exchange area;
-//   * the n x n inverse-Hessian approximation lives in registers as packed symmetric
-//     4x4 blocks: lane q holds row q of every upper-triangle block.
+//     transposes through a wave-private LDS exchange area;
+//   * the 2Q gate matrices are kernel arguments: wave-uniform, so they sit in SGPRs and feed
+//     the fp64 FMAs as scalar operands (no VGPR, no LDS read);
+//   * the n x n inverse-Hessian approximation (the quasi-Newton metric, a preconditioner) is kept
+//     in fp32 VGPRs as packed symmetric 4x4 blocks -- lane q holds row q of every upper-triangle
+//     block -- and is applied / updated with packed fp32 FMAs.  Loss, gradient, parameters,
+//     steps and all scalars of the iteration are fp64.
 //
 // Reference behaviour being computed (paths relative to the reference checkout):
 //   CircuitTemplate.eval            src/slam/basis.py:102-104,124-169
@@ -20,10 +24,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "slam_sincos.hpp"
+
 namespace slamdev {
 
 constexpr int kQuadsPerWave = 16;
 constexpr int kWave = 64;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int K>
 struct Cfg {
@@ -32,12 +41,26 @@ struct Cfg {
     static constexpr int NA = (N + 3) / 4;             // parameter slots per lane
     static constexpr int NP = NA * 4;                  // padded parameter count
     static constexpr int NBLK = NA * (NA + 1) / 2;     // upper-triangle 4x4 blocks of H
-    static constexpr int XSTRIDE = NP * 4 + 4;         // doubles per quad in the exchange area
-    static constexpr int LDS_GATES = K * 32;           // doubles
+    // doubles per quad in the exchange area: >= 4 NP + 4, and == 8 (mod 32) so that the 16 quads of
+    // a wave start 16 banks apart (conflict-free b128 reads of one 16-byte slot per quad)
+    static constexpr int XSTRIDE = (NP * 4 + 4 - 8 + 31) / 32 * 32 + 8;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
     static constexpr int LDS_FH = 2 * K * 4 * kWave * 2;  // 2K column vectors x 4 rows x 64 lanes x (re,im)
-    static constexpr int LDS_DOUBLES = LDS_GATES + LDS_XCHG + LDS_FH;
+    static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH;
 };
+
+// Gate matrices G_1..G_K of the launch: K x 32 doubles, row-major (re, im), in device memory.
+// They are wave-uniform, so they are read through a constant-address-space pointer with scalar
+// loads (s_load_dwordx16) and feed the fp64 FMAs as SGPR operands: no VGPRs, no LDS reads.
+typedef const __attribute__((address_space(4))) double* gate_ptr;
+
+__device__ __forceinline__ gate_ptr gate_matrix(const double* gates, int j) {
+    // opaque to the optimiser: without it the loop-invariant loads of all K matrices are hoisted
+    // out of the iteration loop, 64 K SGPRs do not fit, and every use becomes a v_readlane.
+    unsigned long long a = (unsigned long long)(gates + 32 * j);
+    asm volatile("" : "+s"(a));
+    return (gate_ptr)a;
+}
 
 // ---------------------------------------------------------------------------------
 // quad (4-lane) cross-lane primitives: DPP quad_perm on the two 32-bit halves
@@ -49,7 +72,11 @@ __device__ __forceinline__ double dpp_f64(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-// quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2), [0,0,0,0] = 0x00 (broadcast lane 0)
 __device__ __forceinline__ double quad_sum(double v) {
     v += dpp_f64<0xB1>(v);
     v += dpp_f64<0x4E>(v);
@@ -145,27 +172,37 @@ __device__ __forceinline__ void u3_row(const U3t& t, double& u0r, double& u0i, d
 // (dU/dtheta = 1/2 U M, M = [[0, -e^{i lam}], [e^{-i lam}, 0]])
 __device__ __forceinline__ double dtheta_pair(const U3t& t, double ut0r, double ut0i, double ut1r, double ut1i,
                                               double f0r, double f0i, double f1r, double f1i) {
-    // a = ut1 * f0, b = ut0 * f1
     const double ar = ut1r * f0r - ut1i * f0i, ai = ut1r * f0i + ut1i * f0r;
     const double br = ut0r * f1r - ut0i * f1i, bi = ut0r * f1i + ut0i * f1r;
-    // Re(e^{-i lam} a) = cl*ar + sl*ai ; Re(e^{i lam} b) = cl*br - sl*bi
     return 0.5 * ((t.cl * ar + t.sl * ai) - (t.cl * br - t.sl * bi));
 }
 
 __device__ __forceinline__ double im_mul(double ar, double ai, double br, double bi) { return ar * bi + ai * br; }
 
+// cold path, kept out of line so that its register appetite (ocml's Payne-Hanek reduction) does not
+// shape the register allocation of the optimizer loop
+__device__ __attribute__((noinline)) void sincos_slow(double x, double* s, double* c) { sincos(x, s, c); }
+
+__device__ __forceinline__ void sincos_any(double x, double& s, double& c) {
+    if (__builtin_expect(fabs(x) < kSincosFastLimit, 1)) {
+        sincos_fast(x, s, c);
+    } else {
+        sincos_slow(x, &s, &c);  // huge arguments, NaN/inf propagate
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Fused forward chain + BasicCost + analytic gradient for the quad's item.
 //   xd    this lane's parameter slots: xd[a] = x[4a + q]
 //   tre/tim  column c = q of the target: T[r][c], r = 0..3
-//   gl    LDS: gate matrices G_1..G_K, row-major (re, im)
+//   gates gate matrices G_1..G_K in device memory (scalar loads -> SGPR operands)
 //   xq    LDS: this quad's exchange area (trig table, then gradient transpose)
 //   fh    LDS: this lane's slice of the stored column vectors (stride 64 double2 per row)
 // Returns loss (replicated over the quad), gd[a] = dloss/dx[4a + q] and column q of W.
 // ---------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double (&tre)[4],
-                                          const double (&tim)[4], const double* gl, double* xq, double2* fh,
+                                          const double (&tim)[4], const double* gates, double* xq, double2* fh,
                                           int q, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
                                           double (&Wi)[4]) {
     using C = Cfg<K>;
@@ -178,7 +215,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
             const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
             double s, c;
-            sincos(arg, &s, &c);
+            sincos_any(arg, s, c);
             t2[i] = make_double2(c, s);
         }
     }
@@ -207,16 +244,16 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) fh[((2 * j + 1) * 4 + r) * kWave] = make_double2(Fr[r], Fi[r]);
             // F <- G_{j+1} F
-            const double2* G = reinterpret_cast<const double2*>(gl) + j * 16;
+            const gate_ptr G = gate_matrix(gates, j);
             double nr[4], ni[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double ar = 0.0, ai = 0.0;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const double2 g = G[r * 4 + s];
-                    ar = fma(g.x, Fr[s], fma(-g.y, Fi[s], ar));
-                    ai = fma(g.x, Fi[s], fma(g.y, Fr[s], ai));
+                    const double gx = G[(r * 4 + s) * 2], gy = G[(r * 4 + s) * 2 + 1];
+                    ar = fma(gx, Fr[s], fma(-gy, Fi[s], ar));
+                    ai = fma(gx, Fi[s], fma(gy, Fr[s], ai));
                 }
                 nr[r] = ar; ni[r] = ai;
             }
@@ -224,7 +261,6 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             for (int r = 0; r < 4; ++r) { Fr[r] = nr[r]; Fi[r] = ni[r]; }
         }
     }
-
     // column q of W = template unitary (CircuitTemplate.eval)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Wr[r] = Fr[r]; Wi[r] = Fi[r]; }
@@ -250,9 +286,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         Ur[r] = zr * tre[r] + zi * tim[r];
         Ui[r] = zi * tre[r] - zr * tim[r];
     }
-    double part[C::N];
-    // h = output of the current layer (registers for j = K)
-    double Hr[4], Hi[4];
+    double Hr[4], Hi[4];  // h = output of the current layer (registers for j = K)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Hr[r] = Fr[r]; Hi[r] = Fi[r]; }
 #pragma unroll
@@ -270,8 +304,9 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         const double m1 = im_mul(Ur[1], Ui[1], Hr[1], Hi[1]);
         const double m2 = im_mul(Ur[2], Ui[2], Hr[2], Hi[2]);
         const double m3 = im_mul(Ur[3], Ui[3], Hr[3], Hi[3]);
-        part[6 * j + 1] = -(m1 + m3);  // qubit 0: rows 1, 3
-        part[6 * j + 4] = -(m2 + m3);  // qubit 1: rows 2, 3
+        double part[6];
+        part[1] = -(m1 + m3);  // qubit 0: rows 1, 3
+        part[4] = -(m2 + m3);  // qubit 1: rows 2, 3
         // u~ = u K_j
         u3_row(A, Ur[0], Ui[0], Ur[2], Ui[2]);
         u3_row(A, Ur[1], Ui[1], Ur[3], Ui[3]);
@@ -293,16 +328,24 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         const double l1 = im_mul(Ur[1], Ui[1], fr[1], fi[1]);
         const double l2 = im_mul(Ur[2], Ui[2], fr[2], fi[2]);
         const double l3 = im_mul(Ur[3], Ui[3], fr[3], fi[3]);
-        part[6 * j + 2] = -(l1 + l3);
-        part[6 * j + 5] = -(l2 + l3);
+        part[2] = -(l1 + l3);
+        part[5] = -(l2 + l3);
         // theta
-        part[6 * j + 0] = dtheta_pair(B, Ur[0], Ui[0], Ur[1], Ui[1], fr[0], fi[0], fr[1], fi[1]) +
+        part[0] = dtheta_pair(B, Ur[0], Ui[0], Ur[1], Ui[1], fr[0], fi[0], fr[1], fi[1]) +
                           dtheta_pair(B, Ur[2], Ui[2], Ur[3], Ui[3], fr[2], fi[2], fr[3], fi[3]);
-        part[6 * j + 3] = dtheta_pair(A, Ur[0], Ui[0], Ur[2], Ui[2], fr[0], fi[0], fr[2], fi[2]) +
-                          dtheta_pair(A, Ur[1], Ui[1], Ur[3], Ui[3], fr[1], fi[1], fr[3], fi[3]);
+        part[3] = dtheta_pair(A, Ur[0], Ui[0], Ur[2], Ui[2], fr[0], fi[0], fr[2], fi[2]) +
+                  dtheta_pair(A, Ur[1], Ui[1], Ur[3], Ui[3], fr[1], fi[1], fr[3], fi[3]);
+        // stash this column's 6 partials of layer j in an fh slot this lane has already consumed:
+        // h_j's slot for j < K, f_K's slot for j = K  (rows 0..2 of the slot, as double2)
+        {
+            constexpr int dummy = 0; (void)dummy;
+            const int sl = (j < K) ? (2 * j + 1) : (2 * (K - 1));
+#pragma unroll
+            for (int m = 0; m < 3; ++m) fh[(sl * 4 + m) * kWave] = make_double2(part[2 * m], part[2 * m + 1]);
+        }
         if (j > 0) {
             // u <- u~ G_j
-            const double2* G = reinterpret_cast<const double2*>(gl) + (j - 1) * 16;
+            const gate_ptr G = gate_matrix(gates, j - 1);
             double nr[4], ni[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { nr[s] = 0.0; ni[s] = 0.0; }
@@ -310,9 +353,9 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const double2 g = G[r * 4 + s];
-                    nr[s] = fma(Ur[r], g.x, fma(-Ui[r], g.y, nr[s]));
-                    ni[s] = fma(Ur[r], g.y, fma(Ui[r], g.x, ni[s]));
+                    const double gx = G[(r * 4 + s) * 2], gy = G[(r * 4 + s) * 2 + 1];
+                    nr[s] = fma(Ur[r], gx, fma(-Ui[r], gy, nr[s]));
+                    ni[s] = fma(Ur[r], gy, fma(Ui[r], gx, ni[s]));
                 }
             }
 #pragma unroll
@@ -320,106 +363,133 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         }
     }
 
-    // ---- 5. sum the 4 columns' partials and hand parameter i to lane i & 3
+    // ---- 5. sum the 4 columns' partials: the owner of parameter i = 6j + m (lane i & 3) reads the
+    //         stash of the 4 lanes of its quad
     lds_fence();
+    {
+        const double* fhd = reinterpret_cast<const double*>(fh - q);  // lane 0 of this quad
 #pragma unroll
-    for (int i = 0; i < C::N; ++i) xq[4 * i + q] = part[i];
-    lds_fence();
-#pragma unroll
-    for (int a = 0; a < C::NA; ++a) {
-        const int i = 4 * a + q;
-        const double2* p2 = reinterpret_cast<const double2*>(xq + 4 * i);
-        const double2 v0 = p2[0], v1 = p2[1];
-        const double sum = (v0.x + v0.y) + (v1.x + v1.y);
-        gd[a] = (i < C::N) ? sum : 0.0;
+        for (int a = 0; a < C::NA; ++a) {
+            const int i = 4 * a + q;
+            const int j = (i * 43) >> 8;          // i / 6 for i < 64
+            const int m = i - 6 * j;
+            const int sl = (j < K) ? (2 * j + 1) : (2 * (K - 1));
+            const double* base = fhd + ((sl * 4 + (m >> 1)) * kWave) * 2 + (m & 1);
+            const double sum = (base[0] + base[2]) + (base[4] + base[6]);
+            gd[a] = (i < C::N) ? sum : 0.0;
+        }
     }
     lds_fence();
 }
 
 // ---------------------------------------------------------------------------------
-// Packed symmetric inverse Hessian in registers: block (a, b), a <= b, index b(b+1)/2 + a;
-// lane q holds H[4a + q][4b + beta], beta = 0..3.
+// Packed symmetric fp32 inverse Hessian in registers: block (a, b), a <= b, index b(b+1)/2 + a;
+// lane q holds H[4a + q][4b + e], e = 0..3, as two f32x2.
 // ---------------------------------------------------------------------------------
 __host__ __device__ constexpr int blk(int a, int b) { return b * (b + 1) / 2 + a; }
 
 template <int NA>
-__device__ __forceinline__ void h_set_identity(double (&H)[NA * (NA + 1) / 2][4], int q) {
+struct HMat {
+    f32x2 h[NA * (NA + 1) / 2][2];
+};
+
+template <int NA>
+__device__ __forceinline__ void h_set_identity_where(HMat<NA>& H, int q, bool where) {
 #pragma unroll
     for (int b = 0; b < NA; ++b)
 #pragma unroll
         for (int a = 0; a <= b; ++a)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) H[blk(a, b)][e] = (a == b && e == q) ? 1.0 : 0.0;
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x2 cur = H.h[blk(a, b)][hh];
+                const float id0 = (a == b && 2 * hh == q) ? 1.0f : 0.0f;
+                const float id1 = (a == b && 2 * hh + 1 == q) ? 1.0f : 0.0f;
+                cur.x = where ? id0 : cur.x;
+                cur.y = where ? id1 : cur.y;
+                H.h[blk(a, b)][hh] = cur;
+            }
 }
 
-// out = H v  (v, out distributed: slot a of lane q = component 4a + q)
+// out = H v  (v, out distributed: slot a of lane q = component 4a + q); fp32 arithmetic.
+// Lane q holds row q of each upper block (a, b): it adds H[4a+q][4b+e] v[4b+e] to its own out[a]
+// and owes H[4a+q][4b+e] v[4a+q] to lane e's out[b]; those "transposed" sums go through LDS as soon
+// as column block b is finished, so only one 4-float accumulator is live at a time.
 template <int NA>
-__device__ __forceinline__ void h_matvec(const double (&H)[NA * (NA + 1) / 2][4], const double (&vd)[NA],
-                                         double* xq, int q, double (&out)[NA]) {
-#pragma unroll
-    for (int a = 0; a < NA; ++a) xq[4 * a + q] = vd[a];
-    lds_fence();
-    double accT[NA][4];
+__device__ __forceinline__ void h_matvec(const HMat<NA>& H, const double (&vd)[NA], float* xq32, int q,
+                                         double (&out)[NA]) {
+    float v32[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        out[a] = 0.0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) accT[a][e] = 0.0;
+        v32[a] = (float)vd[a];
+        xq32[4 * a + q] = v32[a];
     }
+    lds_fence();
+    float* xt = xq32 + 4 * NA;  // [b][e][q] transposed partial sums (disjoint from the v area)
+    f32x2 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[a] = f32x2{0.0f, 0.0f};
 #pragma unroll
     for (int b = 0; b < NA; ++b) {
-        const double2* p2 = reinterpret_cast<const double2*>(xq + 4 * b);
-        const double2 v01 = p2[0], v23 = p2[1];
-        const double vb[4] = {v01.x, v01.y, v23.x, v23.y};
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(xq32 + 4 * b);
+        const f32x2 vb0 = f32x2{vb.x, vb.y}, vb1 = f32x2{vb.z, vb.w};
+        f32x2 t0 = f32x2{0.0f, 0.0f}, t1 = f32x2{0.0f, 0.0f};
 #pragma unroll
         for (int a = 0; a <= b; ++a) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[a] = fma(H[blk(a, b)][e], vb[e], out[a]);
+            acc[a] = __builtin_elementwise_fma(H.h[blk(a, b)][0], vb0, acc[a]);
+            acc[a] = __builtin_elementwise_fma(H.h[blk(a, b)][1], vb1, acc[a]);
+            if (a < b) {
+                const f32x2 va = f32x2{v32[a], v32[a]};
+                t0 = __builtin_elementwise_fma(H.h[blk(a, b)][0], va, t0);
+                t1 = __builtin_elementwise_fma(H.h[blk(a, b)][1], va, t1);
+            }
         }
-#pragma unroll
-        for (int a = 0; a < b; ++a) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) accT[b][e] = fma(H[blk(a, b)][e], vd[a], accT[b][e]);
+        if (b >= 1) {
+            xt[(4 * b + 0) * 4 + q] = t0.x;
+            xt[(4 * b + 1) * 4 + q] = t0.y;
+            xt[(4 * b + 2) * 4 + q] = t1.x;
+            xt[(4 * b + 3) * 4 + q] = t1.y;
         }
     }
     lds_fence();
-    // transpose-reduce accT[b][e] (held by lane q) into lane e, slot b
 #pragma unroll
-    for (int b = 1; b < NA; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xq[(4 * b + e) * 4 + q] = accT[b][e];
-    lds_fence();
-#pragma unroll
-    for (int b = 1; b < NA; ++b) {
-        const double2* p2 = reinterpret_cast<const double2*>(xq + (4 * b + q) * 4);
-        const double2 v0 = p2[0], v1 = p2[1];
-        out[b] += (v0.x + v0.y) + (v1.x + v1.y);
+    for (int a = 0; a < NA; ++a) {
+        float o = acc[a].x + acc[a].y;
+        if (a >= 1) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xt + (4 * a + q) * 4);
+            o += (t.x + t.y) + (t.z + t.w);
+        }
+        out[a] = (double)o;
     }
     lds_fence();
 }
 
-// H += s w^T + v s^T  (rank-2 BFGS inverse update), s, w, v distributed
+// H += s w^T + v s^T  (rank-2 BFGS inverse update), s, w, v distributed (already fp32)
 template <int NA>
-__device__ __forceinline__ void h_update(double (&H)[NA * (NA + 1) / 2][4], const double (&sd)[NA],
-                                         const double (&wd)[NA], const double (&vd)[NA], double* xq, int q) {
+__device__ __forceinline__ void h_update(HMat<NA>& H, const float (&s32)[NA], const float (&w32)[NA],
+                                         const float (&v32)[NA], float* xq32, int q) {
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        xq[4 * a + q] = wd[a];
-        xq[4 * NA + 4 * a + q] = sd[a];
+        xq32[4 * a + q] = w32[a];
+        xq32[4 * NA + 4 * a + q] = s32[a];
     }
     lds_fence();
 #pragma unroll
     for (int b = 0; b < NA; ++b) {
-        const double2* pw = reinterpret_cast<const double2*>(xq + 4 * b);
-        const double2* ps = reinterpret_cast<const double2*>(xq + 4 * NA + 4 * b);
-        const double2 w01 = pw[0], w23 = pw[1], s01 = ps[0], s23 = ps[1];
-        const double wb[4] = {w01.x, w01.y, w23.x, w23.y};
-        const double sb[4] = {s01.x, s01.y, s23.x, s23.y};
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(xq32 + 4 * b);
+        const f32x4 sb = *reinterpret_cast<const f32x4*>(xq32 + 4 * NA + 4 * b);
+        const f32x2 wb0 = f32x2{wb.x, wb.y}, wb1 = f32x2{wb.z, wb.w};
+        const f32x2 sb0 = f32x2{sb.x, sb.y}, sb1 = f32x2{sb.z, sb.w};
 #pragma unroll
         for (int a = 0; a <= b; ++a) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                H[blk(a, b)][e] = fma(sd[a], wb[e], fma(vd[a], sb[e], H[blk(a, b)][e]));
+            const f32x2 sa = f32x2{s32[a], s32[a]};
+            const f32x2 va = f32x2{v32[a], v32[a]};
+            f32x2 h0 = H.h[blk(a, b)][0], h1 = H.h[blk(a, b)][1];
+            h0 = __builtin_elementwise_fma(va, sb0, h0);
+            h1 = __builtin_elementwise_fma(va, sb1, h1);
+            h0 = __builtin_elementwise_fma(sa, wb0, h0);
+            h1 = __builtin_elementwise_fma(sa, wb1, h1);
+            H.h[blk(a, b)][0] = h0;
+            H.h[blk(a, b)][1] = h1;
         }
     }
     lds_fence();

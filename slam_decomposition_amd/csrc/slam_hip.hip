@@ -82,7 +82,13 @@ struct slam_ctx {
     // decompose results
     DevBuf best_loss, best_x, best_cycles;
     int32_t result_nmax = 0;
-    DevBuf counters;  // [0]: eval counter (u64), [1]: n_out (i32)
+    DevBuf counters;  // [0,8): eval counter (u64), [8,12): compaction count, [16,20): work counter
+    DevBuf solved;
+    DevBuf span_gates;  // 64 slots x [SLAM_MAX_SPAN_EVAL][32] doubles
+    int gate_slot = 0;
+    std::vector<double> gates_host;
+    int compute_units = 0;
+    int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1] = {};
     // eval buffers
     DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary;
     slam_stats stats{};
@@ -91,7 +97,7 @@ struct slam_ctx {
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &counters, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary};
+                         &best_x, &best_cycles, &counters, &solved, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary};
         for (DevBuf* b : all) b->release();
         if (ev_a) (void)hipEventDestroy(ev_a);
         if (ev_b) (void)hipEventDestroy(ev_b);
@@ -106,29 +112,88 @@ namespace {
 template <int K>
 constexpr size_t lds_bytes() { return sizeof(double) * Cfg<K>::LDS_DOUBLES; }
 
+// copy G_1..G_K of this span, in order, into the context's small device buffer (stream-ordered)
+int stage_gates(slam_ctx* c, int k, const int32_t* gate_seq, const double** d_out) {
+    double tmp[SLAM_MAX_SPAN_EVAL * 32];
+    for (int j = 0; j < k; ++j) std::memcpy(tmp + 32 * j, c->gates_host.data() + (size_t)gate_seq[j] * 32, 32 * sizeof(double));
+    // a rotating set of slots so that an in-flight kernel never sees its matrices overwritten
+    c->gate_slot = (c->gate_slot + 1) % 64;
+    double* dst = c->span_gates.as<double>() + (size_t)c->gate_slot * SLAM_MAX_SPAN_EVAL * 32;
+    HIP_TRY(hipMemcpyAsync(dst, tmp, (size_t)k * 32 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    *d_out = dst;
+    return SLAM_OK;
+}
+
 template <int K>
-int launch_eval(slam_ctx* c, const EvalArgs& a) {
+int launch_eval(slam_ctx* c, const int32_t* gate_seq, const double* d_x, const int32_t* d_tof, int64_t M,
+                double* d_loss, double* d_grad, double* d_unitary) {
     const size_t lds = lds_bytes<K>();
     if (!c->max_lds_set[K][0]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_kernel<K>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->max_lds_set[K][0] = true;
     }
-    const int64_t blocks = (a.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    EvalArgs<K> a{};
+    a.targets = c->targets.as<double>();
+    a.x = d_x;
+    a.target_of = d_tof;
+    a.n_items = M;
+    a.loss = d_loss;
+    a.grad = d_grad;
+    a.unitary = d_unitary;
+    { int rc = stage_gates(c, K, gate_seq, &a.gates); if (rc) return rc; }
+    const int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
     hipLaunchKernelGGL(eval_kernel<K>, dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
 
+struct StageLaunch {
+    const int32_t* gate_seq;
+    const int32_t* d_active;
+    const double* d_x0;
+    int64_t n_items;
+    const slam_opt_params* prm;
+};
+
 template <int K>
-int launch_minimize(slam_ctx* c, const MinimizeArgs& a) {
+int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     const size_t lds = lds_bytes<K>();
     if (!c->max_lds_set[K][1]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_kernel<K>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_kernel<K>),
+                                                             kWave, lds));
+        if (per_cu < 1) per_cu = 1;
+        c->resident_waves[K] = (int64_t)per_cu * c->compute_units;
         c->max_lds_set[K][1] = true;
     }
-    const int64_t blocks = (a.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    const slam_opt_params* prm = sl.prm;
+    MinimizeArgs<K> a{};
+    a.targets = c->targets.as<double>();
+    a.active = sl.d_active;
+    a.x0 = sl.d_x0;
+    a.n_items = sl.n_items;
+    a.restarts = prm->restarts;
+    a.maxiter = prm->maxiter;
+    a.gtol = prm->gtol;
+    a.stop_loss = prm->stop_loss;
+    a.gtol_far = prm->gtol_far;
+    a.far_loss = prm->far_loss;
+    a.seed = prm->seed;
+    a.flags = prm->flags;
+    a.work_counter = reinterpret_cast<unsigned int*>(c->counters.as<char>() + 16);
+    a.solved = c->solved.as<int32_t>();
+    a.item_loss = c->item_loss.as<double>();
+    a.item_x = c->item_x.as<double>();
+    a.item_iters = c->item_iters.as<int32_t>();
+    a.item_status = c->item_status.as<int32_t>();
+    a.item_evals = c->item_evals.as<int32_t>();
+    { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
+    // persistent wavefronts: never more blocks than can be resident, every quad pulls items
+    int64_t blocks = (sl.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    if (blocks > c->resident_waves[K]) blocks = c->resident_waves[K];
     HIP_TRY(hipEventRecord(c->ev_a, c->stream));
     hipLaunchKernelGGL(minimize_kernel<K>, dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
@@ -159,7 +224,7 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     const int n = 6 * (k + 1);
     const int64_t M = n_active * (int64_t)prm->restarts;
     if (M <= 0) return SLAM_OK;
-    if (M / kQuadsPerWave + 1 > 0x7fffffffLL) return fail(SLAM_ERR_INVALID, "too many work items (%lld)", (long long)M);
+    if (M > 0x7fff0000LL) return fail(SLAM_ERR_INVALID, "too many work items in one stage (%lld)", (long long)M);
     HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
     HIP_TRY(c->item_x.reserve(M * n * sizeof(double)));
     HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
@@ -168,40 +233,25 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     HIP_TRY(c->stage_loss.reserve(n_active * sizeof(double)));
     HIP_TRY(c->stage_x.reserve(n_active * n * sizeof(double)));
     HIP_TRY(c->stage_restart.reserve(n_active * sizeof(int32_t)));
+    HIP_TRY(c->solved.reserve(n_active * sizeof(int32_t)));
 
-    MinimizeArgs a{};
-    a.targets = c->targets.as<double>();
-    a.gates = c->gates.as<double>();
-    a.active = d_active;
-    a.x0 = d_x0;
-    a.n_items = M;
-    a.restarts = prm->restarts;
-    a.maxiter = prm->maxiter;
-    a.gtol = prm->gtol;
-    a.stop_loss = prm->stop_loss;
-    a.seed = prm->seed;
-    a.flags = prm->flags;
-    for (int j = 0; j < k; ++j) a.gate_seq[j] = gate_seq[j];
-    a.item_loss = c->item_loss.as<double>();
-    a.item_x = c->item_x.as<double>();
-    a.item_iters = c->item_iters.as<int32_t>();
-    a.item_status = c->item_status.as<int32_t>();
-    a.item_evals = c->item_evals.as<int32_t>();
-
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8, c->stream));
+    // [0,8): eval counter, [8,12): compaction count, [16,20): work counter
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 32, c->stream));
+    if (prm->flags & SLAM_FLAG_EARLY_EXIT) HIP_TRY(hipMemsetAsync(c->solved.p, 0, n_active * sizeof(int32_t), c->stream));
+    StageLaunch sl{gate_seq, d_active, d_x0, M, prm};
     int rc;
     switch (k) {
-        case 1: rc = launch_minimize<1>(c, a); break;
-        case 2: rc = launch_minimize<2>(c, a); break;
-        case 3: rc = launch_minimize<3>(c, a); break;
+        case 1: rc = launch_minimize<1>(c, sl); break;
+        case 2: rc = launch_minimize<2>(c, sl); break;
+        case 3: rc = launch_minimize<3>(c, sl); break;
         default: return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
     }
     if (rc != SLAM_OK) return rc;
 
     ReduceArgs r{};
-    r.item_loss = a.item_loss;
-    r.item_x = a.item_x;
-    r.item_evals = a.item_evals;
+    r.item_loss = c->item_loss.as<double>();
+    r.item_x = c->item_x.as<double>();
+    r.item_evals = c->item_evals.as<int32_t>();
     r.n_active = n_active;
     r.restarts = prm->restarts;
     r.n = n;
@@ -350,6 +400,12 @@ int slam_ctx_create(int device, slam_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
     if (e == hipSuccess) e = c->counters.reserve(64);
+    if (e == hipSuccess) e = c->span_gates.reserve((size_t)64 * SLAM_MAX_SPAN_EVAL * 32 * sizeof(double));
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) c->compute_units = prop.multiProcessorCount;
+    }
     if (e != hipSuccess) {
         delete c;
         return fail(SLAM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -401,6 +457,7 @@ int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates) {
     HIP_TRY(ctx->gates.reserve(bytes));
     HIP_TRY(hipMemcpyAsync(ctx->gates.p, gates, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->gates_host.assign(gates, gates + (size_t)n_gates * 32);
     ctx->n_gates = n_gates;
     return SLAM_OK;
 }
@@ -428,22 +485,17 @@ static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
     if (unitary) HIP_TRY(ctx->ev_unitary.reserve((size_t)M * 32 * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(ctx->ev_x.p, x, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->ev_tof.p, target_of, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    EvalArgs a{};
-    a.targets = ctx->targets.as<double>();
-    a.gates = ctx->gates.as<double>();
-    a.x = ctx->ev_x.as<double>();
-    a.target_of = ctx->ev_tof.as<int32_t>();
-    a.n_items = M;
-    for (int j = 0; j < k; ++j) a.gate_seq[j] = gate_seq[j];
-    a.loss = ctx->ev_loss.as<double>();
-    a.grad = grad ? ctx->ev_grad.as<double>() : nullptr;
-    a.unitary = unitary ? ctx->ev_unitary.as<double>() : nullptr;
+    double* d_loss = ctx->ev_loss.as<double>();
+    double* d_grad = grad ? ctx->ev_grad.as<double>() : nullptr;
+    double* d_unit = unitary ? ctx->ev_unitary.as<double>() : nullptr;
+    const double* d_x = ctx->ev_x.as<double>();
+    const int32_t* d_tof = ctx->ev_tof.as<int32_t>();
     switch (k) {
-        case 1: rc = launch_eval<1>(ctx, a); break;
-        case 2: rc = launch_eval<2>(ctx, a); break;
-        case 3: rc = launch_eval<3>(ctx, a); break;
-        case 4: rc = launch_eval<4>(ctx, a); break;
-        default: rc = launch_eval<5>(ctx, a); break;
+        case 1: rc = launch_eval<1>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
+        case 2: rc = launch_eval<2>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
+        case 3: rc = launch_eval<3>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
+        case 4: rc = launch_eval<4>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
+        default: rc = launch_eval<5>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
     }
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(loss, ctx->ev_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

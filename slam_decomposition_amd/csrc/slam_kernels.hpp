@@ -13,9 +13,9 @@ constexpr double kStallGnorm = 1e-5;
 
 enum : int { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_NONFINITE = 3, ST_STALLED = 4, ST_PREEMPTED = 5 };
 
+template <int K>
 struct MinimizeArgs {
     const double* targets;    // [n_targets][32]
-    const double* gates;      // [n_gates][32]
     const int32_t* active;    // [n_active] or nullptr
     const double* x0;         // [M][n] or nullptr
     int64_t n_items;          // M = n_active * restarts
@@ -23,53 +23,45 @@ struct MinimizeArgs {
     int32_t maxiter;
     double gtol;
     double stop_loss;
+    double gtol_far;
+    double far_loss;
     uint64_t seed;
     uint32_t flags;
-    int32_t gate_seq[8];
+    unsigned int* work_counter;  // zeroed before launch
+    int32_t* solved;             // [n_active], zeroed before launch (SLAM_FLAG_EARLY_EXIT)
     // per-item outputs
     double* item_loss;        // [M]
     double* item_x;           // [M][n]
     int32_t* item_iters;      // [M]
     int32_t* item_status;     // [M]
     int32_t* item_evals;      // [M]
+    const double* gates;      // [K][32]: G_1..G_K of this span
 };
 
+template <int K>
 struct EvalArgs {
     const double* targets;
-    const double* gates;
     const double* x;          // [M][n]
     const int32_t* target_of; // [M]
     int64_t n_items;
-    int32_t gate_seq[8];
     double* loss;             // [M]
     double* grad;             // [M][n] or nullptr
     double* unitary;          // [M][4][4][2] or nullptr: W = CircuitTemplate.eval(x)
+    const double* gates;      // [K][32]: G_1..G_K of this span
 };
 
-template <int K>
-__device__ __forceinline__ void stage_gates(const double* gates, const int32_t (&gate_seq)[8], double* gl, int lane) {
-    // K * 32 doubles: lane l copies doubles l, l + 64, ...
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (lane < 32) gl[j * 32 + lane] = gates[(int64_t)gate_seq[j] * 32 + lane];
-    }
-}
-
 // ---------------------------------------------------------------------------------
-// loss + gradient for explicit parameter vectors (slam_eval_loss_grad)
+// loss + gradient (+ template unitary) for explicit parameter vectors
 // ---------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs args) {
+__global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
     using C = Cfg<K>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* gl = lds;
-    double* xchg = lds + C::LDS_GATES;
-    double2* fhbase = reinterpret_cast<double2*>(lds + C::LDS_GATES + C::LDS_XCHG);
+    double* xchg = lds;
+    double2* fhbase = reinterpret_cast<double2*>(lds + C::LDS_XCHG);
     const int lane = threadIdx.x;
     const int q = lane & 3;
     const int quad = lane >> 2;
-    stage_gates<K>(args.gates, args.gate_seq, gl, lane);
-    lds_fence();
     const int64_t item = (int64_t)blockIdx.x * kQuadsPerWave + quad;
     const bool live = item < args.n_items;
     const int64_t it = live ? item : 0;
@@ -87,7 +79,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs args) {
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad<K>(xd, tre, tim, gl, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
+    eval_quad<K>(xd, tre, tim, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -108,150 +100,219 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs args) {
 }
 
 // ---------------------------------------------------------------------------------
-// batched quasi-Newton minimisation: one quad per (target, seed)
+// batched quasi-Newton minimisation.  Persistent wavefronts: each of the 16 quads of a wave
+// owns one (target, seed) item at a time and pulls the next one from a global counter when
+// it finishes, so lanes stay busy although items need very different iteration counts.
+// All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs args) {
+__global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args) {
     using C = Cfg<K>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* gl = lds;
-    double* xchg = lds + C::LDS_GATES;
-    double2* fhbase = reinterpret_cast<double2*>(lds + C::LDS_GATES + C::LDS_XCHG);
+    double* xchg = lds;
+    double2* fhbase = reinterpret_cast<double2*>(lds + C::LDS_XCHG);
     const int lane = threadIdx.x;
     const int q = lane & 3;
     const int quad = lane >> 2;
     double* xq = xchg + quad * C::XSTRIDE;
+    float* xq32 = reinterpret_cast<float*>(xq);
     double2* fh = fhbase + lane;
-    stage_gates<K>(args.gates, args.gate_seq, gl, lane);
-    lds_fence();
+    const unsigned n_items = (unsigned)args.n_items;
 
-    const int64_t item = (int64_t)blockIdx.x * kQuadsPerWave + quad;
-    const bool live = item < args.n_items;
-    const int64_t itc = live ? item : 0;
-    const int64_t slot = itc / args.restarts;
-    const int32_t restart = (int32_t)(itc - slot * args.restarts);
-    const int32_t tgt = args.active ? args.active[slot] : (int32_t)slot;
-
-    double tre[4], tim[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        tre[r] = args.targets[(int64_t)tgt * 32 + (r * 4 + q) * 2];
-        tim[r] = args.targets[(int64_t)tgt * 32 + (r * 4 + q) * 2 + 1];
-    }
-
+    // ---- per-quad state (replicated over the quad's 4 lanes unless distributed)
+    bool live = false, fresh = false, scaled = false;
+    unsigned item = 0;
+    int slot = 0, tgt = 0;
+    int nev = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
+    double f = 0.0, alpha = 0.0, gp = 0.0, gnorm = 0.0;
+    double tre[4] = {0, 0, 0, 0}, tim[4] = {0, 0, 0, 0};
     double x[NA], g[NA], p[NA];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
-        const int i = 4 * a + q;
-        if (i < C::N) {
-            x[a] = args.x0 ? args.x0[itc * C::N + i]
-                           : x0_philox(args.seed, (uint32_t)tgt, (uint32_t)restart, (uint32_t)K, (uint32_t)i);
-        } else {
-            x[a] = 0.0;
+    for (int a = 0; a < NA; ++a) { x[a] = 0.0; g[a] = 0.0; p[a] = 0.0; }
+    HMat<NA> H;
+    h_set_identity_where<NA>(H, q, true);
+    bool exhausted = false;  // wave-uniform
+
+    while (true) {
+        // ---- 1. idle quads pull work
+        if (!exhausted && __any(!live)) {
+            bool taken = false;
+#pragma unroll 1
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                const bool want = !live;
+                const unsigned long long mask = __ballot(want && q == 0);
+                if (mask == 0ull) break;
+                const int cnt = __popcll(mask);
+                const int leader = __ffsll((long long)mask) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(args.work_counter, (unsigned)cnt);
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                const unsigned idx = (unsigned)dpp_i32<0x00>((int)(base + (unsigned)rank));
+                if (base + (unsigned)cnt >= n_items) exhausted = true;
+                if (want && idx < n_items) {
+                    const unsigned sl = idx / (unsigned)args.restarts;
+                    bool skip = false;
+                    if (args.flags & 1u)
+                        skip = __hip_atomic_load(&args.solved[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (skip) {
+                        // a sibling restart already reached stop_loss: nothing to do for this item
+                        if (q == 0) {
+                            args.item_loss[idx] = INFINITY;
+                            args.item_iters[idx] = 0;
+                            args.item_status[idx] = ST_PREEMPTED;
+                            args.item_evals[idx] = 0;
+                        }
+                    } else {
+                        item = idx;
+                        slot = (int)sl;
+                        const unsigned restart = idx - sl * (unsigned)args.restarts;
+                        tgt = args.active ? args.active[sl] : (int)sl;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            tre[r] = args.targets[(int64_t)tgt * 32 + (r * 4 + q) * 2];
+                            tim[r] = args.targets[(int64_t)tgt * 32 + (r * 4 + q) * 2 + 1];
+                        }
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            const int i = 4 * a + q;
+                            double xv = 0.0;
+                            if (i < C::N)
+                                xv = args.x0 ? args.x0[(int64_t)idx * C::N + i]
+                                             : x0_philox(args.seed, (uint32_t)tgt, restart, (uint32_t)K, (uint32_t)i);
+                            x[a] = xv;
+                            p[a] = 0.0;
+                            g[a] = 0.0;
+                        }
+                        alpha = 0.0; gp = 0.0; f = 0.0;
+                        nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
+                        scaled = false; fresh = true; live = true; taken = true;
+                    }
+                }
+                if (exhausted) break;
+            }
+            if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
         }
-    }
+        if (!__any(live)) {
+            if (exhausted) break;
+            continue;
+        }
 
-    double H[C::NBLK][4];
-    h_set_identity<NA>(H, q);
+        // early-exit flag of this quad's target (consumed at the end of the round)
+        int sflag = 0;
+        if ((args.flags & 1u) && live)
+            sflag = __hip_atomic_load(&args.solved[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    double f, Wr[4], Wi[4];
-    eval_quad<K>(x, tre, tim, gl, xq, fh, q, f, g, Wr, Wi);
-    int nev = 1, iters = 0, nback = 0, nstall = 0;
-    bool scaled = false;
-    int status = ST_MAXITER;
-    bool done = !live;
-    double gg = qdot<NA>(g, g);
-    double gnorm;
-    {
-        double m = 0.0;
+        // ---- 2. one fused loss + gradient evaluation at the trial point x + alpha p (x itself when
+        //         fresh: alpha = 0, p = 0)
+        double gt[NA];
+        double ft, Wr[4], Wi[4];
+        {
+            double xt[NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) m = fmax(m, fabs(g[a]));
-        gnorm = quad_max(m);
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a) p[a] = -g[a];
-    double gp = -gg;
-    double alpha = fmin(1.0, 1.0 / fmax(sqrt(gg), 1e-300));
-    if (!isfinite(f)) { status = ST_NONFINITE; done = true; }
-    else if (f < args.stop_loss || gnorm < args.gtol) { status = ST_CONVERGED; done = true; }
-    if (args.maxiter <= 0 && !done) { done = true; }
-
-    // every quad evaluates in lock-step; the wave leaves when all its quads are done
-    while (!__all(done)) {
-        const bool was_done = done;
-        double xt[NA], gt[NA];
-#pragma unroll
-        for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-        double ft;
-        eval_quad<K>(xt, tre, tim, gl, xq, fh, q, ft, gt, Wr, Wi);
-        const bool active = !done;
+            for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
+            eval_quad<K>(xt, tre, tim, args.gates, xq, fh, q, ft, gt, Wr, Wi);
+        }
+        const bool active = live;
         if (active) ++nev;
         const bool finite = isfinite(ft);
         const bool armijo = finite && (ft <= f + kArmijoC1 * alpha * gp);
-        const bool acc = active && armijo;
+        const bool acc = active && (fresh ? finite : armijo);
+        const bool step = acc && !fresh;  // a real quasi-Newton step (not the initial evaluation)
 
-        // ---- quasi-Newton update (masked by acc through zeroed s, y)
-        double s[NA], y[NA];
+        // ---- 3. quasi-Newton update.  s = am p and y = ym (g' - g) are formed on the fly; for quads
+        //         that do not step, am = ym = 0 and (by select) w = v = 0, so H is left unchanged.
+        const double am = step ? alpha : 0.0;
+        const double ym = step ? 1.0 : 0.0;
+        double qv[NA];
+        h_matvec<NA>(H, gt, xq32, q, qv);
+        double sy = 0.0, yy = 0.0, ss = 0.0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            s[a] = acc ? (xt[a] - x[a]) : 0.0;
-            y[a] = acc ? (gt[a] - g[a]) : 0.0;
+            const double sa = am * p[a];
+            const double ya = ym * (gt[a] - g[a]);
+            sy = fma(sa, ya, sy);
+            yy = fma(ya, ya, yy);
+            ss = fma(sa, sa, ss);
         }
-        double qv[NA];
-        h_matvec<NA>(H, gt, xq, q, qv);
-        const double sy = qdot<NA>(s, y);
-        const double yy = qdot<NA>(y, y);
-        const double ss = qdot<NA>(s, s);
-        const bool curv = acc && (sy > kCurvEps * sqrt(ss * yy));
+        sy = quad_sum(sy);
+        yy = quad_sum(yy);
+        ss = quad_sum(ss);
+        const bool curv = step && (sy > kCurvEps * sqrt(ss * yy));
         const bool first = curv && !scaled;
         scaled = scaled || curv;
         const double fac = first ? (sy / yy) : 1.0;
         if (__any(first)) {
+            const float f32 = (float)fac;
+            const f32x2 f2 = f32x2{f32, f32};
 #pragma unroll
-            for (int b = 0; b < C::NBLK; ++b)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) H[b][e] *= fac;
+            for (int b = 0; b < C::NBLK; ++b) {
+                H.h[b][0] *= f2;
+                H.h[b][1] *= f2;
+            }
         }
-        double u[NA];
+        // u = H y = H g' - H g = fac (q + p)   (p = -H g, q = H g' before the first-update scaling)
+        double yu = 0.0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             qv[a] *= fac;
-            u[a] = fma(fac, p[a], qv[a]);  // H y = H g' - H g = q + p  (p = -H g)
+            const double ua = fma(fac, p[a], qv[a]);
+            yu = fma(ym * (gt[a] - g[a]), ua, yu);
         }
-        const double yu = qdot<NA>(y, u);
+        yu = quad_sum(yu);
         const double rho = curv ? 1.0 / sy : 0.0;
         const double cf = rho * (1.0 + rho * yu);
-        double w[NA], v[NA];
+        double wg = 0.0, sg = 0.0;
+        {
+            float s32[NA], w32[NA], v32[NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            // selects, not products with rho = 0: u may be non-finite after a rejected trial point
-            w[a] = curv ? (cf * s[a] - rho * u[a]) : 0.0;
-            v[a] = curv ? (-rho * u[a]) : 0.0;
+            for (int a = 0; a < NA; ++a) {
+                const double sa = am * p[a];
+                const double ua = fma(fac, p[a], qv[a]);
+                // selects, not products with rho = 0: u may be non-finite after a rejected trial point
+                const double wa = curv ? (cf * sa - rho * ua) : 0.0;
+                const double va = curv ? (-rho * ua) : 0.0;
+                s32[a] = (float)sa;
+                w32[a] = (float)wa;
+                v32[a] = (float)va;
+                wg = fma(wa, gt[a], wg);
+                sg = fma(sa, gt[a], sg);
+            }
+            h_update<NA>(H, s32, w32, v32, xq32, q);
         }
-        h_update<NA>(H, s, w, v, xq, q);
-        const double wg = qdot<NA>(w, gt);
-        const double sg = qdot<NA>(s, gt);
+        wg = quad_sum(wg);
+        sg = quad_sum(sg);
 
-        // ---- per-quad state machine
+        // ---- 4. per-quad state machine
+        bool done = false;
         if (acc) {
-            nstall = ((f - ft) <= kStallDf) ? nstall + 1 : 0;
+            nstall = (step && (f - ft) <= kStallDf) ? nstall + 1 : 0;
             f = ft;
-            ++iters;
+            if (step) ++iters;
             nback = 0;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                x[a] = xt[a];
+                const double sa = am * p[a];
+                const double ua = fma(fac, p[a], qv[a]);
+                const double va = curv ? (-rho * ua) : 0.0;
+                x[a] += sa;
                 g[a] = gt[a];
-                p[a] = -(qv[a] + s[a] * wg + v[a] * sg);
+                p[a] = -(qv[a] + sa * wg + va * sg);
             }
         } else if (active) {
-            const double denom = 2.0 * (ft - f - gp * alpha);
-            const double anew = (finite && denom > 0.0 && isfinite(denom)) ? (-gp * alpha * alpha / denom) : 0.5 * alpha;
-            alpha = fmin(fmax(anew, 0.1 * alpha), 0.5 * alpha);
-            ++nback;
+            if (fresh) {
+                f = ft;
+                status = ST_NONFINITE;
+                done = true;
+            } else {
+                const double denom = 2.0 * (ft - f - gp * alpha);
+                const double anew = (finite && denom > 0.0 && isfinite(denom)) ? (-gp * alpha * alpha / denom) : 0.5 * alpha;
+                alpha = fmin(fmax(anew, 0.1 * alpha), 0.5 * alpha);
+                ++nback;
+            }
         }
-        // quad-uniform reductions must be executed by all lanes
+        // quad reductions are executed by all lanes
         {
             double m = 0.0;
 #pragma unroll
@@ -260,54 +321,48 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs args) {
         }
         gp = qdot<NA>(g, p);
         const double pp = qdot<NA>(p, p);
-        if (acc) alpha = fmin(1.0, kStepMax / fmax(sqrt(pp), 1e-300));
         if (acc) {
-            if (f < args.stop_loss || gnorm < args.gtol) { status = ST_CONVERGED; done = true; }
-            else if (nstall >= 2) { status = ST_STALLED; done = true; }
+            alpha = fmin(1.0, kStepMax / fmax(sqrt(pp), 1e-300));
+            if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) {
+                status = ST_CONVERGED; done = true;
+            } else if (nstall >= 2) { status = ST_STALLED; done = true; }
             else if (iters >= args.maxiter) { status = ST_MAXITER; done = true; }
-        } else if (active) {
+        } else if (active && !fresh) {
             if (nback > kMaxBacktrack) { status = (gnorm < kStallGnorm) ? ST_STALLED : ST_LINESEARCH; done = true; }
         }
+        fresh = false;
         // not a descent direction (H lost positive definiteness numerically): restart from steepest descent
-        const bool reset = !done && !(gp < 0.0);
+        const bool reset = active && !done && !(gp < 0.0);
         if (__any(reset)) {
-#pragma unroll
-            for (int b = 0; b < NA; ++b)
-#pragma unroll
-                for (int a = 0; a <= b; ++a)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        H[blk(a, b)][e] = reset ? ((a == b && e == q) ? 1.0 : 0.0) : H[blk(a, b)][e];
+            h_set_identity_where<NA>(H, q, reset);
 #pragma unroll
             for (int a = 0; a < NA; ++a) p[a] = reset ? -g[a] : p[a];
             const double gg2 = qdot<NA>(g, g);
             gp = reset ? -gg2 : gp;
         }
-        // a sibling restart of the same target reached stop_loss: stop working on that target
+        // ---- 5. early exit across the restarts of one target (optimizer.py:287-295)
         if (args.flags & 1u) {
-            const bool succ = done && !was_done && status == ST_CONVERGED && f < args.stop_loss;
-            if (__any(succ)) {
-#pragma unroll
-                for (int qd = 0; qd < kQuadsPerWave; ++qd) {
-                    const int t_qd = __builtin_amdgcn_readlane(tgt, 4 * qd);
-                    const int s_qd = __builtin_amdgcn_readlane((int)succ, 4 * qd);
-                    if (s_qd && t_qd == tgt && !done) { done = true; status = ST_PREEMPTED; }
-                }
+            if (active && !done && sflag) { status = ST_PREEMPTED; done = true; }
+            if (active && done && status == ST_CONVERGED && f < args.stop_loss && q == 0)
+                __hip_atomic_store(&args.solved[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- 6. finished items leave; their quads pull new work next round
+        if (active && done) {
+            if (q == 0) {
+                args.item_loss[item] = f;
+                args.item_iters[item] = iters;
+                args.item_status[item] = status;
+                args.item_evals[item] = nev;
             }
-        }
-    }
-
-    if (live) {
-        if (q == 0) {
-            args.item_loss[item] = f;
-            args.item_iters[item] = iters;
-            args.item_status[item] = status;
-            args.item_evals[item] = nev;
-        }
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const int i = 4 * a + q;
-            if (i < C::N) args.item_x[item * C::N + i] = x[a];
+            for (int a = 0; a < NA; ++a) {
+                const int i = 4 * a + q;
+                if (i < C::N) args.item_x[(int64_t)item * C::N + i] = x[a];
+            }
+            live = false;
+            alpha = 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) p[a] = 0.0;
         }
     }
 }
@@ -337,7 +392,7 @@ __global__ void reduce_best_kernel(ReduceArgs a) {
         for (int r = 0; r < a.restarts; ++r) {
             const double l = a.item_loss[t * a.restarts + r];
             ev += (unsigned long long)a.item_evals[t * a.restarts + r];
-            if (l < best) { best = l; br = r; }   // NaN never wins
+            if (l < best) { best = l; br = r; }   // NaN / +inf (pre-empted) never win
         }
         a.best_loss[t] = best;
         a.best_restart[t] = br;

@@ -59,7 +59,8 @@ def test_first_iterations_follow_cpu_port(hip_ctx, k, gate):
                 f, x, it, st, nev = minimize_port(x0[t, r], [gate] * k, targets[t], maxiter=maxiter)
                 assert out["item_iters"][t, r] == it
                 assert out["item_evals"][t, r] == nev
-                assert abs(out["item_loss"][t, r] - f) < 1e-9 * max(1.0, 10.0 ** maxiter * 1e-3)
+                # the inverse Hessian is float32 on both sides but summed in a different order
+                assert abs(out["item_loss"][t, r] - f) < (1e-11 if maxiter == 1 else 1e-5)
 
 
 @pytest.mark.parametrize(
@@ -99,6 +100,7 @@ def test_converged_loss_matches_scipy_bfgs(hip_ctx, name, gate, k, expect_succes
     else:
         assert np.all(out["best_loss"] > 1e-6)
     assert np.all(np.isin(out["item_status"], [0, 4]))
+    assert np.all(out["item_evals"] >= out["item_iters"] + 1)
 
 
 def test_early_exit_preempts_siblings(hip_ctx):
