@@ -200,7 +200,10 @@ __device__ __forceinline__ void sincos_any(double x, double& s, double& c) {
 //   fh    LDS: this lane's slice of the stored column vectors (stride 64 double2 per row)
 // Returns loss (replicated over the quad), gd[a] = dloss/dx[4a + q] and column q of W.
 // ---------------------------------------------------------------------------------
-template <int K>
+// HUGE_ARGS: also handle |x| >= 2e9 (out-of-line ocml path).  The optimizer kernel keeps |x| far
+// below that (x0 in [0, 2 pi) or validated by the host, steps <= 2 rad) and instantiates false, so no
+// function call -- and none of the register save/restore traffic a call site drags in -- sits in its loop.
+template <int K, bool HUGE_ARGS>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double (&tre)[4],
                                           const double (&tim)[4], const double* gates, double* xq, double2* fh,
                                           int q, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
@@ -215,7 +218,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
             const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
             double s, c;
-            sincos_any(arg, s, c);
+            if (HUGE_ARGS) sincos_any(arg, s, c);
+            else sincos_fast(arg, s, c);
             t2[i] = make_double2(c, s);
         }
     }

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad<K>(xd, tre, tim, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
+    eval_quad<K, true>(xd, tre, tim, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K>(xt, tre, tim, args.gates, xq, fh, q, ft, gt, Wr, Wi);
+            eval_quad<K, false>(xt, tre, tim, args.gates, xq, fh, q, ft, gt, Wr, Wi);
         }
         const bool active = live;
         if (active) ++nev;
@@ -226,7 +226,9 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
         const double am = step ? alpha : 0.0;
         const double ym = step ? 1.0 : 0.0;
         double qv[NA];
+        __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: interleaving them only adds live registers
         h_matvec<NA>(H, gt, xq32, q, qv);
+        __builtin_amdgcn_sched_barrier(0);
         double sy = 0.0, yy = 0.0, ss = 0.0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -279,7 +281,9 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
                 wg = fma(wa, gt[a], wg);
                 sg = fma(sa, gt[a], sg);
             }
+            __builtin_amdgcn_sched_barrier(0);
             h_update<NA>(H, s32, w32, v32, xq32, q);
+            __builtin_amdgcn_sched_barrier(0);
         }
         wg = quad_sum(wg);
         sg = quad_sum(sg);
