@@ -1,0 +1,100 @@
+"""CPU: host-side mirror of the reference interface (gates, sampler, template structure, Weyl
+coordinates, sharding) checked against the oracle.  No GPU calls."""
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as o
+from slam_decomposition_amd import gates as G
+from slam_decomposition_amd.basis import CircuitTemplate
+from slam_decomposition_amd.basis_abc import DataDictEntry
+from slam_decomposition_amd.cost_function import BasicCost
+from slam_decomposition_amd.parallel import LocalComm, merge_results, shard_range
+from slam_decomposition_amd.sampler import GateSample, HaarBatch, HaarSample
+from slam_decomposition_amd.weyl import c1c2c3
+
+
+def test_gate_matrices_match_oracle():
+    assert np.array_equal(G.CXGate().to_matrix(), o.cx_matrix())
+    for a in (0.25, 0.5, 1.0):
+        assert np.allclose(G.RiSwapGate(a).to_matrix(), o.riswap_matrix(a), atol=0, rtol=0)
+    assert np.allclose(G.BerkeleyGate().to_matrix(), o.berkeley_matrix(), atol=1e-16)
+    assert np.allclose(G.CanonicalGate(0.3, 0.2, 0.1).to_matrix(), o.canonical_matrix(0.6 / np.pi, 0.4 / np.pi, 0.2 / np.pi), atol=1e-15)
+    p = (0.3, -0.7, 0.9, 0.4, 1.3)
+    assert np.allclose(G.ConversionGainGate(*p).to_matrix(), o.conversion_gain_matrix_expm(*p), atol=5e-15)
+    assert np.asarray(G.RiSwapGate(0.5)).shape == (4, 4)  # __array__ protocol like the reference gates
+    assert G.RiSwapGate(0.5).cost() == 0.5 and G.RiSwapGate(0.5).duration == 0.5
+    assert str(G.ConversionGainGate(0, 0, np.pi / 2, 0, 1)) == "2QGate(1.57079633, 0.00000000, 1.00000000)"
+    with pytest.raises(ValueError):
+        G.gate_matrix(np.eye(3))
+
+
+def test_weyl_coordinates_match_oracle():
+    for s in range(20):
+        U = o.haar_unitary(s)
+        assert c1c2c3(U) == o.c1c2c3(U)
+    assert c1c2c3(G.SwapGate().to_matrix()) == (0.5, 0.5, 0.5)
+
+
+def test_samplers():
+    a = list(HaarSample(seed=3, n_samples=2))
+    ref = o.haar_sample_reference(3, 2)
+    assert np.array_equal(a[0], ref[0]) and np.array_equal(a[1], ref[1]) and np.array_equal(a[0], a[1])
+    b = HaarBatch(seed0=o.BENCH_TARGET_SEED0, n_samples=3).as_array()
+    assert np.array_equal(b, o.haar_batch(3))
+    (g,) = list(GateSample(G.CXGate()))
+    assert np.array_equal(g, o.cx_matrix())
+    assert len(list(HaarSample(seed=None, n_samples=0))) == 0
+
+
+def test_basic_cost_matches_oracle():
+    U, V = o.haar_unitary(1), o.haar_unitary(2)
+    c = BasicCost()
+    assert c.normalization == 1
+    assert c.unitary_fidelity(U, V) == pytest.approx(o.basic_cost(U, V), abs=1e-16)
+    assert c.unitary_fidelity(np.exp(0.3j) * V, V) < 1e-15  # global-phase invariant
+
+
+def test_circuit_template_structure():
+    t = CircuitTemplate(base_gates=[G.RiSwapGate(1.0), G.BerkeleyGate()], maximum_span_guess=3)
+    assert t.n_qubits == 2 and list(t.spanning_range) == [1, 2, 3]
+    assert (t.using_bounds, t.bounds_list, t.using_constraints, t.constraint_func, t.preseeded) == (False, None, False, None, False)
+    with pytest.raises(ValueError):
+        t.build(0)
+    t.build(3)
+    assert t.cycles == 3 and t.n_params == 24
+    assert t.gate_sequence() == [0, 1, 0]  # cycle restarts at every build (documented deviation C-2)
+    x = t.parameter_guess()
+    assert x.shape == (24,) and np.all((x >= 0) & (x < 2 * np.pi))
+    gl = t.to_gate_list(np.arange(24.0))
+    assert [g[0] for g in gl] == ["u", "u", "gate", "u", "u", "gate", "u", "u", "gate", "u", "u"]
+    assert gl[0] == ("u", 0, (0.0, 1.0, 2.0)) and gl[1] == ("u", 1, (3.0, 4.0, 5.0)) and gl[3] == ("u", 0, (6.0, 7.0, 8.0))
+    assert t.target_invariant(o.cx_matrix()) == (0.5, 0.0, 0.0)
+    assert t.target_invariant(np.eye(8)) == (-1, -1, -1, -1)
+    for kwargs in (dict(use_polytopes=True), dict(no_exterior_1q=True), dict(n_qubits=3), dict(edge_params=[[(1, 0)]])):
+        with pytest.raises(NotImplementedError):
+            CircuitTemplate(**kwargs)
+
+
+def test_qiskit_parameter_order_helpers():
+    """The reference zips Xk with name-sorted parameters (P0, P1, P10, ..., P2, ...)."""
+    order = CircuitTemplate.qiskit_parameter_order(12)
+    assert order == [0, 1, 10, 11, 2, 3, 4, 5, 6, 7, 8, 9]
+    x = np.arange(24.0)
+    assert np.array_equal(CircuitTemplate.from_qiskit_order(CircuitTemplate.to_qiskit_order(x)), x)
+    assert CircuitTemplate.qiskit_parameter_order(6) == list(range(6))
+
+
+def test_data_dict_entry():
+    d = DataDictEntry(1, 1e-12, [0.0] * 12, 1)
+    assert (d.success_label, d.loss_result, d.cycles) == (1, 1e-12, 1)
+
+
+def test_shard_range_and_local_merge():
+    for n, w in ((262144, 8), (10, 3), (5, 8), (0, 2)):
+        cover = []
+        for r in range(w):
+            f, c = shard_range(n, r, w)
+            cover.extend(range(f, f + c))
+        assert cover == list(range(n))
+    loss, x, cyc = merge_results(LocalComm(), 4, 0, np.arange(4.0), np.ones((4, 6)), np.array([1, 2, 3, 1]))
+    assert np.array_equal(loss, np.arange(4.0)) and x.shape == (4, 6) and list(cyc) == [1, 2, 3, 1]
