@@ -88,9 +88,15 @@ __device__ __forceinline__ double quad_max(double v) {
     return v;
 }
 
-// All LDS traffic is wave-private (one wavefront per workgroup); LDS instructions of a
-// wave execute in order, so only the compiler has to be kept from reordering.
-__device__ __forceinline__ void lds_fence() { __syncthreads(); }
+// All LDS traffic is wave-private (one wavefront per workgroup) and the LDS unit executes one
+// wave's instructions in order, so a write is visible to every later read of the same wave without
+// any wait: only the compiler has to be kept from reordering.  (__syncthreads() here would add
+// s_waitcnt vmcnt(0): every fence would then wait for the global result stores and target loads.)
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---------------------------------------------------------------------------------
 // Philox4x32-10 (must match oracle/slam_oracle.py:philox4x32 / x0_philox bit for bit)
