@@ -39,7 +39,7 @@ extern "C" {
 #define SLAM_ERR_STATE (-5)       /* call order: targets / basis not set */
 
 #define SLAM_MAX_SPAN_EVAL 5     /* reference default maximum_span_guess, src/slam/basis.py:59 */
-#define SLAM_MAX_SPAN_MINIMIZE 3 /* spans the in-register quasi-Newton kernel supports */
+#define SLAM_MAX_SPAN_MINIMIZE 5 /* spans the quasi-Newton kernel is instantiated for (1..3 are the tuned ones) */
 #define SLAM_MAX_GATES 256
 
 /* per-item optimizer status (slam_minimize_stage: item_status) */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libslamhip.so")
 
 MAX_SPAN_EVAL = 5
-MAX_SPAN_MINIMIZE = 3
+MAX_SPAN_MINIMIZE = 5
 
 ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED = range(6)
 FLAG_EARLY_EXIT = 1

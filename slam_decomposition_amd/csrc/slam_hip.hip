@@ -244,6 +244,8 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
         case 1: rc = launch_minimize<1>(c, sl); break;
         case 2: rc = launch_minimize<2>(c, sl); break;
         case 3: rc = launch_minimize<3>(c, sl); break;
+        case 4: rc = launch_minimize<4>(c, sl); break;
+        case 5: rc = launch_minimize<5>(c, sl); break;
         default: return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
     }
     if (rc != SLAM_OK) return rc;

@@ -128,6 +128,28 @@ def test_unsupported_arguments_raise():
     with pytest.raises(ValueError, match="Unrecognized Cost Function"):
         TemplateOptimizer(basis, Other())
     with pytest.raises(NotImplementedError):
-        TemplateOptimizer(CircuitTemplate(maximum_span_guess=5), BasicCost()).approximate_target_U(np.eye(4))
+        TemplateOptimizer(CircuitTemplate(maximum_span_guess=6), BasicCost()).approximate_target_U(np.eye(4))
     with pytest.raises(ValueError):
         basis.build(0)
+
+
+def test_default_template_span5_and_long_templates():
+    """The reference's default CircuitTemplate() has maximum_span_guess=5 (basis.py:59): spans 4 and 5
+    run on the HIP path too.  A quarter-iSWAP basis (iSWAP**0.25) needs >= 4 applications for SWAP-like
+    targets."""
+    opt = TemplateOptimizer(CircuitTemplate(), BasicCost(), training_restarts=8, seed=5)  # all defaults
+    (target,) = list(HaarSample(seed=11, n_samples=1))
+    td = opt.approximate_target_U(target)
+    assert td.success_label == 1 and td.cycles in (2, 3)
+
+    from slam_decomposition_amd.gates import SwapGate
+
+    g = o.riswap_matrix(0.25)
+    basis = CircuitTemplate(base_gates=[RiSwapGate(0.25)], maximum_span_guess=5)
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=16, seed=6, override_fail=True)
+    _, _, (td,) = opt.approximate_from_distribution(GateSample(SwapGate()))
+    assert td.cycles >= 4
+    W = o.template_eval(td.Xk, [g] * td.cycles)
+    assert abs(o.basic_cost(W, SwapGate().to_matrix()) - td.loss_result) < 1e-12
+    if td.success_label:
+        assert td.loss_result <= 1e-10

@@ -103,6 +103,23 @@ def test_converged_loss_matches_scipy_bfgs(hip_ctx, name, gate, k, expect_succes
     assert np.all(out["item_evals"] >= out["item_iters"] + 1)
 
 
+@pytest.mark.parametrize("k", [4, 5])
+def test_long_spans_converge_like_scipy(hip_ctx, k):
+    """Spans 4 and 5 (untuned instantiations of the same kernel): same minima as SciPy BFGS."""
+    N, R = 3, 4
+    targets = o.haar_batch(N, seed0=4100 + k)
+    hip_ctx.set_targets(targets)
+    hip_ctx.set_gates(SQ[None])
+    x0 = np.stack([[o.x0_philox(13, t, r, k) for r in range(R)] for t in range(N)])
+    out = hip_ctx.minimize_stage([0] * k, _params(R), x0=x0)
+    assert np.all(out["best_loss"] < 1e-12)
+    for t in range(N):
+        assert abs(o.loss(out["best_x"][t], [SQ] * k, targets[t]) - out["best_loss"][t]) < 1e-12
+        res = opt.minimize(lambda xx: o.loss_and_grad(xx, [SQ] * k, targets[t]), x0[t, 0], jac=True, method="BFGS",
+                           options={"gtol": 1e-9})
+        assert res.fun < 1e-10
+
+
 def test_early_exit_preempts_siblings(hip_ctx):
     N, R, k = 8, 16, 3
     targets = o.haar_batch(N, seed0=5150)
