@@ -135,14 +135,13 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
     bool exhausted = false;  // wave-uniform
 
     while (true) {
-        // ---- 1. idle quads pull work
-        if (!exhausted && __any(!live)) {
-            bool taken = false;
-#pragma unroll 1
-            for (int attempt = 0; attempt < 2; ++attempt) {
+        // ---- 1. idle quads pull work until every quad has an item or the queue is empty
+        //         (single exit, single back edge: the loop-carried state is large)
+        bool taken = false;
+        {
+            while (!exhausted && __any(!live)) {
                 const bool want = !live;
                 const unsigned long long mask = __ballot(want && q == 0);
-                if (mask == 0ull) break;
                 const int cnt = __popcll(mask);
                 const int leader = __ffsll((long long)mask) - 1;
                 unsigned base = 0;
@@ -190,14 +189,10 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
                         scaled = false; fresh = true; live = true; taken = true;
                     }
                 }
-                if (exhausted) break;
             }
             if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
         }
-        if (!__any(live)) {
-            if (exhausted) break;
-            continue;
-        }
+        if (!__any(live)) break;
 
         // early-exit flag of this quad's target (consumed at the end of the round)
         int sflag = 0;
