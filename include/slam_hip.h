@@ -76,6 +76,7 @@ typedef struct slam_stats {
     int64_t evals[SLAM_MAX_SPAN_EVAL + 1]; /* fused loss+grad evaluations per span k (index k) */
     int64_t items[SLAM_MAX_SPAN_EVAL + 1]; /* (target, seed) work items per span k */
     double total_ms;          /* HIP-event time of the last slam_decompose / slam_minimize_stage */
+    double kernel_ms_span[SLAM_MAX_SPAN_EVAL + 1]; /* kernel_ms split per span k */
 } slam_stats;
 
 /* Thread-local message of the last failing call on this thread. */

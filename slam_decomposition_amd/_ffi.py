@@ -13,7 +13,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libslamhip.so")
+# SLAM_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
+LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslamhip.so")
 
 MAX_SPAN_EVAL = 5
 MAX_SPAN_MINIMIZE = 5
@@ -79,6 +80,7 @@ class Stats(C.Structure):
         ("evals", C.c_int64 * (MAX_SPAN_EVAL + 1)),
         ("items", C.c_int64 * (MAX_SPAN_EVAL + 1)),
         ("total_ms", C.c_double),
+        ("kernel_ms_span", C.c_double * (MAX_SPAN_EVAL + 1)),
     ]
 
 
@@ -327,6 +329,7 @@ class Context:
             "evals": list(s.evals),
             "items": list(s.items),
             "total_ms": s.total_ms,
+            "kernel_ms_span": list(s.kernel_ms_span),
         }
 
     def reset_stats(self) -> None:

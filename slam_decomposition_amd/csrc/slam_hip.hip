@@ -272,6 +272,7 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
     c->stats.kernel_ms += ms;
+    c->stats.kernel_ms_span[k] += ms;
     c->stats.kernel_launches += 1;
     c->stats.evals[k] += (int64_t)evals;
     c->stats.items[k] += M;

@@ -240,7 +240,9 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
         const bool first = curv && !scaled;
         scaled = scaled || curv;
         const double fac = first ? (sy / yy) : 1.0;
-        if (__any(first)) {
+        {
+            // fac = 1 except at a quad's first update; unconditional (42 packed multiplies at k = 3) so
+            // that H is not redefined on one side of a branch
             const float f32 = (float)fac;
             const f32x2 f2 = f32x2{f32, f32};
 #pragma unroll
