@@ -30,6 +30,9 @@ namespace slamdev {
 
 constexpr int kQuadsPerWave = 16;
 constexpr int kWave = 64;
+// row stride (in double2) of the stored column vectors: 64 lanes + 1 pad slot, so that consecutive rows start
+// 4 banks apart and the gradient gather (different rows per lane) does not pile onto one bank column
+constexpr int kRow = kWave + 1;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +48,7 @@ struct Cfg {
     // a wave start 16 banks apart (conflict-free b128 reads of one 16-byte slot per quad)
     static constexpr int XSTRIDE = (NP * 4 + 4 - 8 + 31) / 32 * 32 + 8;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
-    static constexpr int LDS_FH = 2 * K * 4 * kWave * 2;  // 2K column vectors x 4 rows x 64 lanes x (re,im)
+    static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;  // 2K column vectors x 4 rows x (64 lanes + pad) x (re,im)
     static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH;
 };
 
@@ -242,7 +245,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     for (int j = 0; j <= K; ++j) {
         if (j > 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fh[((2 * (j - 1)) * 4 + r) * kWave] = make_double2(Fr[r], Fi[r]);
+            for (int r = 0; r < 4; ++r) fh[((2 * (j - 1)) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
         }
         const U3t B = load_u3(xq, 6 * j);      // qubit 0 gate
         const U3t A = load_u3(xq, 6 * j + 3);  // qubit 1 gate
@@ -252,7 +255,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
         if (j < K) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fh[((2 * j + 1) * 4 + r) * kWave] = make_double2(Fr[r], Fi[r]);
+            for (int r = 0; r < 4; ++r) fh[((2 * j + 1) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
             // F <- G_{j+1} F
             const gate_ptr G = gate_matrix(gates, j);
             double nr[4], ni[4];
@@ -304,7 +307,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         if (j < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((2 * j + 1) * 4 + r) * kWave];
+                const double2 v = fh[((2 * j + 1) * 4 + r) * kRow];
                 Hr[r] = v.x; Hi[r] = v.y;
             }
         }
@@ -327,7 +330,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         if (j > 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((2 * (j - 1)) * 4 + r) * kWave];
+                const double2 v = fh[((2 * (j - 1)) * 4 + r) * kRow];
                 fr[r] = v.x; fi[r] = v.y;
             }
         } else {
@@ -351,7 +354,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             constexpr int dummy = 0; (void)dummy;
             const int sl = (j < K) ? (2 * j + 1) : (2 * (K - 1));
 #pragma unroll
-            for (int m = 0; m < 3; ++m) fh[(sl * 4 + m) * kWave] = make_double2(part[2 * m], part[2 * m + 1]);
+            for (int m = 0; m < 3; ++m) fh[(sl * 4 + m) * kRow] = make_double2(part[2 * m], part[2 * m + 1]);
         }
         if (j > 0) {
             // u <- u~ G_j
@@ -384,7 +387,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             const int j = (i * 43) >> 8;          // i / 6 for i < 64
             const int m = i - 6 * j;
             const int sl = (j < K) ? (2 * j + 1) : (2 * (K - 1));
-            const double* base = fhd + ((sl * 4 + (m >> 1)) * kWave) * 2 + (m & 1);
+            const double* base = fhd + ((sl * 4 + (m >> 1)) * kRow) * 2 + (m & 1);
             const double sum = (base[0] + base[2]) + (base[4] + base[6]);
             gd[a] = (i < C::N) ? sum : 0.0;
         }
