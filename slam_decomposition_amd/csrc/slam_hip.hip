@@ -84,6 +84,7 @@ struct slam_ctx {
     int32_t result_nmax = 0;
     DevBuf counters;  // [0,8): eval counter (u64), [8,12): compaction count, [16,20): work counter
     DevBuf solved;
+    DevBuf stage_targets;
     DevBuf span_gates;  // 64 slots x [SLAM_MAX_SPAN_EVAL][32] doubles
     int gate_slot = 0;
     std::vector<double> gates_host;
@@ -97,7 +98,7 @@ struct slam_ctx {
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &counters, &solved, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary};
+                         &best_x, &best_cycles, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary};
         for (DevBuf* b : all) b->release();
         if (ev_a) (void)hipEventDestroy(ev_a);
         if (ev_b) (void)hipEventDestroy(ev_b);
@@ -150,7 +151,9 @@ int launch_eval(slam_ctx* c, const int32_t* gate_seq, const double* d_x, const i
 
 struct StageLaunch {
     const int32_t* gate_seq;
-    const int32_t* d_active;
+    const double* d_stage_targets;  // [n_active][32]
+    const int32_t* d_active;        // original target index per slot, or nullptr = first_target + slot
+    int32_t first_target;
     const double* d_x0;
     int64_t n_items;
     const slam_opt_params* prm;
@@ -171,8 +174,9 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     }
     const slam_opt_params* prm = sl.prm;
     MinimizeArgs<K> a{};
-    a.targets = c->targets.as<double>();
-    a.active = sl.d_active;
+    a.targets = sl.d_stage_targets;
+    a.orig = sl.d_active;
+    a.first_target = sl.first_target;
     a.x0 = sl.d_x0;
     a.n_items = sl.n_items;
     a.restarts = prm->restarts;
@@ -194,6 +198,10 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     // persistent wavefronts: never more blocks than can be resident, every quad pulls items
     int64_t blocks = (sl.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
     if (blocks > c->resident_waves[K]) blocks = c->resident_waves[K];
+    // a wave takes `chunk` consecutive items at a time.  Big chunks keep a target's restarts in one wave
+    // (early exit then drops the rest without ever starting them); small batches need every wave busy.
+    const int64_t per_wave = sl.n_items / (c->resident_waves[K] > 0 ? c->resident_waves[K] : 1);
+    a.chunk = per_wave >= 256 ? 64u : (per_wave >= 64 ? 32u : 16u);
     HIP_TRY(hipEventRecord(c->ev_a, c->stream));
     hipLaunchKernelGGL(minimize_kernel<K>, dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
@@ -238,7 +246,16 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     // [0,8): eval counter, [8,12): compaction count, [16,20): work counter
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 32, c->stream));
     if (prm->flags & SLAM_FLAG_EARLY_EXIT) HIP_TRY(hipMemsetAsync(c->solved.p, 0, n_active * sizeof(int32_t), c->stream));
-    StageLaunch sl{gate_seq, d_active, d_x0, M, prm};
+    const double* d_stage_targets = c->targets.as<double>();
+    if (d_active) {
+        HIP_TRY(c->stage_targets.reserve((size_t)n_active * 32 * sizeof(double)));
+        const int64_t nt = n_active * 16;
+        hipLaunchKernelGGL(gather_targets_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream,
+                           c->targets.as<double>(), d_active, n_active, c->stage_targets.as<double>());
+        HIP_TRY(hipGetLastError());
+        d_stage_targets = c->stage_targets.as<double>();
+    }
+    StageLaunch sl{gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm};
     int rc;
     switch (k) {
         case 1: rc = launch_minimize<1>(c, sl); break;

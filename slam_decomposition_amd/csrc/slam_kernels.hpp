@@ -15,8 +15,9 @@ enum : int { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_NONFINITE =
 
 template <int K>
 struct MinimizeArgs {
-    const double* targets;    // [n_targets][32]
-    const int32_t* active;    // [n_active] or nullptr
+    const double* targets;    // [n_active][32]: target of stage slot s (gathered, or the resident array itself)
+    const int32_t* orig;      // [n_active] original target index of slot s, or nullptr = first_target + s
+    int32_t first_target;
     const double* x0;         // [M][n] or nullptr
     int64_t n_items;          // M = n_active * restarts
     int32_t restarts;
@@ -27,6 +28,7 @@ struct MinimizeArgs {
     double far_loss;
     uint64_t seed;
     uint32_t flags;
+    uint32_t chunk;              // items a wave takes from the queue at a time (multiple of 16)
     unsigned int* work_counter;  // zeroed before launch
     int32_t* solved;             // [n_active], zeroed before launch (SLAM_FLAG_EARLY_EXIT)
     // per-item outputs
@@ -133,28 +135,53 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
     HMat<NA> H;
     h_set_identity_where<NA>(H, q, true);
     bool exhausted = false;  // wave-uniform
+    const unsigned kChunk = args.chunk;  // wave-uniform: 16 (small batches: spread over all waves) .. 64
+    unsigned cur_next = 0, cur_end = 0;  // wave-uniform
+    unsigned pre_base = 0;               // lane 0: base of the prefetched chunk
+    if (lane == 0) pre_base = atomicAdd(args.work_counter, kChunk);
 
     while (true) {
         // ---- 1. idle quads pull work until every quad has an item or the queue is empty
-        //         (single exit, single back edge: the loop-carried state is large)
+        //         (single exit, single back edge: the loop-carried state is large).
+        // Items are handed out from a wave-private chunk [cur_next, cur_end) of kChunk consecutive
+        // items; the next chunk is requested (one atomicAdd per wave) as soon as the current one is
+        // entered, and its base is only waited for when the current chunk runs dry.
         bool taken = false;
         {
             while (!exhausted && __any(!live)) {
+                if (cur_next >= cur_end) {
+                    const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)pre_base);
+                    cur_next = b;
+                    cur_end = (b + kChunk < n_items) ? b + kChunk : n_items;
+                    if (b >= n_items) { exhausted = true; break; }
+                    if (lane == 0) pre_base = atomicAdd(args.work_counter, kChunk);
+                }
                 const bool want = !live;
                 const unsigned long long mask = __ballot(want && q == 0);
-                const int cnt = __popcll(mask);
-                const int leader = __ffsll((long long)mask) - 1;
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(args.work_counter, (unsigned)cnt);
-                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
                 const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                const unsigned idx = (unsigned)dpp_i32<0x00>((int)(base + (unsigned)rank));
-                if (base + (unsigned)cnt >= n_items) exhausted = true;
-                if (want && idx < n_items) {
-                    const unsigned sl = idx / (unsigned)args.restarts;
-                    bool skip = false;
-                    if (args.flags & 1u)
-                        skip = __hip_atomic_load(&args.solved[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                const unsigned idx = cur_next + (unsigned)dpp_i32<0x00>(rank);
+                const unsigned sl = idx / (unsigned)args.restarts;
+                bool skip = false;
+                if ((args.flags & 1u) && want && idx < cur_end)
+                    skip = __hip_atomic_load(&args.solved[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                // the first idle quad holds item cur_next: if its target is already solved, drop all the
+                // remaining restarts of that target in this chunk at once (they are consecutive items)
+                const int leader = __ffsll((long long)mask) - 1;
+                const bool lead_skip = __builtin_amdgcn_readlane((int)skip, leader) != 0;
+                if (lead_skip) {
+                    const unsigned sl0 = cur_next / (unsigned)args.restarts;
+                    unsigned stop = (sl0 + 1u) * (unsigned)args.restarts;
+                    stop = stop < cur_end ? stop : cur_end;
+                    for (unsigned i = cur_next + (unsigned)lane; i < stop; i += kWave) {
+                        args.item_loss[i] = INFINITY;
+                        args.item_iters[i] = 0;
+                        args.item_status[i] = ST_PREEMPTED;
+                        args.item_evals[i] = 0;
+                    }
+                    cur_next = stop;
+                } else {
+                cur_next += (unsigned)__popcll(mask);
+                if (want && idx < cur_end) {
                     if (skip) {
                         // a sibling restart already reached stop_loss: nothing to do for this item
                         if (q == 0) {
@@ -167,11 +194,13 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
                         item = idx;
                         slot = (int)sl;
                         const unsigned restart = idx - sl * (unsigned)args.restarts;
-                        tgt = args.active ? args.active[sl] : (int)sl;
+                        // three independent loads (no load feeds another's address)
+                        tgt = args.orig ? args.orig[sl] : args.first_target + (int)sl;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            tre[r] = args.targets[(int64_t)tgt * 32 + (r * 4 + q) * 2];
-                            tim[r] = args.targets[(int64_t)tgt * 32 + (r * 4 + q) * 2 + 1];
+                            const double2 t = *reinterpret_cast<const double2*>(args.targets + (int64_t)sl * 32 + (r * 4 + q) * 2);
+                            tre[r] = t.x;
+                            tim[r] = t.y;
                         }
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
@@ -188,6 +217,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
                         nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
                         scaled = false; fresh = true; live = true; taken = true;
                     }
+                }
                 }
             }
             if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
@@ -213,7 +243,10 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
         if (active) ++nev;
         const bool finite = isfinite(ft);
         const bool armijo = finite && (ft <= f + kArmijoC1 * alpha * gp);
-        const bool acc = active && (fresh ? finite : armijo);
+        // flags bit 8 (profiling only): every trial point is accepted and nothing converges, so each item
+        // runs exactly maxiter rounds of "evaluation + full update" -- the pure cost of a round
+        const bool dbg_fixed = (args.flags & 0x100u) != 0;
+        const bool acc = active && (fresh ? finite : (armijo || dbg_fixed));
         const bool step = acc && !fresh;  // a real quasi-Newton step (not the initial evaluation)
 
         // ---- 3. quasi-Newton update.  s = am p and y = ym (g' - g) are formed on the fly; for quads
@@ -324,9 +357,9 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
         const double pp = qdot<NA>(p, p);
         if (acc) {
             alpha = fmin(1.0, kStepMax / fmax(sqrt(pp), 1e-300));
-            if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) {
+            if (!dbg_fixed && (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss))) {
                 status = ST_CONVERGED; done = true;
-            } else if (nstall >= 2) { status = ST_STALLED; done = true; }
+            } else if (!dbg_fixed && nstall >= 2) { status = ST_STALLED; done = true; }
             else if (iters >= args.maxiter) { status = ST_MAXITER; done = true; }
         } else if (active && !fresh) {
             if (nback > kMaxBacktrack) { status = (gnorm < kStallGnorm) ? ST_STALLED : ST_LINESEARCH; done = true; }
@@ -431,6 +464,17 @@ __global__ void merge_stage_kernel(MergeArgs a) {
         a.best_loss[t] = l;
         a.best_cycles[t] = a.k;
         for (int i = 0; i < a.n; ++i) a.best_x[t * a.nmax + i] = a.stage_x[s * a.n + i];
+    }
+}
+
+// stage inputs: gather the active targets into a dense array so that the optimizer kernel addresses a
+// slot's target directly (no active[] -> targets[] dependent load on the refill path)
+__global__ void gather_targets_kernel(const double* targets, const int32_t* active, int64_t n_active, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per double2
+    if (i < n_active * 16) {
+        const int64_t s = i >> 4;
+        const int e = (int)(i & 15);
+        reinterpret_cast<double2*>(out)[i] = reinterpret_cast<const double2*>(targets)[(int64_t)active[s] * 16 + e];
     }
 }
 
