@@ -201,6 +201,122 @@ __device__ __forceinline__ void sincos_any(double x, double& s, double& c) {
 }
 
 // ---------------------------------------------------------------------------------
+// 2Q gate application, specialised by the structure of the launch's gates (classified on the host,
+// slam_hip.hip:classify_gates).  All classes read the same dense row-major (re, im) layout; a structured
+// class simply never touches the entries that are zero by structure.
+//   GC_DENSE  any 4x4 matrix                                            16 complex mul-adds
+//   GC_XGEN   X-shaped: two complex 2x2 blocks on index pairs (0,3), (1,2)       8
+//   GC_XRI    X-shaped with real diagonal and imaginary off-diagonal block entries:
+//             RiSwapGate(alpha) (sqrt-iSWAP, iSWAP), canonical gates with c3 = 0 (B),
+//             ConversionGainGate with zero phases                                 8 real-scalar products
+//   GC_CX     qiskit CXGate: a permutation of amplitudes 1 <-> 3                 0
+// ---------------------------------------------------------------------------------
+enum : int { GC_DENSE = 0, GC_XGEN = 1, GC_XRI = 2, GC_CX = 3 };
+
+#define SLAM_GRE(r, s) G[((r) * 4 + (s)) * 2]
+#define SLAM_GIM(r, s) G[((r) * 4 + (s)) * 2 + 1]
+
+// (a, b) <- [[m00, m01], [m10, m11]] (a, b), complex entries read from G at (r0,r0) (r0,r1) (r1,r0) (r1,r1)
+template <int R0, int R1>
+__device__ __forceinline__ void block_col_gen(gate_ptr G, double (&Fr)[4], double (&Fi)[4]) {
+    const double ar = Fr[R0], ai = Fi[R0], br = Fr[R1], bi = Fi[R1];
+    Fr[R0] = fma(SLAM_GRE(R0, R0), ar, fma(-SLAM_GIM(R0, R0), ai, fma(SLAM_GRE(R0, R1), br, -SLAM_GIM(R0, R1) * bi)));
+    Fi[R0] = fma(SLAM_GRE(R0, R0), ai, fma(SLAM_GIM(R0, R0), ar, fma(SLAM_GRE(R0, R1), bi, SLAM_GIM(R0, R1) * br)));
+    Fr[R1] = fma(SLAM_GRE(R1, R0), ar, fma(-SLAM_GIM(R1, R0), ai, fma(SLAM_GRE(R1, R1), br, -SLAM_GIM(R1, R1) * bi)));
+    Fi[R1] = fma(SLAM_GRE(R1, R0), ai, fma(SLAM_GIM(R1, R0), ar, fma(SLAM_GRE(R1, R1), bi, SLAM_GIM(R1, R1) * br)));
+}
+// (a, b) <- (a, b) [[m00, m01], [m10, m11]]   (row vector times block)
+template <int R0, int R1>
+__device__ __forceinline__ void block_row_gen(gate_ptr G, double (&Ur)[4], double (&Ui)[4]) {
+    const double ar = Ur[R0], ai = Ui[R0], br = Ur[R1], bi = Ui[R1];
+    Ur[R0] = fma(ar, SLAM_GRE(R0, R0), fma(-ai, SLAM_GIM(R0, R0), fma(br, SLAM_GRE(R1, R0), -bi * SLAM_GIM(R1, R0))));
+    Ui[R0] = fma(ar, SLAM_GIM(R0, R0), fma(ai, SLAM_GRE(R0, R0), fma(br, SLAM_GIM(R1, R0), bi * SLAM_GRE(R1, R0))));
+    Ur[R1] = fma(ar, SLAM_GRE(R0, R1), fma(-ai, SLAM_GIM(R0, R1), fma(br, SLAM_GRE(R1, R1), -bi * SLAM_GIM(R1, R1))));
+    Ui[R1] = fma(ar, SLAM_GIM(R0, R1), fma(ai, SLAM_GRE(R0, R1), fma(br, SLAM_GIM(R1, R1), bi * SLAM_GRE(R1, R1))));
+}
+// the same with block = [[d0, i o01], [i o10, d1]], d*, o* real
+template <int R0, int R1>
+__device__ __forceinline__ void block_col_ri(gate_ptr G, double (&Fr)[4], double (&Fi)[4]) {
+    const double d0 = SLAM_GRE(R0, R0), o01 = SLAM_GIM(R0, R1), o10 = SLAM_GIM(R1, R0), d1 = SLAM_GRE(R1, R1);
+    const double ar = Fr[R0], ai = Fi[R0], br = Fr[R1], bi = Fi[R1];
+    Fr[R0] = fma(d0, ar, -o01 * bi);
+    Fi[R0] = fma(d0, ai, o01 * br);
+    Fr[R1] = fma(d1, br, -o10 * ai);
+    Fi[R1] = fma(d1, bi, o10 * ar);
+}
+template <int R0, int R1>
+__device__ __forceinline__ void block_row_ri(gate_ptr G, double (&Ur)[4], double (&Ui)[4]) {
+    const double d0 = SLAM_GRE(R0, R0), o01 = SLAM_GIM(R0, R1), o10 = SLAM_GIM(R1, R0), d1 = SLAM_GRE(R1, R1);
+    const double ar = Ur[R0], ai = Ui[R0], br = Ur[R1], bi = Ui[R1];
+    Ur[R0] = fma(d0, ar, -o10 * bi);
+    Ui[R0] = fma(d0, ai, o10 * br);
+    Ur[R1] = fma(d1, br, -o01 * ai);
+    Ui[R1] = fma(d1, bi, o01 * ar);
+}
+
+// F <- G F
+template <int GC>
+__device__ __forceinline__ void gate_col(gate_ptr G, double (&Fr)[4], double (&Fi)[4]) {
+    if constexpr (GC == GC_CX) {
+        const double tr = Fr[1], ti = Fi[1];
+        Fr[1] = Fr[3]; Fi[1] = Fi[3];
+        Fr[3] = tr; Fi[3] = ti;
+    } else if constexpr (GC == GC_XRI) {
+        block_col_ri<0, 3>(G, Fr, Fi);
+        block_col_ri<1, 2>(G, Fr, Fi);
+    } else if constexpr (GC == GC_XGEN) {
+        block_col_gen<0, 3>(G, Fr, Fi);
+        block_col_gen<1, 2>(G, Fr, Fi);
+    } else {
+        double nr[4], ni[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double ar = 0.0, ai = 0.0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double gx = SLAM_GRE(r, s), gy = SLAM_GIM(r, s);
+                ar = fma(gx, Fr[s], fma(-gy, Fi[s], ar));
+                ai = fma(gx, Fi[s], fma(gy, Fr[s], ai));
+            }
+            nr[r] = ar; ni[r] = ai;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Fr[r] = nr[r]; Fi[r] = ni[r]; }
+    }
+}
+
+// u <- u G
+template <int GC>
+__device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&Ui)[4]) {
+    if constexpr (GC == GC_CX) {
+        const double tr = Ur[1], ti = Ui[1];
+        Ur[1] = Ur[3]; Ui[1] = Ui[3];
+        Ur[3] = tr; Ui[3] = ti;
+    } else if constexpr (GC == GC_XRI) {
+        block_row_ri<0, 3>(G, Ur, Ui);
+        block_row_ri<1, 2>(G, Ur, Ui);
+    } else if constexpr (GC == GC_XGEN) {
+        block_row_gen<0, 3>(G, Ur, Ui);
+        block_row_gen<1, 2>(G, Ur, Ui);
+    } else {
+        double nr[4], ni[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { nr[s] = 0.0; ni[s] = 0.0; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double gx = SLAM_GRE(r, s), gy = SLAM_GIM(r, s);
+                nr[s] = fma(Ur[r], gx, fma(-Ui[r], gy, nr[s]));
+                ni[s] = fma(Ur[r], gy, fma(Ui[r], gx, ni[s]));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { Ur[s] = nr[s]; Ui[s] = ni[s]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Fused forward chain + BasicCost + analytic gradient for the quad's item.
 //   xd    this lane's parameter slots: xd[a] = x[4a + q]
 //   tre/tim  column c = q of the target: T[r][c], r = 0..3
@@ -212,7 +328,7 @@ __device__ __forceinline__ void sincos_any(double x, double& s, double& c) {
 // HUGE_ARGS: also handle |x| >= 2e9 (out-of-line ocml path).  The optimizer kernel keeps |x| far
 // below that (x0 in [0, 2 pi) or validated by the host, steps <= 2 rad) and instantiates false, so no
 // function call -- and none of the register save/restore traffic a call site drags in -- sits in its loop.
-template <int K, bool HUGE_ARGS>
+template <int K, bool HUGE_ARGS, int GC>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double (&tre)[4],
                                           const double (&tim)[4], const double* gates, double* xq, double2* fh,
                                           int q, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
@@ -257,21 +373,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) fh[((2 * j + 1) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
             // F <- G_{j+1} F
-            const gate_ptr G = gate_matrix(gates, j);
-            double nr[4], ni[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double ar = 0.0, ai = 0.0;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double gx = G[(r * 4 + s) * 2], gy = G[(r * 4 + s) * 2 + 1];
-                    ar = fma(gx, Fr[s], fma(-gy, Fi[s], ar));
-                    ai = fma(gx, Fi[s], fma(gy, Fr[s], ai));
-                }
-                nr[r] = ar; ni[r] = ai;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { Fr[r] = nr[r]; Fi[r] = ni[r]; }
+            gate_col<GC>(gate_matrix(gates, j), Fr, Fi);
         }
     }
     // column q of W = template unitary (CircuitTemplate.eval)
@@ -358,21 +460,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         }
         if (j > 0) {
             // u <- u~ G_j
-            const gate_ptr G = gate_matrix(gates, j - 1);
-            double nr[4], ni[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { nr[s] = 0.0; ni[s] = 0.0; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double gx = G[(r * 4 + s) * 2], gy = G[(r * 4 + s) * 2 + 1];
-                    nr[s] = fma(Ur[r], gx, fma(-Ui[r], gy, nr[s]));
-                    ni[s] = fma(Ur[r], gy, fma(Ui[r], gx, ni[s]));
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { Ur[s] = nr[s]; Ui[s] = ni[s]; }
+            gate_row<GC>(gate_matrix(gates, j - 1), Ur, Ui);
         }
     }
 

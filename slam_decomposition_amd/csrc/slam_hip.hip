@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -89,11 +90,11 @@ struct slam_ctx {
     int gate_slot = 0;
     std::vector<double> gates_host;
     int compute_units = 0;
-    int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1] = {};
+    int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1][4] = {};
     // eval buffers
     DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary;
     slam_stats stats{};
-    bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][2] = {};
+    bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][4][2] = {};
 
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
@@ -125,14 +126,51 @@ int stage_gates(slam_ctx* c, int k, const int32_t* gate_seq, const double** d_ou
     return SLAM_OK;
 }
 
-template <int K>
+// Structure class of the gates of one span (see slam_device.hpp: GC_*).  A launch uses the most
+// general class any of its gates needs; entries below 1e-15 count as structural zeros.
+int classify_gates(slam_ctx* c, int k, const int32_t* gate_seq) {
+    const double tol = 1e-15;
+    bool all_cx = true, all_x = true, all_xri = true;
+    for (int j = 0; j < k; ++j) {
+        const double* g = c->gates_host.data() + (size_t)gate_seq[j] * 32;
+        auto re = [&](int r, int s) { return g[(r * 4 + s) * 2]; };
+        auto im = [&](int r, int s) { return g[(r * 4 + s) * 2 + 1]; };
+        auto mag = [&](int r, int s) { return std::fabs(re(r, s)) + std::fabs(im(r, s)); };
+        // qiskit CXGate: ones at (0,0), (1,3), (2,2), (3,1)
+        bool cx = true;
+        for (int r = 0; r < 4; ++r)
+            for (int s = 0; s < 4; ++s) {
+                const bool one = (r == 0 && s == 0) || (r == 1 && s == 3) || (r == 2 && s == 2) || (r == 3 && s == 1);
+                if (std::fabs(re(r, s) - (one ? 1.0 : 0.0)) > tol || std::fabs(im(r, s)) > tol) cx = false;
+            }
+        all_cx = all_cx && cx;
+        // X shape: non-zeros only inside the blocks on index pairs (0,3) and (1,2)
+        bool x = true;
+        for (int r = 0; r < 4; ++r)
+            for (int s = 0; s < 4; ++s) {
+                const bool inside = ((r == 0 || r == 3) && (s == 0 || s == 3)) || ((r == 1 || r == 2) && (s == 1 || s == 2));
+                if (!inside && mag(r, s) > tol) x = false;
+            }
+        all_x = all_x && x;
+        const bool xri = x && std::fabs(im(0, 0)) <= tol && std::fabs(im(3, 3)) <= tol && std::fabs(im(1, 1)) <= tol &&
+                         std::fabs(im(2, 2)) <= tol && std::fabs(re(0, 3)) <= tol && std::fabs(re(3, 0)) <= tol &&
+                         std::fabs(re(1, 2)) <= tol && std::fabs(re(2, 1)) <= tol;
+        all_xri = all_xri && xri;
+    }
+    if (all_cx) return GC_CX;
+    if (all_xri) return GC_XRI;
+    if (all_x) return GC_XGEN;
+    return GC_DENSE;
+}
+
+template <int K, int GC>
 int launch_eval(slam_ctx* c, const int32_t* gate_seq, const double* d_x, const int32_t* d_tof, int64_t M,
                 double* d_loss, double* d_grad, double* d_unitary) {
     const size_t lds = lds_bytes<K>();
-    if (!c->max_lds_set[K][0]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_kernel<K>),
+    if (!c->max_lds_set[K][GC][0]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_kernel<K, GC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        c->max_lds_set[K][0] = true;
+        c->max_lds_set[K][GC][0] = true;
     }
     EvalArgs<K> a{};
     a.targets = c->targets.as<double>();
@@ -144,7 +182,7 @@ int launch_eval(slam_ctx* c, const int32_t* gate_seq, const double* d_x, const i
     a.unitary = d_unitary;
     { int rc = stage_gates(c, K, gate_seq, &a.gates); if (rc) return rc; }
     const int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
-    hipLaunchKernelGGL(eval_kernel<K>, dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
+    hipLaunchKernelGGL((eval_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
@@ -159,18 +197,18 @@ struct StageLaunch {
     const slam_opt_params* prm;
 };
 
-template <int K>
+template <int K, int GC>
 int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     const size_t lds = lds_bytes<K>();
-    if (!c->max_lds_set[K][1]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_kernel<K>),
+    if (!c->max_lds_set[K][GC][1]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_kernel<K, GC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_kernel<K>),
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_kernel<K, GC>),
                                                              kWave, lds));
         if (per_cu < 1) per_cu = 1;
-        c->resident_waves[K] = (int64_t)per_cu * c->compute_units;
-        c->max_lds_set[K][1] = true;
+        c->resident_waves[K][GC] = (int64_t)per_cu * c->compute_units;
+        c->max_lds_set[K][GC][1] = true;
     }
     const slam_opt_params* prm = sl.prm;
     MinimizeArgs<K> a{};
@@ -197,13 +235,13 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
     // persistent wavefronts: never more blocks than can be resident, every quad pulls items
     int64_t blocks = (sl.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
-    if (blocks > c->resident_waves[K]) blocks = c->resident_waves[K];
+    if (blocks > c->resident_waves[K][GC]) blocks = c->resident_waves[K][GC];
     // a wave takes `chunk` consecutive items at a time.  Big chunks keep a target's restarts in one wave
     // (early exit then drops the rest without ever starting them); small batches need every wave busy.
-    const int64_t per_wave = sl.n_items / (c->resident_waves[K] > 0 ? c->resident_waves[K] : 1);
+    const int64_t per_wave = sl.n_items / (c->resident_waves[K][GC] > 0 ? c->resident_waves[K][GC] : 1);
     a.chunk = per_wave >= 256 ? 64u : (per_wave >= 64 ? 32u : 16u);
     HIP_TRY(hipEventRecord(c->ev_a, c->stream));
-    hipLaunchKernelGGL(minimize_kernel<K>, dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
+    hipLaunchKernelGGL((minimize_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_b, c->stream));
     return SLAM_OK;
@@ -257,12 +295,20 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     }
     StageLaunch sl{gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm};
     int rc;
+    const int gc = classify_gates(c, k, gate_seq);
+#define SLAM_MIN_CASE(KK)                                                   \
+    case KK:                                                                \
+        if (gc == GC_CX) rc = launch_minimize<KK, GC_CX>(c, sl);            \
+        else if (gc == GC_XRI) rc = launch_minimize<KK, GC_XRI>(c, sl);     \
+        else if (gc == GC_XGEN) rc = launch_minimize<KK, GC_XGEN>(c, sl);   \
+        else rc = launch_minimize<KK, GC_DENSE>(c, sl);                     \
+        break;
     switch (k) {
-        case 1: rc = launch_minimize<1>(c, sl); break;
-        case 2: rc = launch_minimize<2>(c, sl); break;
-        case 3: rc = launch_minimize<3>(c, sl); break;
-        case 4: rc = launch_minimize<4>(c, sl); break;
-        case 5: rc = launch_minimize<5>(c, sl); break;
+        SLAM_MIN_CASE(1)
+        SLAM_MIN_CASE(2)
+        SLAM_MIN_CASE(3)
+        case 4: rc = launch_minimize<4, GC_DENSE>(c, sl); break;
+        case 5: rc = launch_minimize<5, GC_DENSE>(c, sl); break;
         default: return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
     }
     if (rc != SLAM_OK) return rc;
@@ -510,12 +556,25 @@ static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
     double* d_unit = unitary ? ctx->ev_unitary.as<double>() : nullptr;
     const double* d_x = ctx->ev_x.as<double>();
     const int32_t* d_tof = ctx->ev_tof.as<int32_t>();
+    const int gc = classify_gates(ctx, k, gate_seq);
+#define SLAM_EVAL_CASE(KK)                                                                                  \
+    case KK:                                                                                                \
+        if (gc == GC_CX) rc = launch_eval<KK, GC_CX>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);   \
+        else if (gc == GC_XRI) rc = launch_eval<KK, GC_XRI>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); \
+        else if (gc == GC_XGEN) rc = launch_eval<KK, GC_XGEN>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); \
+        else rc = launch_eval<KK, GC_DENSE>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);          \
+        break;
     switch (k) {
-        case 1: rc = launch_eval<1>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
-        case 2: rc = launch_eval<2>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
-        case 3: rc = launch_eval<3>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
-        case 4: rc = launch_eval<4>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
-        default: rc = launch_eval<5>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break;
+        SLAM_EVAL_CASE(1)
+        SLAM_EVAL_CASE(2)
+        SLAM_EVAL_CASE(3)
+        SLAM_EVAL_CASE(4)
+        default:
+            if (gc == GC_CX) rc = launch_eval<5, GC_CX>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
+            else if (gc == GC_XRI) rc = launch_eval<5, GC_XRI>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
+            else if (gc == GC_XGEN) rc = launch_eval<5, GC_XGEN>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
+            else rc = launch_eval<5, GC_DENSE>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
+            break;
     }
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(loss, ctx->ev_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

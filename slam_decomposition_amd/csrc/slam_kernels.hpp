@@ -55,7 +55,7 @@ struct EvalArgs {
 // ---------------------------------------------------------------------------------
 // loss + gradient (+ template unitary) for explicit parameter vectors
 // ---------------------------------------------------------------------------------
-template <int K>
+template <int K, int GC>
 __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
     using C = Cfg<K>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad<K, true>(xd, tre, tim, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
+    eval_quad<K, true, GC>(xd, tre, tim, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
 // it finishes, so lanes stay busy although items need very different iteration counts.
 // All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
-template <int K>
+template <int K, int GC>
 __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args) {
     using C = Cfg<K>;
     constexpr int NA = C::NA;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K, false>(xt, tre, tim, args.gates, xq, fh, q, ft, gt, Wr, Wi);
+            eval_quad<K, false, GC>(xt, tre, tim, args.gates, xq, fh, q, ft, gt, Wr, Wi);
         }
         const bool active = live;
         if (active) ++nev;
