@@ -148,7 +148,12 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
         // entered, and its base is only waited for when the current chunk runs dry.
         bool taken = false;
         {
-            while (!exhausted && __any(!live)) {
+            // the refill code is wave-wide (everyone waits while it runs), so at short spans -- where
+            // items last only ~40 rounds -- it pays to let kRefillBatch quads go idle before running it
+            constexpr int kRefillBatch = (K == 1) ? 3 : (K == 2 ? 2 : 1);
+            const int n_idle = __popcll(__ballot(!live && q == 0));
+            const bool go = n_idle >= kRefillBatch || n_idle == __popcll(__ballot(q == 0));
+            while (go && !exhausted && __any(!live)) {
                 if (cur_next >= cur_end) {
                     const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)pre_base);
                     cur_next = b;
