@@ -51,6 +51,7 @@ class TemplateOptimizer:
         training_restarts=None,
         override_method=None,
         device=None,
+        devices=None,
         seed=None,
         gtol=DEFAULT_GTOL,
         stop_loss=None,
@@ -84,6 +85,11 @@ class TemplateOptimizer:
         if self.training_restarts <= 0:
             raise ValueError("training_restarts must be positive")
         self.device = basis.device if device is None else device
+        # several GPUs in one process: targets are sharded contiguously over `devices` (one host thread and
+        # one libslamhip context per entry), results concatenated on the host -- no collective needed
+        self.devices = [self.device] if devices is None else list(devices)
+        if not self.devices:
+            raise ValueError("devices must not be empty")
         self.seed = seed
         self.gtol = float(gtol)
         if stop_loss is None:
@@ -119,14 +125,53 @@ class TemplateOptimizer:
                 f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path "
                 f"(got maximum_span_guess = {ks[-1]})"
             )
-        ctx = runtime.get_context(self.device)
-        ctx.set_targets(targets)
-        ctx.set_gates(self.basis.gate_matrices)
         gate_seqs = [self.basis.gate_sequence(k) for k in ks]
-        ctx.reset_stats()
-        best_loss, best_x, best_cycles = ctx.decompose(ks[0], ks[-1], gate_seqs, self._opt_params(), self.success_threshold)
-        self.last_stats = ctx.stats()
-        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(len(targets))]
+        prm = self._opt_params()
+        n = len(targets)
+
+        def run_shard(device, first, count):
+            # a private context per shard: the seeds are keyed on the index *within the context's batch*, so
+            # every shard uploads the whole batch and works on its window (targets are 512 B each)
+            ctx = runtime.get_context(device) if len(self.devices) == 1 else _ffi.Context(device)
+            try:
+                ctx.set_targets(targets)
+                ctx.set_gates(self.basis.gate_matrices)
+                ctx.reset_stats()
+                out = ctx.decompose_range(first, count, ks[0], ks[-1], gate_seqs, prm, self.success_threshold)
+                return out, ctx.stats()
+            finally:
+                if len(self.devices) > 1:
+                    ctx.close()
+
+        if len(self.devices) == 1 or n < len(self.devices):
+            (best_loss, best_x, best_cycles), self.last_stats = run_shard(self.devices[0], 0, n)
+        else:
+            import threading
+
+            from .parallel import shard_range
+
+            parts = [None] * len(self.devices)
+            errors = []
+
+            def work(r):
+                try:
+                    first, count = shard_range(n, r, len(self.devices))
+                    parts[r] = run_shard(self.devices[r], first, count)
+                except Exception as exc:  # surfaced below, in rank order
+                    errors.append(exc)
+
+            threads = [threading.Thread(target=work, args=(r,)) for r in range(len(self.devices))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            best_loss = np.concatenate([p[0][0] for p in parts])
+            best_x = np.concatenate([p[0][1] for p in parts])
+            best_cycles = np.concatenate([p[0][2] for p in parts])
+            self.last_stats = [p[1] for p in parts]
+        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
         return best_loss, xs, best_cycles
 
     def _finish_target(self, target_U, target_coordinates, best_result, best_Xk, best_cycles) -> DataDictEntry:

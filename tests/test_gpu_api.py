@@ -153,3 +153,24 @@ def test_default_template_span5_and_long_templates():
     assert abs(o.basic_cost(W, SwapGate().to_matrix()) - td.loss_result) < 1e-12
     if td.success_label:
         assert td.loss_result <= 1e-10
+
+
+def test_devices_list_shards_targets_and_matches_single_device():
+    """TemplateOptimizer(devices=[...]) shards the batch over several contexts (here twice the same GPU)
+    and returns what the single-device run returns: the seeds are keyed on the absolute target index."""
+    N = 11
+    sampler = HaarBatch(seed0=4321, n_samples=N)
+    kw = dict(training_restarts=8, seed=77)
+
+    def run(**extra):
+        basis = CircuitTemplate(base_gates=[BerkeleyGate()], maximum_span_guess=2)
+        opt = TemplateOptimizer(basis, BasicCost(), **kw, **extra)
+        return opt.approximate_from_distribution(sampler)[2]
+
+    one = run()
+    two = run(devices=[0, 0])
+    three = run(devices=[0, 0, 0])
+    for a, b, c in zip(one, two, three):
+        assert a.cycles == b.cycles == c.cycles == 2
+        assert a.success_label == b.success_label == c.success_label == 1
+        assert max(a.loss_result, b.loss_result, c.loss_result) < 1e-10
