@@ -44,13 +44,26 @@ struct Cfg {
     static constexpr int NA = (N + 3) / 4;             // parameter slots per lane
     static constexpr int NP = NA * 4;                  // padded parameter count
     static constexpr int NBLK = NA * (NA + 1) / 2;     // upper-triangle 4x4 blocks of H
-    // doubles per quad in the exchange area: >= 4 NP + 4, and == 8 (mod 32) so that the 16 quads of
-    // a wave start 16 banks apart (conflict-free b128 reads of one 16-byte slot per quad)
-    static constexpr int XSTRIDE = (NP * 4 + 4 - 8 + 31) / 32 * 32 + 8;
+    // doubles per quad in the exchange area.  Users: trig table [0, 2N) + layer-K gradient stash
+    // [2N, 2N + 24); fp32 mat-vec broadcast + transposed partial sums (20 NA floats); fp32 rank-2 update
+    // broadcasts (8 NA floats).  Rounded up to == 8 (mod 32) so that the 16 quads of a wave start 16
+    // banks apart (conflict-free b128 reads of one 16-byte slot per quad).
+    static constexpr int XNEED = (2 * N + 24 > 10 * NA) ? 2 * N + 24 : 10 * NA;
+    static constexpr int XSTRIDE = (XNEED - 8 + 31) / 32 * 32 + 8;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
     static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;  // 2K column vectors x 4 rows x (64 lanes + pad) x (re,im)
     static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH;
+    // LEAN layout (structured gate classes): only the K layer outputs h_j are stored; the layer inputs
+    // f_j = G_j h_{j-1} are recomputed in the backward pass (0 / 8 / 16 products for CX / XRI / XGEN gates)
+    static constexpr int LDS_FH_LEAN = K * 4 * kRow * 2;
+    static constexpr int LDS_DOUBLES_LEAN = LDS_XCHG + LDS_FH_LEAN;
+    static_assert(2 * N + 24 <= XSTRIDE, "exchange area too small for the layer-K stash");
 };
+
+template <int K, int GC>
+__host__ __device__ constexpr bool lean_layout() { return GC != 0; }  // every class but GC_DENSE
+template <int K, int GC>
+__host__ __device__ constexpr int lds_doubles() { return lean_layout<K, GC>() ? Cfg<K>::LDS_DOUBLES_LEAN : Cfg<K>::LDS_DOUBLES; }
 
 // Gate matrices G_1..G_K of the launch: K x 32 doubles, row-major (re, im), in device memory.
 // They are wave-uniform, so they are read through a constant-address-space pointer with scalar
@@ -319,7 +332,8 @@ __device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&U
 // ---------------------------------------------------------------------------------
 // Fused forward chain + BasicCost + analytic gradient for the quad's item.
 //   xd    this lane's parameter slots: xd[a] = x[4a + q]
-//   tre/tim  column c = q of the target: T[r][c], r = 0..3
+//   tcol  global pointer to T[0][q] of the item's target (row-major (re, im): T[r][q] is 8 r doubles on);
+//         the column is re-read every evaluation (L1/L2 hits) instead of living in 16 registers
 //   gates gate matrices G_1..G_K in device memory (scalar loads -> SGPR operands)
 //   xq    LDS: this quad's exchange area (trig table, then gradient transpose)
 //   fh    LDS: this lane's slice of the stored column vectors (stride 64 double2 per row)
@@ -329,11 +343,13 @@ __device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&U
 // below that (x0 in [0, 2 pi) or validated by the host, steps <= 2 rad) and instantiates false, so no
 // function call -- and none of the register save/restore traffic a call site drags in -- sits in its loop.
 template <int K, bool HUGE_ARGS, int GC>
-__device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double (&tre)[4],
-                                          const double (&tim)[4], const double* gates, double* xq, double2* fh,
+__device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double* tcol,
+                                          const double* gates, double* xq, double2* fh,
                                           int q, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
                                           double (&Wi)[4]) {
     using C = Cfg<K>;
+    constexpr bool LEAN = lean_layout<K, GC>();
+    auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
     // ---- 1. trig table: each lane handles its own parameter slots
     {
         double2* t2 = reinterpret_cast<double2*>(xq);
@@ -359,7 +375,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     }
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
-        if (j > 0) {
+        if (j > 0 && !LEAN) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) fh[((2 * (j - 1)) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
         }
@@ -371,7 +387,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
         if (j < K) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fh[((2 * j + 1) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
+            for (int r = 0; r < 4; ++r) fh[(HS(j) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
             // F <- G_{j+1} F
             gate_col<GC>(gate_matrix(gates, j), Fr, Fi);
         }
@@ -381,6 +397,13 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     for (int r = 0; r < 4; ++r) { Wr[r] = Fr[r]; Wi[r] = Fi[r]; }
 
     // ---- 3. t = Tr(T^+ W), loss, z = -conj(t) / (4|t|)
+    double tre[4], tim[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
+        tre[r] = t.x;
+        tim[r] = t.y;
+    }
     double pr = 0.0, pi = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -409,7 +432,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         if (j < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((2 * j + 1) * 4 + r) * kRow];
+                const double2 v = fh[(HS(j) * 4 + r) * kRow];
                 Hr[r] = v.x; Hi[r] = v.y;
             }
         }
@@ -432,9 +455,10 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         if (j > 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((2 * (j - 1)) * 4 + r) * kRow];
+                const double2 v = fh[((LEAN ? HS(j - 1) : 2 * (j - 1)) * 4 + r) * kRow];
                 fr[r] = v.x; fi[r] = v.y;
             }
+            if (LEAN) gate_col<GC>(gate_matrix(gates, j - 1), fr, fi);  // f_j = G_j h_{j-1}
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fr[r] = (r == q) ? 1.0 : 0.0; fi[r] = 0.0; }
@@ -452,9 +476,12 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
                   dtheta_pair(A, Ur[1], Ui[1], Ur[3], Ui[3], fr[1], fi[1], fr[3], fi[3]);
         // stash this column's 6 partials of layer j in an fh slot this lane has already consumed:
         // h_j's slot for j < K, f_K's slot for j = K  (rows 0..2 of the slot, as double2)
-        {
-            constexpr int dummy = 0; (void)dummy;
-            const int sl = (j < K) ? (2 * j + 1) : (2 * (K - 1));
+        if (LEAN && j == K) {
+            // no consumed slot yet at the top layer: its partials go behind the trig table, [m][q]
+#pragma unroll
+            for (int m = 0; m < 6; ++m) xq[2 * C::N + 4 * m + q] = part[m];
+        } else {
+            const int sl = (j < K) ? HS(j) : (2 * (K - 1));
 #pragma unroll
             for (int m = 0; m < 3; ++m) fh[(sl * 4 + m) * kRow] = make_double2(part[2 * m], part[2 * m + 1]);
         }
@@ -474,9 +501,11 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             const int i = 4 * a + q;
             const int j = (i * 43) >> 8;          // i / 6 for i < 64
             const int m = i - 6 * j;
-            const int sl = (j < K) ? (2 * j + 1) : (2 * (K - 1));
+            const int sl = (j < K) ? HS(j) : (2 * (K - 1));
             const double* base = fhd + ((sl * 4 + (m >> 1)) * kRow) * 2 + (m & 1);
-            const double sum = (base[0] + base[2]) + (base[4] + base[6]);
+            int stride = 2;  // the 4 lanes' stashes are 16 bytes apart in an fh row
+            if (LEAN && j >= K) { base = xq + 2 * C::N + 4 * m; stride = 1; }
+            const double sum = (base[0] + base[stride]) + (base[2 * stride] + base[3 * stride]);
             gd[a] = (i < C::N) ? sum : 0.0;
         }
     }

@@ -111,8 +111,8 @@ struct slam_ctx {
 
 namespace {
 
-template <int K>
-constexpr size_t lds_bytes() { return sizeof(double) * Cfg<K>::LDS_DOUBLES; }
+template <int K, int GC>
+constexpr size_t lds_bytes() { return sizeof(double) * lds_doubles<K, GC>(); }
 
 // copy G_1..G_K of this span, in order, into the context's small device buffer (stream-ordered)
 int stage_gates(slam_ctx* c, int k, const int32_t* gate_seq, const double** d_out) {
@@ -166,7 +166,7 @@ int classify_gates(slam_ctx* c, int k, const int32_t* gate_seq) {
 template <int K, int GC>
 int launch_eval(slam_ctx* c, const int32_t* gate_seq, const double* d_x, const int32_t* d_tof, int64_t M,
                 double* d_loss, double* d_grad, double* d_unitary) {
-    const size_t lds = lds_bytes<K>();
+    const size_t lds = lds_bytes<K, GC>();
     if (!c->max_lds_set[K][GC][0]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_kernel<K, GC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -199,7 +199,7 @@ struct StageLaunch {
 
 template <int K, int GC>
 int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
-    const size_t lds = lds_bytes<K>();
+    const size_t lds = lds_bytes<K, GC>();
     if (!c->max_lds_set[K][GC][1]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_kernel<K, GC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -68,12 +68,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
     const bool live = item < args.n_items;
     const int64_t it = live ? item : 0;
     const int64_t tgt = args.target_of[it];
-    double tre[4], tim[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        tre[r] = args.targets[tgt * 32 + (r * 4 + q) * 2];
-        tim[r] = args.targets[tgt * 32 + (r * 4 + q) * 2 + 1];
-    }
+    const double* tcol = args.targets + tgt * 32 + q * 2;
     double xd[C::NA], gd[C::NA];
 #pragma unroll
     for (int a = 0; a < C::NA; ++a) {
@@ -81,7 +76,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad<K, true, GC>(xd, tre, tim, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
+    eval_quad<K, true, GC>(xd, tcol, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -108,7 +103,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
 // All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
 template <int K, int GC>
-__global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args) {
+__global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args) {
     using C = Cfg<K>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -128,7 +123,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
     int slot = 0, tgt = 0;
     int nev = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
     double f = 0.0, alpha = 0.0, gp = 0.0, gnorm = 0.0;
-    double tre[4] = {0, 0, 0, 0}, tim[4] = {0, 0, 0, 0};
+    const double* tcol = args.targets + q * 2;  // this lane's column of the quad's target
     double x[NA], g[NA], p[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) { x[a] = 0.0; g[a] = 0.0; p[a] = 0.0; }
@@ -201,12 +196,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
                         const unsigned restart = idx - sl * (unsigned)args.restarts;
                         // three independent loads (no load feeds another's address)
                         tgt = args.orig ? args.orig[sl] : args.first_target + (int)sl;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double2 t = *reinterpret_cast<const double2*>(args.targets + (int64_t)sl * 32 + (r * 4 + q) * 2);
-                            tre[r] = t.x;
-                            tim[r] = t.y;
-                        }
+                        tcol = args.targets + (int64_t)sl * 32 + q * 2;
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
                             const int i = 4 * a + q;
@@ -242,7 +232,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_kernel(MinimizeArgs<K> args
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K, false, GC>(xt, tre, tim, args.gates, xq, fh, q, ft, gt, Wr, Wi);
+            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, q, ft, gt, Wr, Wi);
         }
         const bool active = live;
         if (active) ++nev;
