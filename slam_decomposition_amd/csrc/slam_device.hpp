@@ -44,12 +44,12 @@ struct Cfg {
     static constexpr int NA = (N + 3) / 4;             // parameter slots per lane
     static constexpr int NP = NA * 4;                  // padded parameter count
     static constexpr int NBLK = NA * (NA + 1) / 2;     // upper-triangle 4x4 blocks of H
-    // doubles per quad in the exchange area.  Users: trig table [0, 2N) + layer-K gradient stash
-    // [2N, 2N + 24); fp32 mat-vec broadcast + transposed partial sums (20 NA floats); fp32 rank-2 update
-    // broadcasts (8 NA floats).  Rounded up to == 8 (mod 32) so that the 16 quads of a wave start 16
-    // banks apart (conflict-free b128 reads of one 16-byte slot per quad).
-    static constexpr int XNEED = (2 * N + 24 > 10 * NA) ? 2 * N + 24 : 10 * NA;
-    static constexpr int XSTRIDE = (XNEED - 8 + 31) / 32 * 32 + 8;
+    // doubles per quad in the exchange area.  Users: trig table [0, 2N) (the top layer's entries later
+    // hold that layer's pair-summed gradient partials); fp32 mat-vec broadcast (4 NA floats) + transposed
+    // partial sums (16 (NA - 1) floats); fp32 rank-2 update broadcasts (8 NA floats).  Rounded up to
+    // == 8 (mod 16) so that the four quads of a b128 read group start 16 banks apart.
+    static constexpr int XNEED = (2 * N > 10 * NA - 8) ? 2 * N : 10 * NA - 8;
+    static constexpr int XSTRIDE = (XNEED - 8 + 15) / 16 * 16 + 8;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
     static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;  // 2K column vectors x 4 rows x (64 lanes + pad) x (re,im)
     static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH;
@@ -57,7 +57,6 @@ struct Cfg {
     // f_j = G_j h_{j-1} are recomputed in the backward pass (0 / 8 / 16 products for CX / XRI / XGEN gates)
     static constexpr int LDS_FH_LEAN = K * 4 * kRow * 2;
     static constexpr int LDS_DOUBLES_LEAN = LDS_XCHG + LDS_FH_LEAN;
-    static_assert(2 * N + 24 <= XSTRIDE, "exchange area too small for the layer-K stash");
 };
 
 template <int K, int GC>
@@ -477,9 +476,13 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         // stash this column's 6 partials of layer j in an fh slot this lane has already consumed:
         // h_j's slot for j < K, f_K's slot for j = K  (rows 0..2 of the slot, as double2)
         if (LEAN && j == K) {
-            // no consumed slot yet at the top layer: its partials go behind the trig table, [m][q]
+            // no consumed fh slot yet at the top layer: add lane pairs (q, q^1) and park the 6 x 2 pair
+            // sums in this layer's own trig-table entries, which are dead from here on
 #pragma unroll
-            for (int m = 0; m < 6; ++m) xq[2 * C::N + 4 * m + q] = part[m];
+            for (int m = 0; m < 6; ++m) {
+                const double ps = part[m] + dpp_f64<0xB1>(part[m]);
+                if ((q & 1) == 0) xq[12 * K + 2 * m + (q >> 1)] = ps;
+            }
         } else {
             const int sl = (j < K) ? HS(j) : (2 * (K - 1));
 #pragma unroll
@@ -503,9 +506,13 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             const int m = i - 6 * j;
             const int sl = (j < K) ? HS(j) : (2 * (K - 1));
             const double* base = fhd + ((sl * 4 + (m >> 1)) * kRow) * 2 + (m & 1);
-            int stride = 2;  // the 4 lanes' stashes are 16 bytes apart in an fh row
-            if (LEAN && j >= K) { base = xq + 2 * C::N + 4 * m; stride = 1; }
-            const double sum = (base[0] + base[stride]) + (base[2 * stride] + base[3 * stride]);
+            double sum;
+            if (LEAN && j >= K) {
+                const double2 ps = *reinterpret_cast<const double2*>(xq + 12 * K + 2 * m);
+                sum = ps.x + ps.y;
+            } else {
+                sum = (base[0] + base[2]) + (base[4] + base[6]);  // the 4 lanes' stashes are 16 bytes apart
+            }
             gd[a] = (i < C::N) ? sum : 0.0;
         }
     }
@@ -554,7 +561,7 @@ __device__ __forceinline__ void h_matvec(const HMat<NA>& H, const double (&vd)[N
         xq32[4 * a + q] = v32[a];
     }
     lds_fence();
-    float* xt = xq32 + 4 * NA;  // [b][e][q] transposed partial sums (disjoint from the v area)
+    float* xt = xq32 + 4 * NA - 16;  // [b >= 1][e][q] transposed partial sums, stored from b = 1 (disjoint from the v area)
     f32x2 acc[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) acc[a] = f32x2{0.0f, 0.0f};

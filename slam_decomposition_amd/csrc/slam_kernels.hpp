@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
 // All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
 template <int K, int GC>
-__global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args) {
+__global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args) {
     using C = Cfg<K>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
