@@ -200,6 +200,22 @@ __device__ __forceinline__ double dtheta_pair(const U3t& t, double ut0r, double 
 
 __device__ __forceinline__ double im_mul(double ar, double ai, double br, double bi) { return ar * bi + ai * br; }
 
+// 1/x and 1/sqrt(x) for normal positive x: hardware seed + two Newton steps (<= 1 ulp typical).  The
+// IEEE-correct division the compiler emits (v_div_scale / v_div_fmas / v_div_fixup) is ~3x the instructions
+// and its special-case handling is not needed: every caller guards x <= 0 / non-finite by a select.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    return y;
+}
+
 // cold path, kept out of line so that its register appetite (ocml's Payne-Hanek reduction) does not
 // shape the register allocation of the optimizer loop
 __device__ __attribute__((noinline)) void sincos_slow(double x, double* s, double* c) { sincos(x, s, c); }
@@ -411,9 +427,11 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     }
     pr = quad_sum(pr);
     pi = quad_sum(pi);
-    const double at = sqrt(pr * pr + pi * pi);
+    const double at2 = pr * pr + pi * pi;
+    const double rat = (at2 > 1e-300) ? fast_rsqrt(at2) : 0.0;  // 1 / |t|
+    const double at = at2 * rat;
     fout = 1.0 - 0.25 * at;
-    const double inv = (at > 1e-300) ? 0.25 / at : 0.0;
+    const double inv = 0.25 * rat;
     const double zr = -pr * inv, zi = pi * inv;
 
     // ---- 4. backward: u = row q of (z T^+)(suffix); accumulate this column's partials

@@ -264,10 +264,10 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         sy = quad_sum(sy);
         yy = quad_sum(yy);
         ss = quad_sum(ss);
-        const bool curv = step && (sy > kCurvEps * sqrt(ss * yy));
+        const bool curv = step && sy > 0.0 && (sy * sy > (kCurvEps * kCurvEps) * (ss * yy));
         const bool first = curv && !scaled;
         scaled = scaled || curv;
-        const double fac = first ? (sy / yy) : 1.0;
+        const double fac = first ? (sy * fast_rcp(yy)) : 1.0;
         {
             // fac = 1 except at a quad's first update; unconditional (42 packed multiplies at k = 3) so
             // that H is not redefined on one side of a branch
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             yu = fma(ym * (gt[a] - g[a]), ua, yu);
         }
         yu = quad_sum(yu);
-        const double rho = curv ? 1.0 / sy : 0.0;
+        const double rho = curv ? fast_rcp(sy) : 0.0;
         const double cf = rho * (1.0 + rho * yu);
         double wg = 0.0, sg = 0.0;
         {
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         gp = qdot<NA>(g, p);
         const double pp = qdot<NA>(p, p);
         if (acc) {
-            alpha = fmin(1.0, kStepMax / fmax(sqrt(pp), 1e-300));
+            alpha = (pp > 1e-300) ? fmin(1.0, kStepMax * fast_rsqrt(pp)) : 1.0;
             if (!dbg_fixed && (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss))) {
                 status = ST_CONVERGED; done = true;
             } else if (!dbg_fixed && nstall >= 2) { status = ST_STALLED; done = true; }
