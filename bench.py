@@ -103,13 +103,13 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100 for cfg2, 4 for the big workloads)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10 for cfg2, 2 otherwise)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--targets", type=int, default=None, help="override targets per step per GPU")
     ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 4 for cfg2, 1 otherwise")
+                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 8 for cfg2-sized batches, 2 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     args = ap.parse_args()
@@ -145,7 +145,9 @@ def main():
         n_per_step = args.targets
     if args.restarts:
         restarts = args.restarts
-    steps, warmup = args.steps, args.warmup
+    small = n_per_step * restarts <= 65536
+    steps = args.steps if args.steps is not None else (100 if small else 4)
+    warmup = args.warmup if args.warmup is not None else (10 if small else 2)
     total_steps = steps + warmup
     seed0 = 20260000 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
     opt_seed = 20261003
