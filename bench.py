@@ -23,6 +23,9 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# one hardware queue per batch in flight (the HIP runtime maps streams onto 4 hardware queues by default;
+# streams that share a queue serialise).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -109,7 +112,7 @@ def main():
     ap.add_argument("--targets", type=int, default=None, help="override targets per step per GPU")
     ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 8 for cfg2-sized batches, 2 otherwise")
+                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 3 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     args = ap.parse_args()
@@ -152,7 +155,7 @@ def main():
     seed0 = 20260000 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
     opt_seed = 20261003
 
-    n_streams = args.streams if args.streams else (8 if n_per_step * restarts <= 65536 else 2)
+    n_streams = args.streams if args.streams else (16 if n_per_step * restarts <= 65536 else 3)
     n_streams = max(1, min(n_streams, steps))
     ctxs = [_ffi.Context(local_rank) for _ in range(n_streams)]
     ctx = ctxs[0]
