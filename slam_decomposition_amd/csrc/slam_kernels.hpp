@@ -238,10 +238,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         if (active) ++nev;
         const bool finite = isfinite(ft);
         const bool armijo = finite && (ft <= f + kArmijoC1 * alpha * gp);
-        // flags bit 8 (profiling only): every trial point is accepted and nothing converges, so each item
-        // runs exactly maxiter rounds of "evaluation + full update" -- the pure cost of a round
-        const bool dbg_fixed = (args.flags & 0x100u) != 0;
-        const bool acc = active && (fresh ? finite : (armijo || dbg_fixed));
+        const bool acc = active && (fresh ? finite : armijo);
         const bool step = acc && !fresh;  // a real quasi-Newton step (not the initial evaluation)
 
         // ---- 3. quasi-Newton update.  s = am p and y = ym (g' - g) are formed on the fly; for quads
@@ -352,9 +349,9 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         const double pp = qdot<NA>(p, p);
         if (acc) {
             alpha = (pp > 1e-300) ? fmin(1.0, kStepMax * fast_rsqrt(pp)) : 1.0;
-            if (!dbg_fixed && (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss))) {
+            if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) {
                 status = ST_CONVERGED; done = true;
-            } else if (!dbg_fixed && nstall >= 2) { status = ST_STALLED; done = true; }
+            } else if (nstall >= 2) { status = ST_STALLED; done = true; }
             else if (iters >= args.maxiter) { status = ST_MAXITER; done = true; }
         } else if (active && !fresh) {
             if (nback > kMaxBacktrack) { status = (gnorm < kStallGnorm) ? ST_STALLED : ST_LINESEARCH; done = true; }
