@@ -26,7 +26,7 @@ from .basis import CircuitTemplate
 from .basis_abc import DataDictEntry, VariationalTemplate
 from .cost_function import BasicCost, UnitaryCostFunction
 from .sampler import SampleFunction
-from .weyl import c1c2c3
+from .weyl import c1c2c3_batch
 
 SUCCESS_THRESHOLD = 1e-10  # optimizer.py:18
 TRAINING_RESTARTS = 5  # optimizer.py:19
@@ -174,23 +174,36 @@ class TemplateOptimizer:
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
         return best_loss, xs, best_cycles
 
-    def _finish_target(self, target_U, target_coordinates, best_result, best_Xk, best_cycles) -> DataDictEntry:
+    def _finish_target(self, target_coordinates, best_result, best_Xk, best_cycles, found_coordinates) -> DataDictEntry:
         """Labelling / logging / exception of approximate_target_U (optimizer.py:80-119)."""
         logging.info(f"Overall Best Loss={best_result}")
         self.training_loss.append(best_result)  # optimizer.py:307-309 (no callback)
         self.best_cycle_list.append(best_cycles)
-        self.basis.build(n_repetitions=best_cycles)
         if best_result <= self.success_threshold:
             success_label = 1
-            alternative_coordinate = c1c2c3(self.basis.eval(best_Xk))
-            logging.info(f"Success: {target_coordinates}, Found: {alternative_coordinate}")
+            logging.info(f"Success: {target_coordinates}, Found: {found_coordinates}")
         else:
             if not self.override_fail:
                 raise ValueError(_FAIL_MSG)
             success_label = 0
-            alternative_coordinate = c1c2c3(self.basis.eval(best_Xk))
-            logging.info(f"Fail: {target_coordinates}, Found: {alternative_coordinate}")
+            logging.info(f"Fail: {target_coordinates}, Found: {found_coordinates}")
         return DataDictEntry(success_label, best_result, best_Xk, best_cycles)
+
+    def _found_coordinates(self, best_xs, best_cycles) -> np.ndarray:
+        """c1c2c3 of the found circuits (optimizer.py:85,103): one batched CircuitTemplate.eval on the GPU
+        per distinct span, one batched eigen-decomposition on the host."""
+        n = len(best_xs)
+        found = np.zeros((n, 3))
+        ctx = runtime.get_context(self.devices[0])
+        ctx.set_gates(self.basis.gate_matrices)
+        if ctx.n_targets == 0:
+            ctx.set_targets(np.eye(4, dtype=np.complex128)[None])
+        for k in np.unique(best_cycles):
+            idx = np.nonzero(best_cycles == k)[0]
+            X = np.stack([best_xs[i] for i in idx])
+            W, _ = ctx.eval_unitary(self.basis.gate_sequence(int(k)), X)
+            found[idx] = c1c2c3_batch(W)
+        return found
 
     # ------------------------------------------------------------------------------------------
     def approximate_target_U(self, target_U) -> DataDictEntry:
@@ -207,14 +220,18 @@ class TemplateOptimizer:
         for t in targets:
             if t.shape != (4, 4):
                 raise ValueError("targets must be 4x4 unitaries")
-        coords = [self.basis.target_invariant(t) for t in targets]
+        stacked = np.stack(targets)
+        coords = [tuple(float(v) for v in c) for c in c1c2c3_batch(stacked)]  # target_invariant, basis_abc.py:80-84
         self.basis.assign_seed(None)  # optimizer.py:150-152
         spanning_range = self.basis.get_spanning_range(targets[0])
-        best_loss, best_xs, best_cycles = self._run_batch(np.stack(targets), spanning_range)
+        best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)
+        found = self._found_coordinates(best_xs, np.asarray(best_cycles))
+        self.basis.build(n_repetitions=int(best_cycles[-1]))  # the reference leaves the template at the last size
         out = []
-        for i, t in enumerate(targets):
+        for i in range(len(targets)):
             if log_index:
                 logging.info(f"Starting sample iter {i}")
             logging.info(f"Begin search: {coords[i]}")
-            out.append(self._finish_target(t, coords[i], float(best_loss[i]), best_xs[i], int(best_cycles[i])))
+            fc = tuple(float(v) for v in found[i])
+            out.append(self._finish_target(coords[i], float(best_loss[i]), best_xs[i], int(best_cycles[i]), fc))
         return out

@@ -33,6 +33,11 @@ def test_weyl_coordinates_match_oracle():
         U = o.haar_unitary(s)
         assert c1c2c3(U) == o.c1c2c3(U)
     assert c1c2c3(G.SwapGate().to_matrix()) == (0.5, 0.5, 0.5)
+    from slam_decomposition_amd.weyl import c1c2c3_batch
+
+    U = np.stack([o.haar_unitary(s) for s in range(64)] + [o.cx_matrix(), o.riswap_matrix(1.0), np.eye(4, dtype=complex)])
+    assert np.array_equal(c1c2c3_batch(U), np.array([c1c2c3(u) for u in U]))
+    assert c1c2c3_batch(np.zeros((0, 4, 4))).shape == (0, 3)
 
 
 def test_samplers():
