@@ -187,6 +187,17 @@ int slam_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min,
 int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t count,
                              double* best_loss, double* best_x, int32_t* best_cycles);
 
+/*
+ * Objective used by every later evaluation / minimisation of this context
+ * (UnitaryCostFunction subclasses, src/slam/cost_function.py):
+ *   SLAM_COST_BASIC   BasicCost   1 - |Tr(T^+ U)| / d                       (cost_function.py:140-145), default
+ *   SLAM_COST_SQUARE  SquareCost  1 - (|Tr(T^+ U)|^2 + d) / (d (d + 1))     (cost_function.py:169-173)
+ * Anything else fails like the reference's objective_func: "Unrecognized Cost Function" (optimizer.py:211).
+ */
+#define SLAM_COST_BASIC 0
+#define SLAM_COST_SQUARE 1
+int slam_set_cost(slam_ctx* ctx, int cost);
+
 /* Block until all work queued on the context's stream has finished. */
 int slam_synchronize(slam_ctx* ctx);
 

@@ -220,6 +220,13 @@ def loss_and_grad(x, gate_seq, target) -> Tuple[float, np.ndarray]:
     return float(val), grad
 
 
+def square_loss_and_grad(x, gate_seq, target) -> Tuple[float, np.ndarray]:
+    """SquareCost (src/slam/cost_function.py:169-173) and its gradient.  With d = 4 and L = BasicCost,
+    |t| = 4 (1 - L), so SquareCost = 1 - (16 (1 - L)^2 + 4) / 20 = 0.8 (2 L - L^2)."""
+    val, grad = loss_and_grad(x, gate_seq, target)
+    return 0.8 * val * (2.0 - val), 1.6 * (1.0 - val) * grad
+
+
 def fd_grad(x, gate_seq, target, h: float = 1e-6) -> np.ndarray:
     """Central-difference gradient of :func:`loss` (oracle for A5)."""
     x = np.asarray(x, dtype=np.float64)

@@ -21,6 +21,7 @@ MAX_SPAN_MINIMIZE = 5
 
 ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED = range(6)
 FLAG_EARLY_EXIT = 1
+COST_BASIC, COST_SQUARE = 0, 1
 
 # every symbol include/slam_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = (
@@ -40,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "slam_fetch_results",
     "slam_decompose_range",
     "slam_fetch_results_range",
+    "slam_set_cost",
     "slam_synchronize",
     "slam_get_stats",
     "slam_reset_stats",
@@ -116,6 +118,7 @@ def load_library() -> C.CDLL:
     lib.slam_fetch_results.argtypes = [P, C.c_int, P, P, P]
     lib.slam_decompose_range.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results_range.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, P, P]
+    lib.slam_set_cost.argtypes = [P, C.c_int]
     lib.slam_synchronize.argtypes = [P]
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.slam_reset_stats.argtypes = [P]
@@ -316,6 +319,10 @@ class Context:
         best_cycles = np.empty(count, dtype=np.int32)
         _check(self._lib.slam_fetch_results_range(self._h, k_max, int(first), int(count), _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
         return best_loss, best_x, best_cycles
+
+    def set_cost(self, kind: int) -> None:
+        """0 = BasicCost (default), 1 = SquareCost."""
+        _check(self._lib.slam_set_cost(self._h, int(kind)))
 
     def synchronize(self) -> None:
         _check(self._lib.slam_synchronize(self._h))

@@ -27,3 +27,14 @@ class BasicCost(UnitaryCostFunction):
         h = np.asarray(target_u).conj().T
         cur = np.asarray(current_u)
         return 1 - np.abs(np.trace(h @ cur)) / cur.shape[0]
+
+
+class SquareCost(UnitaryCostFunction):
+    """1 - (|Tr(T^dagger U)|^2 + d) / (d (d + 1))  (src/slam/cost_function.py:169-173): the objective most
+    of the reference's notebooks use.  On the HIP path it is the same fused kernel with a different
+    scalar map of |Tr| (and of the gradient scale)."""
+
+    def unitary_fidelity(self, current_u, target_u):
+        h = np.asarray(target_u).conj().T
+        d = np.asarray(target_u).shape[0]
+        return 1 - (np.abs(np.trace(h @ np.asarray(current_u))) ** 2 + d) / (d * (d + 1))

@@ -352,6 +352,7 @@ __device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&U
 //   gates gate matrices G_1..G_K in device memory (scalar loads -> SGPR operands)
 //   xq    LDS: this quad's exchange area (trig table, then gradient transpose)
 //   fh    LDS: this lane's slice of the stored column vectors (stride 64 double2 per row)
+//   cost_kind  0 = BasicCost, 1 = SquareCost (wave-uniform)
 // Returns loss (replicated over the quad), gd[a] = dloss/dx[4a + q] and column q of W.
 // ---------------------------------------------------------------------------------
 // HUGE_ARGS: also handle |x| >= 2e9 (out-of-line ocml path).  The optimizer kernel keeps |x| far
@@ -360,7 +361,7 @@ __device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&U
 template <int K, bool HUGE_ARGS, int GC>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double* tcol,
                                           const double* gates, double* xq, double2* fh,
-                                          int q, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
+                                          int q, int cost_kind, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
                                           double (&Wi)[4]) {
     using C = Cfg<K>;
     constexpr bool LEAN = lean_layout<K, GC>();
@@ -430,8 +431,11 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     const double at2 = pr * pr + pi * pi;
     const double rat = (at2 > 1e-300) ? fast_rsqrt(at2) : 0.0;  // 1 / |t|
     const double at = at2 * rat;
-    fout = 1.0 - 0.25 * at;
-    const double inv = 0.25 * rat;
+    const double basic = 1.0 - 0.25 * at;  // BasicCost, cost_function.py:140-145
+    // SquareCost (cost_function.py:169-173): 1 - (|t|^2 + d) / (d (d + 1)), d = 4, is the monotone map
+    // 0.8 (2 L - L^2) of BasicCost L, so its gradient is 1.6 (1 - L) times BasicCost's (wave-uniform select)
+    fout = (cost_kind == 1) ? 0.8 * basic * (2.0 - basic) : basic;
+    const double inv = (cost_kind == 1) ? 0.25 * rat * 1.6 * (1.0 - basic) : 0.25 * rat;
     const double zr = -pr * inv, zi = pi * inv;
 
     // ---- 4. backward: u = row q of (z T^+)(suffix); accumulate this column's partials

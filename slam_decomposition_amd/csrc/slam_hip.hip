@@ -88,6 +88,7 @@ struct slam_ctx {
     DevBuf stage_targets;
     DevBuf span_gates;  // 64 slots x [SLAM_MAX_SPAN_EVAL][32] doubles
     int gate_slot = 0;
+    int cost_kind = 0;  // SLAM_COST_*
     std::vector<double> gates_host;
     int compute_units = 0;
     int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1][4] = {};
@@ -180,6 +181,7 @@ int launch_eval(slam_ctx* c, const int32_t* gate_seq, const double* d_x, const i
     a.loss = d_loss;
     a.grad = d_grad;
     a.unitary = d_unitary;
+    a.cost_kind = c->cost_kind;
     { int rc = stage_gates(c, K, gate_seq, &a.gates); if (rc) return rc; }
     const int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
     hipLaunchKernelGGL((eval_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
@@ -225,6 +227,7 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.far_loss = prm->far_loss;
     a.seed = prm->seed;
     a.flags = prm->flags;
+    a.cost_kind = c->cost_kind;
     a.work_counter = reinterpret_cast<unsigned int*>(c->counters.as<char>() + 16);
     a.solved = c->solved.as<int32_t>();
     a.item_loss = c->item_loss.as<double>();
@@ -702,6 +705,14 @@ int slam_decompose(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs
     int rc = decompose_impl(ctx, 0, ctx->n_targets, k_min, k_max, gate_seqs, params, success_threshold);
     if (rc) return rc;
     return slam_fetch_results(ctx, k_max, best_loss, best_x, best_cycles);
+}
+
+int slam_set_cost(slam_ctx* ctx, int cost) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (cost != SLAM_COST_BASIC && cost != SLAM_COST_SQUARE)
+        return fail(SLAM_ERR_INVALID, "Unrecognized Cost Function (%d)", cost);
+    ctx->cost_kind = cost;
+    return SLAM_OK;
 }
 
 int slam_synchronize(slam_ctx* ctx) {

@@ -29,6 +29,7 @@ struct MinimizeArgs {
     uint64_t seed;
     uint32_t flags;
     uint32_t chunk;              // items a wave takes from the queue at a time (multiple of 16)
+    int32_t cost_kind;           // 0 BasicCost, 1 SquareCost
     unsigned int* work_counter;  // zeroed before launch
     int32_t* solved;             // [n_active], zeroed before launch (SLAM_FLAG_EARLY_EXIT)
     // per-item outputs
@@ -49,6 +50,7 @@ struct EvalArgs {
     double* loss;             // [M]
     double* grad;             // [M][n] or nullptr
     double* unitary;          // [M][4][4][2] or nullptr: W = CircuitTemplate.eval(x)
+    int32_t cost_kind;        // 0 BasicCost, 1 SquareCost
     const double* gates;      // [K][32]: G_1..G_K of this span
 };
 
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad<K, true, GC>(xd, tcol, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, f, gd, Wr, Wi);
+    eval_quad<K, true, GC>(xd, tcol, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, args.cost_kind, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, q, ft, gt, Wr, Wi);
+            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, q, args.cost_kind, ft, gt, Wr, Wi);
         }
         const bool active = live;
         if (active) ++nev;

@@ -24,7 +24,7 @@ import numpy as np
 from . import _ffi, runtime
 from .basis import CircuitTemplate
 from .basis_abc import DataDictEntry, VariationalTemplate
-from .cost_function import BasicCost, UnitaryCostFunction
+from .cost_function import BasicCost, SquareCost, UnitaryCostFunction
 from .sampler import SampleFunction
 from .weyl import c1c2c3_batch
 
@@ -72,7 +72,11 @@ class TemplateOptimizer:
 
         if not isinstance(basis, CircuitTemplate):
             raise NotImplementedError("the HIP optimizer needs a slam_decomposition_amd CircuitTemplate")
-        if not isinstance(self.objective, BasicCost):
+        if isinstance(self.objective, SquareCost):
+            self._cost_kind = _ffi.COST_SQUARE
+        elif isinstance(self.objective, BasicCost):
+            self._cost_kind = _ffi.COST_BASIC
+        else:
             # the reference raises this for objectives its objective_func does not know (optimizer.py:211)
             raise ValueError("Unrecognized Cost Function")
         if use_callback:
@@ -136,6 +140,7 @@ class TemplateOptimizer:
             try:
                 ctx.set_targets(targets)
                 ctx.set_gates(self.basis.gate_matrices)
+                ctx.set_cost(self._cost_kind)
                 ctx.reset_stats()
                 out = ctx.decompose_range(first, count, ks[0], ks[-1], gate_seqs, prm, self.success_threshold)
                 return out, ctx.stats()

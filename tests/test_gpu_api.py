@@ -174,3 +174,24 @@ def test_devices_list_shards_targets_and_matches_single_device():
         assert a.cycles == b.cycles == c.cycles == 2
         assert a.success_label == b.success_label == c.success_label == 1
         assert max(a.loss_result, b.loss_result, c.loss_result) < 1e-10
+
+
+def test_square_cost_objective_like_the_reference_notebooks():
+    """decomp_trajectory.ipynb cell 5: SquareCost, sqrt(iSWAP) k = 3, target SWAP -> Success with a loss of a few
+    1e-9 in the reference (finite differences); the HIP path ends below 1e-12."""
+    from slam_decomposition_amd.cost_function import SquareCost
+    from slam_decomposition_amd.gates import SwapGate
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
+    opt = TemplateOptimizer(basis, SquareCost(), training_restarts=16, seed=8)
+    _, _, (td,) = opt.approximate_from_distribution(GateSample(SwapGate()))
+    assert td.success_label == 1 and td.cycles == 3 and td.loss_result < 1e-12
+    W = o.template_eval(td.Xk, [o.riswap_matrix(0.5)] * 3)
+    assert abs(o.square_cost(W, SwapGate().to_matrix()) - td.loss_result) < 1e-13
+    assert SquareCost().unitary_fidelity(W, SwapGate().to_matrix()) == pytest.approx(td.loss_result, abs=1e-13)
+    assert np.max(np.abs(np.array(c1c2c3(W)) - 0.5)) < 1e-6
+    # the shared context goes back to BasicCost for BasicCost optimizers
+    opt2 = TemplateOptimizer(basis, BasicCost(), training_restarts=16, seed=8)
+    td2 = opt2.approximate_target_U(SwapGate().to_matrix())
+    assert abs(o.basic_cost(o.template_eval(td2.Xk, [o.riswap_matrix(0.5)] * td2.cycles), SwapGate().to_matrix()) - td2.loss_result) < 1e-13

@@ -93,3 +93,36 @@ def test_eval_large_angles_and_empty(hip_ctx):
     ref_loss, ref_grad = _oracle_batch(x, tof, targets, [GATES["sqiswap"]] * 2)
     assert np.max(np.abs(loss - ref_loss)) < 1e-10
     assert np.max(np.abs(grad - ref_grad)) < 1e-10
+
+
+def test_square_cost_kat1_and_gradient(hip_ctx):
+    """SquareCost on the HIP path: KAT-1's recorded value (decomp_trajectory.ipynb:87,
+    3.550885807612758e-09 against SWAP) and the gradient against the oracle."""
+    import json, os
+
+    from slam_decomposition_amd import _ffi
+
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat1.json")))
+    swap = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex)
+    sq = o.riswap_matrix(0.5)
+    try:
+        hip_ctx.set_cost(_ffi.COST_SQUARE)
+        hip_ctx.set_targets(swap[None])
+        hip_ctx.set_gates(sq[None])
+        loss, _ = hip_ctx.eval_loss_grad([0, 0, 0], np.array([kat["params"]]), np.zeros(1, np.int32))
+        assert abs(loss[0] - kat["square_cost_vs_swap"]) < 1e-15  # 15 printed digits of the parameters
+        rng = np.random.default_rng(8)
+        targets = o.haar_batch(3, seed0=66)
+        hip_ctx.set_targets(targets)
+        x = rng.uniform(0, 2 * np.pi, size=(9, 18))
+        tof = (np.arange(9) % 3).astype(np.int32)
+        loss, grad = hip_ctx.eval_loss_grad([0, 0], x, tof)
+        for m in range(9):
+            v, g = o.square_loss_and_grad(x[m], [sq, sq], targets[tof[m]])
+            W = o.template_eval(x[m], [sq, sq])
+            assert abs(o.square_cost(W, targets[tof[m]]) - v) < 1e-15
+            assert abs(loss[m] - v) < 1e-12 and np.max(np.abs(grad[m] - g)) < 1e-12
+        with pytest.raises(_ffi.SlamHipError, match="Unrecognized Cost Function"):
+            hip_ctx.set_cost(7)
+    finally:
+        hip_ctx.set_cost(_ffi.COST_BASIC)

@@ -57,6 +57,16 @@ def test_basic_cost_matches_oracle():
     assert c.normalization == 1
     assert c.unitary_fidelity(U, V) == pytest.approx(o.basic_cost(U, V), abs=1e-16)
     assert c.unitary_fidelity(np.exp(0.3j) * V, V) < 1e-15  # global-phase invariant
+    from slam_decomposition_amd.cost_function import SquareCost
+
+    assert SquareCost().unitary_fidelity(U, V) == pytest.approx(o.square_cost(U, V), abs=1e-16)
+    x = np.linspace(0.1, 2.0, 18)
+    gs = [o.riswap_matrix(0.5)] * 2
+    v, g = o.square_loss_and_grad(x, gs, V)
+    assert abs(v - o.square_cost(o.template_eval(x, gs), V)) < 1e-15
+    h = 1e-6
+    fd = np.array([(o.square_loss_and_grad(x + h * e, gs, V)[0] - o.square_loss_and_grad(x - h * e, gs, V)[0]) / (2 * h) for e in np.eye(18)])
+    assert np.max(np.abs(fd - g)) < 2e-9
 
 
 def test_circuit_template_structure():
