@@ -101,6 +101,16 @@ int slam_ctx_device_info(slam_ctx* ctx, char* name, int name_len, int* compute_u
 int slam_set_targets(slam_ctx* ctx, const double* targets, int64_t n_targets);
 
 /*
+ * Fill the resident batch with n_targets Haar-random 4x4 unitaries generated on the device:
+ * T_i = QR(Ginibre(Philox(seed, first_index + i))).Q with a positive diagonal of R -- the recipe of
+ * HaarSample._get_unitary (src/slam/sampler.py:62-71 -> qiskit random_unitary -> SciPy unitary_group),
+ * with Philox4x32-10 + Box-Muller in place of NumPy's generator: same distribution, different sample.
+ * slam_get_targets copies resident targets [first, first + count) back: double[count][4][4][2].
+ */
+int slam_sample_haar(slam_ctx* ctx, uint64_t seed, int64_t first_index, int64_t n_targets);
+int slam_get_targets(slam_ctx* ctx, int64_t first, int64_t count, double* out);
+
+/*
  * Upload the table of 2Q basis-gate matrices (CircuitTemplate(base_gates=...),
  * src/slam/basis.py:52-69; matrices from src/slam/utils/gates/custom_gates.py).
  * gates: double[n_gates][4][4][2].

@@ -464,3 +464,29 @@ def approximate_target_U(
             )
         label = 0
     return DataDictEntry(label, best_result, best_Xk, best_cycles)
+
+
+def haar_philox_port(seed: int, index: int) -> np.ndarray:
+    """NumPy restatement of the device Haar sampler (slam_decomposition_amd/csrc/slam_sampler.hpp):
+    Ginibre entries from Philox4x32-10 + Box-Muller keyed on (seed, index), then Gram-Schmidt (two
+    passes) = QR with a positive diagonal of R, the recipe of src/slam/sampler.py:62-71 (qiskit
+    random_unitary / SciPy unitary_group) with a different generator."""
+    ctr = np.zeros((16, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(16, dtype=np.uint32)
+    ctr[:, 1] = np.uint32(0x48414152)
+    ctr[:, 2] = np.uint32(index & 0xFFFFFFFF)
+    ctr[:, 3] = np.uint32((index >> 32) & 0xFFFFFFFF)
+    w = philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).astype(np.uint64)
+    m0 = (w[:, 0] >> np.uint64(5)) * np.uint64(1 << 26) + (w[:, 1] >> np.uint64(6))
+    m1 = (w[:, 2] >> np.uint64(5)) * np.uint64(1 << 26) + (w[:, 3] >> np.uint64(6))
+    u0 = (m0.astype(np.float64) + 0.5) / 9007199254740992.0
+    u1 = (m1.astype(np.float64) + 0.5) / 9007199254740992.0
+    r = np.sqrt(-2.0 * np.log(u0))
+    z = (r * np.cos(TWO_PI * u1) + 1j * r * np.sin(TWO_PI * u1)).reshape(4, 4)
+    q = z.copy()
+    for c in range(4):
+        for _ in range(2):
+            for p in range(c):
+                q[:, c] -= np.vdot(q[:, p], q[:, c]) * q[:, p]
+        q[:, c] /= np.linalg.norm(q[:, c])
+    return q

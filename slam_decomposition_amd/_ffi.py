@@ -33,6 +33,8 @@ EXPORTED_SYMBOLS = (
     "slam_ctx_device_info",
     "slam_set_targets",
     "slam_set_gates",
+    "slam_sample_haar",
+    "slam_get_targets",
     "slam_eval_loss_grad",
     "slam_eval_unitary",
     "slam_minimize_stage",
@@ -110,6 +112,8 @@ def load_library() -> C.CDLL:
     lib.slam_ctx_device_info.argtypes = [P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.slam_set_targets.argtypes = [P, P, C.c_int64]
     lib.slam_set_gates.argtypes = [P, P, C.c_int32]
+    lib.slam_sample_haar.argtypes = [P, C.c_uint64, C.c_int64, C.c_int64]
+    lib.slam_get_targets.argtypes = [P, C.c_int64, C.c_int64, P]
     lib.slam_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P]
     lib.slam_eval_unitary.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P]
     lib.slam_minimize_stage.argtypes = [P, C.c_int, P, P, C.c_int64, P, C.POINTER(OptParams)] + [P] * 7
@@ -195,6 +199,18 @@ class Context:
             raise ValueError("targets must have shape [N, 4, 4]")
         _check(self._lib.slam_set_targets(self._h, _ptr(t), t.shape[0]))
         self.n_targets = t.shape[0]
+
+    def sample_haar(self, seed: int, n_targets: int, first_index: int = 0) -> None:
+        """Generate the resident batch on the device: T_i = Haar(seed, first_index + i)."""
+        _check(self._lib.slam_sample_haar(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_index), int(n_targets)))
+        self.n_targets = int(n_targets)
+
+    def get_targets(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """Resident targets [first, first + count) as complex128[count, 4, 4]."""
+        count = self.n_targets - first if count is None else count
+        out = np.empty((count, 4, 4, 2), dtype=np.float64)
+        _check(self._lib.slam_get_targets(self._h, int(first), int(count), _ptr(out)))
+        return out.view(np.complex128).reshape(count, 4, 4)
 
     def set_gates(self, gates: np.ndarray) -> None:
         g = _mat_to_ri(gates)

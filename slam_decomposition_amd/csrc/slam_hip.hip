@@ -2,6 +2,7 @@
 // gfx950 only; no torch, no CUDA compatibility layer.
 #include "../../include/slam_hip.h"
 #include "slam_kernels.hpp"
+#include "slam_sampler.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -705,6 +706,33 @@ int slam_decompose(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs
     int rc = decompose_impl(ctx, 0, ctx->n_targets, k_min, k_max, gate_seqs, params, success_threshold);
     if (rc) return rc;
     return slam_fetch_results(ctx, k_max, best_loss, best_x, best_cycles);
+}
+
+int slam_sample_haar(slam_ctx* ctx, uint64_t seed, int64_t first_index, int64_t n_targets) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (n_targets <= 0 || n_targets > 0x7fffffffLL) return fail(SLAM_ERR_INVALID, "n_targets must be in 1..2^31-1");
+    if (first_index < 0) return fail(SLAM_ERR_INVALID, "first_index < 0");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->targets.reserve((size_t)n_targets * 32 * sizeof(double)));
+    hipLaunchKernelGGL(haar_targets_kernel, dim3((unsigned)((n_targets + 127) / 128)), dim3(128), 0, ctx->stream,
+                       ctx->targets.as<double>(), first_index, n_targets, seed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n_targets = n_targets;
+    ctx->result_nmax = 0;
+    return SLAM_OK;
+}
+
+int slam_get_targets(slam_ctx* ctx, int64_t first, int64_t count, double* out) {
+    if (!ctx || !out) return fail(SLAM_ERR_INVALID, "NULL argument");
+    if (first < 0 || count < 0 || first + count > ctx->n_targets)
+        return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    if (count == 0) return SLAM_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(out, ctx->targets.as<double>() + first * 32, (size_t)count * 32 * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
 }
 
 int slam_set_cost(slam_ctx* ctx, int cost) {

@@ -102,6 +102,8 @@ class TemplateOptimizer:
         self.last_stats = None
 
     # ------------------------------------------------------------------------------------------
+    _device_sampler = None
+
     def _opt_params(self) -> "_ffi.OptParams":
         seed = self.seed
         if seed is None:
@@ -138,7 +140,10 @@ class TemplateOptimizer:
             # every shard uploads the whole batch and works on its window (targets are 512 B each)
             ctx = runtime.get_context(device) if len(self.devices) == 1 else _ffi.Context(device)
             try:
-                ctx.set_targets(targets)
+                if self._device_sampler is not None:
+                    self._device_sampler.fill(ctx)  # generated in place, nothing crosses PCIe
+                else:
+                    ctx.set_targets(targets)
                 ctx.set_gates(self.basis.gate_matrices)
                 ctx.set_cost(self._cost_kind)
                 ctx.reset_stats()
@@ -218,7 +223,11 @@ class TemplateOptimizer:
     def approximate_from_distribution(self, sampler: SampleFunction):
         """optimizer.py:180-186; all targets of the sampler are optimised as one GPU batch."""
         targets = [np.asarray(t, dtype=np.complex128) for t in sampler]
-        target_data = self._approximate_batch(targets, log_index=True) if targets else []
+        self._device_sampler = sampler if hasattr(sampler, "fill") else None  # sampler.DeviceHaarBatch
+        try:
+            target_data = self._approximate_batch(targets, log_index=True) if targets else []
+        finally:
+            self._device_sampler = None
         return self.training_loss, self.coordinate_list, target_data
 
     def _approximate_batch(self, targets: List[np.ndarray], log_index: bool) -> List[DataDictEntry]:

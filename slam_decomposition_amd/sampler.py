@@ -71,3 +71,35 @@ class HaarBatch(SampleFunction):
 
     def as_array(self) -> np.ndarray:
         return np.stack(list(self))
+
+
+class DeviceHaarBatch(SampleFunction):
+    """``n_samples`` distinct Haar targets generated on the GPU (``slam_sample_haar``): same recipe as
+    :class:`HaarSample` (Ginibre -> QR with positive diagonal) but driven by Philox4x32-10 keyed on
+    ``(seed, start + i)``, so no host RNG and no upload.  ``TemplateOptimizer`` recognises this sampler
+    and leaves the targets on the device; iterating it (like any sampler) copies them back once."""
+
+    def __init__(self, seed: int = 0, n_samples: int = 1, start: int = 0, device: int = 0, n_qubits=2):
+        if n_qubits != 2:
+            raise NotImplementedError("device sampler: 2 qubits only")
+        self.seed = int(seed)
+        self.start = int(start)
+        self.device = device
+        self._cache = None
+        super().__init__(n_samples=n_samples, n_qubits=n_qubits)
+
+    def fill(self, ctx) -> None:
+        """Make this batch the resident targets of ``ctx`` (generated in place)."""
+        ctx.sample_haar(self.seed, self.n_samples, self.start)
+
+    def as_array(self) -> np.ndarray:
+        if self._cache is None:
+            from . import runtime
+
+            ctx = runtime.get_context(self.device)
+            self.fill(ctx)
+            self._cache = ctx.get_targets(0, self.n_samples)
+        return self._cache
+
+    def __iter__(self):
+        return iter(self.as_array())

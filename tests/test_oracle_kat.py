@@ -148,3 +148,14 @@ def test_bfgs_port_agrees_with_scipy_bfgs():
                 assert f < 1e-12 and res.fun < 1e-10
             agree += abs(f - res.fun) < 1e-6
     assert agree >= 6
+
+
+def test_philox_haar_port_is_unitary_and_haar_like():
+    """The NumPy restatement of the device sampler: unitary to rounding, Haar second moments."""
+    U = np.stack([o.haar_philox_port(11, i) for i in range(3000)])
+    err = np.abs(np.einsum("nji,njk->nik", U.conj(), U) - np.eye(4)).max()
+    assert err < 5e-15
+    p = np.abs(U) ** 2
+    assert abs(p.mean() - 0.25) < 1e-12  # rows sum to one exactly
+    assert abs((p**2).mean() - 0.1) < 4e-3
+    assert not np.allclose(o.haar_philox_port(11, 0), o.haar_philox_port(12, 0))
