@@ -77,6 +77,8 @@ typedef struct slam_stats {
     int64_t items[SLAM_MAX_SPAN_EVAL + 1]; /* (target, seed) work items per span k */
     double total_ms;          /* HIP-event time of the last slam_decompose / slam_minimize_stage */
     double kernel_ms_span[SLAM_MAX_SPAN_EVAL + 1]; /* kernel_ms split per span k */
+    int64_t wave_rounds[SLAM_MAX_SPAN_EVAL + 1];   /* lock-step evaluation rounds summed over wavefronts, per span:
+                                                      evals / (16 * wave_rounds) = fraction of quads that held an item */
 } slam_stats;
 
 /* Thread-local message of the last failing call on this thread. */

@@ -85,6 +85,7 @@ class Stats(C.Structure):
         ("items", C.c_int64 * (MAX_SPAN_EVAL + 1)),
         ("total_ms", C.c_double),
         ("kernel_ms_span", C.c_double * (MAX_SPAN_EVAL + 1)),
+        ("wave_rounds", C.c_int64 * (MAX_SPAN_EVAL + 1)),
     ]
 
 
@@ -353,6 +354,7 @@ class Context:
             "items": list(s.items),
             "total_ms": s.total_ms,
             "kernel_ms_span": list(s.kernel_ms_span),
+            "wave_rounds": list(s.wave_rounds),
         }
 
     def reset_stats(self) -> None:

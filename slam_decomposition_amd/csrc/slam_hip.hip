@@ -230,6 +230,7 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.flags = prm->flags;
     a.cost_kind = c->cost_kind;
     a.work_counter = reinterpret_cast<unsigned int*>(c->counters.as<char>() + 16);
+    a.round_counter = reinterpret_cast<unsigned long long*>(c->counters.as<char>() + 24);
     a.solved = c->solved.as<int32_t>();
     a.item_loss = c->item_loss.as<double>();
     a.item_x = c->item_x.as<double>();
@@ -289,7 +290,7 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     HIP_TRY(c->stage_restart.reserve(n_active * sizeof(int32_t)));
     HIP_TRY(c->solved.reserve(n_active * sizeof(int32_t)));
 
-    // [0,8): eval counter, [8,12): compaction count, [16,20): work counter
+    // [0,8): eval counter, [8,12): compaction count, [16,20): work counter, [24,32): wave-round counter
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 32, c->stream));
     if (prm->flags & SLAM_FLAG_EARLY_EXIT) HIP_TRY(hipMemsetAsync(c->solved.p, 0, n_active * sizeof(int32_t), c->stream));
     const double* d_stage_targets = c->targets.as<double>();
@@ -337,15 +338,16 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     HIP_TRY(hipGetLastError());
 
     // statistics need the kernel to be finished: callers synchronise right after anyway
-    unsigned long long evals = 0;
-    HIP_TRY(hipMemcpyAsync(&evals, c->counters.p, 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
     c->stats.kernel_ms += ms;
     c->stats.kernel_ms_span[k] += ms;
     c->stats.kernel_launches += 1;
-    c->stats.evals[k] += (int64_t)evals;
+    c->stats.evals[k] += (int64_t)cnt[0];
+    c->stats.wave_rounds[k] += (int64_t)cnt[3];
     c->stats.items[k] += M;
     return SLAM_OK;
 }

@@ -31,6 +31,7 @@ struct MinimizeArgs {
     uint32_t chunk;              // items a wave takes from the queue at a time (multiple of 16)
     int32_t cost_kind;           // 0 BasicCost, 1 SquareCost
     unsigned int* work_counter;  // zeroed before launch
+    unsigned long long* round_counter;  // += evaluation rounds of every wave (quad occupancy = evals / 16 / rounds)
     int32_t* solved;             // [n_active], zeroed before launch (SLAM_FLAG_EARLY_EXIT)
     // per-item outputs
     double* item_loss;        // [M]
@@ -135,6 +136,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     const unsigned kChunk = args.chunk;  // wave-uniform: 16 (small batches: spread over all waves) .. 64
     unsigned cur_next = 0, cur_end = 0;  // wave-uniform
     unsigned pre_base = 0;               // lane 0: base of the prefetched chunk
+    unsigned rounds = 0;                 // wave-uniform
     if (lane == 0) pre_base = atomicAdd(args.work_counter, kChunk);
 
     while (true) {
@@ -220,6 +222,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
         }
         if (!__any(live)) break;
+        ++rounds;
 
         // early-exit flag of this quad's target (consumed at the end of the round)
         int sflag = 0;
@@ -393,6 +396,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             for (int a = 0; a < NA; ++a) p[a] = 0.0;
         }
     }
+    if (lane == 0 && rounds) atomicAdd(args.round_counter, (unsigned long long)rounds);
 }
 
 // ---------------------------------------------------------------------------------

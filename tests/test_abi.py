@@ -34,7 +34,7 @@ def test_version_and_struct_layout():
     assert _ffi.OptParams.gtol_far.offset == 40
     p = _ffi.OptParams(restarts=7, seed=2**63 + 5)
     assert p.restarts == 7 and p.seed == 2**63 + 5 and p.gtol_far == 1e-5 and p.far_loss == 1e-6
-    assert ctypes.sizeof(_ffi.Stats) == 8 + 8 + 6 * 8 + 6 * 8 + 8 + 6 * 8
+    assert ctypes.sizeof(_ffi.Stats) == 8 + 8 + 6 * 8 + 6 * 8 + 8 + 6 * 8 + 6 * 8
 
 
 def test_no_gpu_fails_loudly():

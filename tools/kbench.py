@@ -27,4 +27,5 @@ for rep in range(reps + 1):
 tf = sum(best["evals"][k] * f_eval(k) for k in (1, 2, 3)) / (best["kernel_ms"] * 1e-3) / 1e12
 print(f"{gname} N={N} R={R}: kernel ms per span {[round(best['kernel_ms_span'][k], 2) for k in (1, 2, 3)]} total {best['kernel_ms']:.2f} ms; "
       f"evals {[best['evals'][k] for k in (1, 2, 3)]}; {tf:.2f} TF/s = {100 * tf / 78.6:.1f}% ; "
+      f"quad occupancy {[round(best['evals'][k] / 16 / max(best['wave_rounds'][k], 1), 3) for k in (1, 2, 3)]}; "
       f"G evals/s per span {[round(best['evals'][k] / best['kernel_ms_span'][k] / 1e6, 3) if best['kernel_ms_span'][k] else 0 for k in (1, 2, 3)]}")
