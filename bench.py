@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--streams", type=int, default=None,
                     help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 3 otherwise")
+    ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "0")),
+                    help="launch shaping (slam_opt_params.items_per_quad); 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     args = ap.parse_args()
@@ -166,7 +168,8 @@ def main():
         c.set_gates(table)
         c.set_targets(targets)  # every batch resident in HBM before the timed region
     gate_seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
-    prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=opt_seed, flags=_ffi.FLAG_EARLY_EXIT)
+    prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=opt_seed, flags=_ffi.FLAG_EARLY_EXIT,
+                          items_per_quad=args.items_per_quad)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
 
     def one_step(s: int, c):

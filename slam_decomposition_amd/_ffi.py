@@ -67,14 +67,15 @@ class OptParams(C.Structure):
         ("stop_loss", C.c_double),
         ("seed", C.c_uint64),
         ("flags", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("items_per_quad", C.c_uint32),
         ("gtol_far", C.c_double),
         ("far_loss", C.c_double),
     ]
 
-    def __init__(self, restarts=5, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=0, flags=0, gtol_far=1e-5, far_loss=1e-6):
+    def __init__(self, restarts=5, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=0, flags=0, gtol_far=1e-5, far_loss=1e-6,
+                 items_per_quad=0):
         super().__init__(int(restarts), int(maxiter), float(gtol), float(stop_loss), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                         int(flags), 0, float(gtol_far), float(far_loss))
+                         int(flags), int(items_per_quad), float(gtol_far), float(far_loss))
 
 
 class Stats(C.Structure):

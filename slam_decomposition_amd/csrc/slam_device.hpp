@@ -133,15 +133,18 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// x0[i] ~ U[0, 2pi): parameter i of (seed, target index, restart, span k)
+// two Philox words -> x0 ~ U[0, 2pi) with 53 random bits
+__device__ __forceinline__ double x0_from_words(uint32_t a, uint32_t b) {
+    const uint64_t m = ((uint64_t)(a >> 5) << 26) + (uint64_t)(b >> 6);
+    return (double)m * (1.0 / 9007199254740992.0) * 6.283185307179586476925286766559;
+}
+// x0[i]: parameter i of (seed, target index, restart, span k); words (0,1) of the Philox block of
+// parameter pair i >> 1 for even i, words (2,3) for odd i
 __device__ __forceinline__ double x0_philox(uint64_t seed, uint32_t target, uint32_t restart, uint32_t k,
                                             uint32_t i) {
     uint32_t w[4];
     philox4x32_10(i >> 1, restart, target, k, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-    const uint32_t a = (i & 1) ? w[2] : w[0];
-    const uint32_t b = (i & 1) ? w[3] : w[1];
-    const uint64_t m = ((uint64_t)(a >> 5) << 26) + (uint64_t)(b >> 6);
-    return (double)m * (1.0 / 9007199254740992.0) * 6.283185307179586476925286766559;
+    return (i & 1) ? x0_from_words(w[2], w[3]) : x0_from_words(w[0], w[1]);
 }
 
 // ---------------------------------------------------------------------------------

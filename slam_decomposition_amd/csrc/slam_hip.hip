@@ -240,15 +240,19 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
     // persistent wavefronts: never more blocks than can be resident, every quad pulls items
     int64_t blocks = (sl.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    if (prm->items_per_quad > 1) {
+        blocks = (sl.n_items + (int64_t)kQuadsPerWave * prm->items_per_quad - 1) / ((int64_t)kQuadsPerWave * prm->items_per_quad);
+        if (blocks < 1) blocks = 1;
+    }
     if (blocks > c->resident_waves[K][GC]) blocks = c->resident_waves[K][GC];
     // a wave takes `chunk` consecutive items at a time.  Big chunks keep a target's restarts in one wave
     // (early exit then drops the rest without ever starting them); small batches need every wave busy.
-    const int64_t per_wave = sl.n_items / (c->resident_waves[K][GC] > 0 ? c->resident_waves[K][GC] : 1);
+    const int64_t per_wave = sl.n_items / (blocks > 0 ? blocks : 1);
     a.chunk = per_wave >= 256 ? 64u : (per_wave >= 64 ? 32u : 16u);
     // with at least one target per resident wave, give a wave whole targets: splitting a target's restarts
     // over two waves doubles the restarts that run before the first success is seen
     const int64_t r16 = ((int64_t)prm->restarts + 15) / 16 * 16;
-    if (r16 > a.chunk && r16 <= 64 && sl.n_items / prm->restarts >= c->resident_waves[K][GC]) a.chunk = (uint32_t)r16;
+    if (r16 > a.chunk && r16 <= 64 && sl.n_items / prm->restarts >= blocks) a.chunk = (uint32_t)r16;
     HIP_TRY(hipEventRecord(c->ev_a, c->stream));
     hipLaunchKernelGGL((minimize_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
