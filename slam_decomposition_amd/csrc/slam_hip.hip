@@ -72,7 +72,7 @@ struct DevBuf {
 struct slam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;   // kernel bracket
+    hipEvent_t ev_a[SLAM_MAX_SPAN_EVAL + 1] = {}, ev_b[SLAM_MAX_SPAN_EVAL + 1] = {};  // optimizer-kernel bracket per span
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr; // whole-call bracket
     int64_t n_targets = 0;
     int32_t n_gates = 0;
@@ -84,7 +84,7 @@ struct slam_ctx {
     // decompose results
     DevBuf best_loss, best_x, best_cycles;
     int32_t result_nmax = 0;
-    DevBuf counters;  // [0,8): eval counter (u64), [8,12): compaction count, [16,20): work counter
+    DevBuf counters;  // StageCtl[SLAM_MAX_SPAN_EVAL + 2]: one control block per span stage (slam_kernels.hpp)
     DevBuf solved;
     DevBuf stage_targets;
     DevBuf span_gates;  // 64 slots x [SLAM_MAX_SPAN_EVAL][32] doubles
@@ -103,8 +103,8 @@ struct slam_ctx {
                          &item_status, &item_evals, &stage_loss, &stage_x, &stage_restart, &best_loss,
                          &best_x, &best_cycles, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary};
         for (DevBuf* b : all) b->release();
-        if (ev_a) (void)hipEventDestroy(ev_a);
-        if (ev_b) (void)hipEventDestroy(ev_b);
+        for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
         if (ev_t0) (void)hipEventDestroy(ev_t0);
         if (ev_t1) (void)hipEventDestroy(ev_t1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -196,8 +196,9 @@ struct StageLaunch {
     const int32_t* d_active;        // original target index per slot, or nullptr = first_target + slot
     int32_t first_target;
     const double* d_x0;
-    int64_t n_items;
+    int64_t n_items_max;            // upper bound (grid sizing); the kernel reads the real count from ctl
     const slam_opt_params* prm;
+    StageCtl* ctl;
 };
 
 template <int K, int GC>
@@ -219,7 +220,7 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.orig = sl.d_active;
     a.first_target = sl.first_target;
     a.x0 = sl.d_x0;
-    a.n_items = sl.n_items;
+    a.ctl = sl.ctl;
     a.restarts = prm->restarts;
     a.maxiter = prm->maxiter;
     a.gtol = prm->gtol;
@@ -228,9 +229,8 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.far_loss = prm->far_loss;
     a.seed = prm->seed;
     a.flags = prm->flags;
+    a.items_per_quad = prm->items_per_quad;
     a.cost_kind = c->cost_kind;
-    a.work_counter = reinterpret_cast<unsigned int*>(c->counters.as<char>() + 16);
-    a.round_counter = reinterpret_cast<unsigned long long*>(c->counters.as<char>() + 24);
     a.solved = c->solved.as<int32_t>();
     a.item_loss = c->item_loss.as<double>();
     a.item_x = c->item_x.as<double>();
@@ -238,25 +238,19 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.item_status = c->item_status.as<int32_t>();
     a.item_evals = c->item_evals.as<int32_t>();
     { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
-    // persistent wavefronts: never more blocks than can be resident, every quad pulls items
-    int64_t blocks = (sl.n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    // persistent wavefronts: never more blocks than can be resident, every quad pulls items.  The grid is
+    // sized for the upper bound of the item count; the kernel derives the real launch shape (waves that
+    // take part, chunk size) from the device-side target count and surplus waves exit at once.
+    int64_t blocks = (sl.n_items_max + kQuadsPerWave - 1) / kQuadsPerWave;
     if (prm->items_per_quad > 1) {
-        blocks = (sl.n_items + (int64_t)kQuadsPerWave * prm->items_per_quad - 1) / ((int64_t)kQuadsPerWave * prm->items_per_quad);
+        blocks = (sl.n_items_max + (int64_t)kQuadsPerWave * prm->items_per_quad - 1) / ((int64_t)kQuadsPerWave * prm->items_per_quad);
         if (blocks < 1) blocks = 1;
     }
     if (blocks > c->resident_waves[K][GC]) blocks = c->resident_waves[K][GC];
-    // a wave takes `chunk` consecutive items at a time.  Big chunks keep a target's restarts in one wave
-    // (early exit then drops the rest without ever starting them); small batches need every wave busy.
-    const int64_t per_wave = sl.n_items / (blocks > 0 ? blocks : 1);
-    a.chunk = per_wave >= 256 ? 64u : (per_wave >= 64 ? 32u : 16u);
-    // with at least one target per resident wave, give a wave whole targets: splitting a target's restarts
-    // over two waves doubles the restarts that run before the first success is seen
-    const int64_t r16 = ((int64_t)prm->restarts + 15) / 16 * 16;
-    if (r16 > a.chunk && r16 <= 64 && sl.n_items / prm->restarts >= blocks) a.chunk = (uint32_t)r16;
-    HIP_TRY(hipEventRecord(c->ev_a, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_a[K], c->stream));
     hipLaunchKernelGGL((minimize_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_b, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_b[K], c->stream));
     return SLAM_OK;
 }
 
@@ -276,37 +270,43 @@ int check_params(const slam_opt_params* p) {
     return SLAM_OK;
 }
 
-// Runs one span stage for the device-resident active list (d_active may be nullptr = identity).
-// Leaves per-slot results in ctx->stage_loss / stage_x / stage_restart and per-item arrays.
-int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_active, int64_t n_active,
-              const double* d_x0, const slam_opt_params* prm) {
-    const int n = 6 * (k + 1);
-    const int64_t M = n_active * (int64_t)prm->restarts;
-    if (M <= 0) return SLAM_OK;
+StageCtl* stage_ctl(slam_ctx* c, int k) { return c->counters.as<StageCtl>() + k; }
+
+// Work buffers of a stage with at most n_upper targets at span <= k_max.
+int reserve_stage_buffers(slam_ctx* c, int64_t n_upper, int k_max, const slam_opt_params* prm) {
+    const int n = 6 * (k_max + 1);
+    const int64_t M = n_upper * (int64_t)prm->restarts;
     if (M > 0x7fff0000LL) return fail(SLAM_ERR_INVALID, "too many work items in one stage (%lld)", (long long)M);
     HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
     HIP_TRY(c->item_x.reserve(M * n * sizeof(double)));
     HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
     HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
     HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
-    HIP_TRY(c->stage_loss.reserve(n_active * sizeof(double)));
-    HIP_TRY(c->stage_x.reserve(n_active * n * sizeof(double)));
-    HIP_TRY(c->stage_restart.reserve(n_active * sizeof(int32_t)));
-    HIP_TRY(c->solved.reserve(n_active * sizeof(int32_t)));
+    HIP_TRY(c->stage_loss.reserve(n_upper * sizeof(double)));
+    HIP_TRY(c->stage_x.reserve(n_upper * n * sizeof(double)));
+    HIP_TRY(c->stage_restart.reserve(n_upper * sizeof(int32_t)));
+    HIP_TRY(c->solved.reserve(n_upper * sizeof(int32_t)));
+    HIP_TRY(c->stage_targets.reserve((size_t)n_upper * 32 * sizeof(double)));
+    return SLAM_OK;
+}
 
-    // [0,8): eval counter, [8,12): compaction count, [16,20): work counter, [24,32): wave-round counter
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 32, c->stream));
-    if (prm->flags & SLAM_FLAG_EARLY_EXIT) HIP_TRY(hipMemsetAsync(c->solved.p, 0, n_active * sizeof(int32_t), c->stream));
-    const double* d_stage_targets = c->targets.as<double>();
-    if (d_active) {
-        HIP_TRY(c->stage_targets.reserve((size_t)n_active * 32 * sizeof(double)));
-        const int64_t nt = n_active * 16;
-        hipLaunchKernelGGL(gather_targets_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream,
-                           c->targets.as<double>(), d_active, n_active, c->stage_targets.as<double>());
-        HIP_TRY(hipGetLastError());
-        d_stage_targets = c->stage_targets.as<double>();
-    }
-    StageLaunch sl{gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm};
+// Enqueues one span stage for the device-resident active list (d_active may be nullptr = identity): stage
+// inputs, the optimizer kernel, the per-target reduction and (merge) the span loop's bookkeeping.  No host
+// synchronisation: the stage's target count lives in its control block (stage_ctl(c, k)->n_active, at most
+// n_upper), which must have been zeroed and published on the stream before.  Leaves per-slot results in
+// ctx->stage_loss / stage_x / stage_restart and the per-item arrays.
+int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_active, int64_t n_upper,
+                  const double* d_x0, const slam_opt_params* prm, bool merge) {
+    const int n = 6 * (k + 1);
+    const int64_t M = n_upper * (int64_t)prm->restarts;
+    if (M <= 0) return SLAM_OK;
+    StageCtl* ctl = stage_ctl(c, k);
+    const int64_t nt = n_upper * 16;
+    hipLaunchKernelGGL(stage_prepare_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream,
+                       c->targets.as<double>(), d_active, ctl, c->stage_targets.as<double>(), c->solved.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    const double* d_stage_targets = d_active ? c->stage_targets.as<double>() : c->targets.as<double>();
+    StageLaunch sl{gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm, ctl};
     int rc;
     const int gc = classify_gates(c, k, gate_seq);
 #define SLAM_MIN_CASE(KK)                                                   \
@@ -330,29 +330,39 @@ int run_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_acti
     r.item_loss = c->item_loss.as<double>();
     r.item_x = c->item_x.as<double>();
     r.item_evals = c->item_evals.as<int32_t>();
-    r.n_active = n_active;
+    r.ctl = ctl;
     r.restarts = prm->restarts;
     r.n = n;
-    r.best_loss = c->stage_loss.as<double>();
-    r.best_x = c->stage_x.as<double>();
-    r.best_restart = c->stage_restart.as<int32_t>();
-    r.eval_counter = c->counters.as<unsigned long long>();
+    r.stage_loss = c->stage_loss.as<double>();
+    r.stage_x = c->stage_x.as<double>();
+    r.stage_restart = c->stage_restart.as<int32_t>();
+    if (merge) {
+        r.active = d_active;
+        r.nmax = c->result_nmax;
+        r.k = k;
+        r.best_loss = c->best_loss.as<double>();
+        r.best_x = c->best_x.as<double>();
+        r.best_cycles = c->best_cycles.as<int32_t>();
+    }
     const int rb = 256;
-    hipLaunchKernelGGL(reduce_best_kernel, dim3((unsigned)((n_active + rb - 1) / rb)), dim3(rb), 0, c->stream, r);
+    hipLaunchKernelGGL(reduce_merge_kernel, dim3((unsigned)((n_upper + rb - 1) / rb)), dim3(rb), 0, c->stream, r);
     HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
 
-    // statistics need the kernel to be finished: callers synchronise right after anyway
-    unsigned long long cnt[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
-    c->stats.kernel_ms += ms;
-    c->stats.kernel_ms_span[k] += ms;
-    c->stats.kernel_launches += 1;
-    c->stats.evals[k] += (int64_t)cnt[0];
-    c->stats.wave_rounds[k] += (int64_t)cnt[3];
-    c->stats.items[k] += M;
+// After the stream has drained: fold the stages' control blocks and kernel brackets into the statistics.
+int collect_stats(slam_ctx* c, int k_min, int k_max, const StageCtl* h_ctl, int restarts) {
+    for (int k = k_min; k <= k_max; ++k) {
+        if (h_ctl[k].n_active <= 0) continue;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_a[k], c->ev_b[k]));
+        c->stats.kernel_ms += ms;
+        c->stats.kernel_ms_span[k] += ms;
+        c->stats.kernel_launches += 1;
+        c->stats.evals[k] += (int64_t)h_ctl[k].evals;
+        c->stats.wave_rounds[k] += (int64_t)h_ctl[k].rounds;
+        c->stats.items[k] += (int64_t)h_ctl[k].n_active * restarts;
+    }
     return SLAM_OK;
 }
 
@@ -394,54 +404,43 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     const int64_t N = count;
     HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
     HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));
+    rc = reserve_stage_buffers(c, N, k_max, prm);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), c->stream));
     const bool whole = (first == 0 && count == c->n_targets);
     hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream,
                        c->best_loss.as<double>(), c->best_cycles.as<int32_t>(),
-                       whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N);
+                       whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N, stage_ctl(c, k_min));
     HIP_TRY(hipGetLastError());
 
+    // The whole span loop is enqueued at once: a stage's target count is produced on the device by the
+    // previous stage's compaction (every stage is sized for N on the host; a stage without targets costs a
+    // few empty launches), so the only host synchronisation is the one at the end.
     const int32_t* d_active = whole ? nullptr : c->active.as<int32_t>();  // nullptr = identity
-    int64_t n_active = N;
     DevBuf* cur = &c->active;
     DevBuf* nxt = &c->active2;
     const int32_t* gs = gate_seqs;
-    for (int k = k_min; k <= k_max && n_active > 0; ++k) {
-        rc = run_stage(c, k, gs, d_active, n_active, nullptr, prm);
+    for (int k = k_min; k <= k_max; ++k) {
+        rc = enqueue_stage(c, k, gs, d_active, N, nullptr, prm, true);
         if (rc) return rc;
         gs += k;
-        MergeArgs m{};
-        m.active = d_active;
-        m.stage_loss = c->stage_loss.as<double>();
-        m.stage_x = c->stage_x.as<double>();
-        m.n_active = n_active;
-        m.n = 6 * (k + 1);
-        m.nmax = c->result_nmax;
-        m.k = k;
-        m.best_loss = c->best_loss.as<double>();
-        m.best_x = c->best_x.as<double>();
-        m.best_cycles = c->best_cycles.as<int32_t>();
-        hipLaunchKernelGGL(merge_stage_kernel, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, c->stream, m);
-        HIP_TRY(hipGetLastError());
         if (k < k_max) {
-            int32_t* d_nout = reinterpret_cast<int32_t*>(c->counters.as<char>() + 8);
-            hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, c->stream, d_active, n_active,
-                               c->best_loss.as<double>(), success_threshold, nxt->as<int32_t>(), d_nout);
+            hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, c->stream, d_active, stage_ctl(c, k),
+                               c->best_loss.as<double>(), success_threshold, nxt->as<int32_t>(), stage_ctl(c, k + 1));
             HIP_TRY(hipGetLastError());
-            int32_t n_out = 0;
-            HIP_TRY(hipMemcpyAsync(&n_out, d_nout, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            n_active = n_out;
             d_active = nxt->as<int32_t>();
             DevBuf* t = cur; cur = nxt; nxt = t;
         }
     }
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    StageCtl h_ctl[SLAM_MAX_SPAN_EVAL + 2];
+    HIP_TRY(hipMemcpyAsync(h_ctl, c->counters.p, sizeof(h_ctl), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
     c->stats.total_ms = ms;
-    return SLAM_OK;
+    return collect_stats(c, k_min, k_max, h_ctl, prm->restarts);
 }
 
 }  // namespace
@@ -475,11 +474,13 @@ int slam_ctx_create(int device, slam_ctx** out) {
     if (!c) return fail(SLAM_ERR_NOMEM, "out of host memory");
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_a);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_b);
+    for (int k = 0; k <= SLAM_MAX_SPAN_EVAL && e == hipSuccess; ++k) {
+        e = hipEventCreate(&c->ev_a[k]);
+        if (e == hipSuccess) e = hipEventCreate(&c->ev_b[k]);
+    }
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
-    if (e == hipSuccess) e = c->counters.reserve(64);
+    if (e == hipSuccess) e = c->counters.reserve(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2));
     if (e == hipSuccess) e = c->span_gates.reserve((size_t)64 * SLAM_MAX_SPAN_EVAL * 32 * sizeof(double));
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
@@ -653,10 +654,17 @@ int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int
         HIP_TRY(hipMemcpyAsync(ctx->x0.p, x0, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         d_x0 = ctx->x0.as<double>();
     }
+    rc = reserve_stage_buffers(ctx, n_active, k, params);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_t0, ctx->stream));
-    rc = run_stage(ctx, k, gate_seq, d_active, n_active, d_x0, params);
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), ctx->stream));
+    hipLaunchKernelGGL(set_n_active_kernel, dim3(1), dim3(1), 0, ctx->stream, stage_ctl(ctx, k), (int32_t)n_active);
+    HIP_TRY(hipGetLastError());
+    rc = enqueue_stage(ctx, k, gate_seq, d_active, n_active, d_x0, params, false);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
+    StageCtl h_ctl[SLAM_MAX_SPAN_EVAL + 2];
+    HIP_TRY(hipMemcpyAsync(h_ctl, ctx->counters.p, sizeof(h_ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(best_loss, ctx->stage_loss.p, (size_t)n_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(best_x, ctx->stage_x.p, (size_t)n_active * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (best_restart) HIP_TRY(hipMemcpyAsync(best_restart, ctx->stage_restart.p, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -668,7 +676,7 @@ int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
     ctx->stats.total_ms = ms;
-    return SLAM_OK;
+    return collect_stats(ctx, k, k, h_ctl, params->restarts);
 }
 
 int slam_decompose_resident(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs,

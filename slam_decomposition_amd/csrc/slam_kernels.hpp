@@ -13,13 +13,25 @@ constexpr double kStallGnorm = 1e-5;
 
 enum : int { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_NONFINITE = 3, ST_STALLED = 4, ST_PREEMPTED = 5 };
 
+// Device-side control block of one span stage.  The span loop (optimizer.py:233-303) is enqueued as one
+// chain of kernels without host round trips: the number of targets a stage works on is produced on the
+// device by the previous stage's compaction, and every kernel of the stage reads it from here.
+struct StageCtl {
+    unsigned long long evals;    // += fused loss+gradient evaluations (reduce kernel)
+    unsigned long long rounds;   // += lock-step evaluation rounds of every wavefront
+    unsigned int work_counter;   // work queue of the optimizer kernel
+    int32_t n_active;            // targets of this stage (written by init / the previous stage's compaction)
+    int32_t pad[10];
+};
+static_assert(sizeof(StageCtl) == 64, "StageCtl layout");
+
 template <int K>
 struct MinimizeArgs {
     const double* targets;    // [n_active][32]: target of stage slot s (gathered, or the resident array itself)
     const int32_t* orig;      // [n_active] original target index of slot s, or nullptr = first_target + s
     int32_t first_target;
     const double* x0;         // [M][n] or nullptr
-    int64_t n_items;          // M = n_active * restarts
+    StageCtl* ctl;            // n_active (-> M = n_active * restarts work items), work queue, round counter
     int32_t restarts;
     int32_t maxiter;
     double gtol;
@@ -28,10 +40,8 @@ struct MinimizeArgs {
     double far_loss;
     uint64_t seed;
     uint32_t flags;
-    uint32_t chunk;              // items a wave takes from the queue at a time (multiple of 16)
+    uint32_t items_per_quad;     // launch shaping (slam_opt_params.items_per_quad)
     int32_t cost_kind;           // 0 BasicCost, 1 SquareCost
-    unsigned int* work_counter;  // zeroed before launch
-    unsigned long long* round_counter;  // += evaluation rounds of every wave (quad occupancy = evals / 16 / rounds)
     int32_t* solved;             // [n_active], zeroed before launch (SLAM_FLAG_EARLY_EXIT)
     // per-item outputs
     double* item_loss;        // [M]
@@ -118,7 +128,26 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     double* xq = xchg + quad * C::XSTRIDE;
     float* xq32 = reinterpret_cast<float*>(xq);
     double2* fh = fhbase + lane;
-    const unsigned n_items = (unsigned)args.n_items;
+    // ---- launch shape from the device-side target count (the grid is sized for the host's upper bound)
+    const unsigned n_items = (unsigned)args.ctl->n_active * (unsigned)args.restarts;
+    unsigned n_waves = (n_items + kQuadsPerWave - 1) / kQuadsPerWave;
+    if (args.items_per_quad > 1) {
+        n_waves = (n_items + kQuadsPerWave * args.items_per_quad - 1) / (kQuadsPerWave * args.items_per_quad);
+        if (n_waves < 1 && n_items) n_waves = 1;
+    }
+    if (n_waves > gridDim.x) n_waves = gridDim.x;
+    if (blockIdx.x >= n_waves) return;
+    // A wave takes `chunk` consecutive items at a time.  Big chunks keep a target's restarts in one wave
+    // (early exit then drops the rest without ever starting them); small batches need every wave busy.
+    // With at least one target per wave, give a wave whole targets: splitting a target's restarts over two
+    // waves doubles the restarts that run before the first success is seen.
+    unsigned kChunkV;
+    {
+        const unsigned per_wave = n_items / n_waves;
+        kChunkV = per_wave >= 256u ? 64u : (per_wave >= 64u ? 32u : 16u);
+        const unsigned r16 = ((unsigned)args.restarts + 15u) / 16u * 16u;
+        if (r16 > kChunkV && r16 <= 64u && (unsigned)args.ctl->n_active >= n_waves) kChunkV = r16;
+    }
 
     // ---- per-quad state (replicated over the quad's 4 lanes unless distributed)
     bool live = false, fresh = false, scaled = false;
@@ -133,11 +162,11 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     HMat<NA> H;
     h_set_identity_where<NA>(H, q, true);
     bool exhausted = false;  // wave-uniform
-    const unsigned kChunk = args.chunk;  // wave-uniform: 16 (small batches: spread over all waves) .. 64
+    const unsigned kChunk = kChunkV;  // wave-uniform: 16 (small batches: spread over all waves) .. 64
     unsigned cur_next = 0, cur_end = 0;  // wave-uniform
     unsigned pre_base = 0;               // lane 0: base of the prefetched chunk
     unsigned rounds = 0;                 // wave-uniform
-    if (lane == 0) pre_base = atomicAdd(args.work_counter, kChunk);
+    if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
 
     while (true) {
         // ---- 1. idle quads pull work until every quad has an item or the queue is empty
@@ -158,7 +187,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                     cur_next = b;
                     cur_end = (b + kChunk < n_items) ? b + kChunk : n_items;
                     if (b >= n_items) { exhausted = true; break; }
-                    if (lane == 0) pre_base = atomicAdd(args.work_counter, kChunk);
+                    if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
                 }
                 const bool want = !live;
                 const unsigned long long mask = __ballot(want && q == 0);
@@ -396,91 +425,86 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             for (int a = 0; a < NA; ++a) p[a] = 0.0;
         }
     }
-    if (lane == 0 && rounds) atomicAdd(args.round_counter, (unsigned long long)rounds);
+    if (lane == 0 && rounds) atomicAdd(&args.ctl->rounds, (unsigned long long)rounds);
 }
 
 // ---------------------------------------------------------------------------------
-// per-target reduction over restarts: argmin of item_loss (ties -> lowest restart)
+// per-target reduction over restarts: argmin of item_loss (ties -> lowest restart), then the span loop's
+// bookkeeping (TemplateOptimizer._run, optimizer.py:281-303): "if best_result is None or result.fun <
+// best_result" the stage result replaces the target's best (loss, parameters, cycles).
 // ---------------------------------------------------------------------------------
 struct ReduceArgs {
     const double* item_loss;   // [n_active * R]
     const double* item_x;      // [n_active * R][n]
     const int32_t* item_evals; // [n_active * R]
-    int64_t n_active;
+    StageCtl* ctl;             // n_active; evals += sum of item_evals
     int32_t restarts;
     int32_t n;                 // parameters at this span
-    double* best_loss;         // [n_active]
-    double* best_x;            // [n_active][n]
-    int32_t* best_restart;     // [n_active]
-    unsigned long long* eval_counter;  // += sum of evals
+    double* stage_loss;        // [n_active]
+    double* stage_x;           // [n_active][n]
+    int32_t* stage_restart;    // [n_active]
+    // merge into the resident results (best_loss == nullptr: single-stage call, no merge)
+    const int32_t* active;     // [n_active] target index of each stage slot (nullptr = identity)
+    int32_t nmax;
+    int32_t k;
+    double* best_loss;         // [n_targets]
+    double* best_x;            // [n_targets][nmax]
+    int32_t* best_cycles;      // [n_targets]
 };
 
-__global__ void reduce_best_kernel(ReduceArgs a) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void reduce_merge_kernel(ReduceArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long ev = 0;
-    if (t < a.n_active) {
+    if (s < a.ctl->n_active) {
         double best = INFINITY;
         int br = 0;
         for (int r = 0; r < a.restarts; ++r) {
-            const double l = a.item_loss[t * a.restarts + r];
-            ev += (unsigned long long)a.item_evals[t * a.restarts + r];
+            const double l = a.item_loss[s * a.restarts + r];
+            ev += (unsigned long long)a.item_evals[s * a.restarts + r];
             if (l < best) { best = l; br = r; }   // NaN / +inf (pre-empted) never win
         }
-        a.best_loss[t] = best;
-        a.best_restart[t] = br;
-        const double* src = a.item_x + (t * a.restarts + br) * a.n;
-        for (int i = 0; i < a.n; ++i) a.best_x[t * a.n + i] = src[i];
+        a.stage_loss[s] = best;
+        a.stage_restart[s] = br;
+        const double* src = a.item_x + (s * a.restarts + br) * a.n;
+        for (int i = 0; i < a.n; ++i) a.stage_x[s * a.n + i] = src[i];
+        if (a.best_loss) {
+            const int64_t t = a.active ? a.active[s] : s;
+            if (a.best_cycles[t] < 0 || best < a.best_loss[t]) {
+                a.best_loss[t] = best;
+                a.best_cycles[t] = a.k;
+                for (int i = 0; i < a.n; ++i) a.best_x[t * a.nmax + i] = src[i];
+            }
+        }
     }
     // wave-level sum, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
-    if ((threadIdx.x & 63) == 0 && ev) atomicAdd(a.eval_counter, ev);
+    if ((threadIdx.x & 63) == 0 && ev) atomicAdd(&a.ctl->evals, ev);
 }
 
-// ---------------------------------------------------------------------------------
-// span-loop bookkeeping on the device (TemplateOptimizer._run, optimizer.py:281-303)
-// ---------------------------------------------------------------------------------
-struct MergeArgs {
-    const int32_t* active;      // [n_active] target index of each stage slot (nullptr = identity)
-    const double* stage_loss;   // [n_active]
-    const double* stage_x;      // [n_active][n]
-    int64_t n_active;
-    int32_t n;
-    int32_t nmax;
-    int32_t k;
-    double* best_loss;          // [n_targets]
-    double* best_x;             // [n_targets][nmax]
-    int32_t* best_cycles;       // [n_targets]
-};
-
-__global__ void merge_stage_kernel(MergeArgs a) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n_active) return;
-    const int64_t t = a.active ? a.active[s] : s;
-    const double l = a.stage_loss[s];
-    // "if best_result is None or result.fun < best_result" (optimizer.py:281)
-    if (a.best_cycles[t] < 0 || l < a.best_loss[t]) {
-        a.best_loss[t] = l;
-        a.best_cycles[t] = a.k;
-        for (int i = 0; i < a.n; ++i) a.best_x[t * a.nmax + i] = a.stage_x[s * a.n + i];
-    }
-}
-
-// stage inputs: gather the active targets into a dense array so that the optimizer kernel addresses a
-// slot's target directly (no active[] -> targets[] dependent load on the refill path)
-__global__ void gather_targets_kernel(const double* targets, const int32_t* active, int64_t n_active, double* out) {
+// stage inputs: clear the early-exit flags and gather the active targets into a dense array so that the
+// optimizer kernel addresses a slot's target directly (no active[] -> targets[] dependent load on the
+// refill path).  active == nullptr: the stage works on the resident array itself, nothing to gather.
+__global__ void stage_prepare_kernel(const double* targets, const int32_t* active, const StageCtl* ctl, double* out,
+                                     int32_t* solved) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per double2
-    if (i < n_active * 16) {
+    const int64_t n_active = ctl->n_active;
+    if (i < n_active) solved[i] = 0;
+    if (active && i < n_active * 16) {
         const int64_t s = i >> 4;
         const int e = (int)(i & 15);
         reinterpret_cast<double2*>(out)[i] = reinterpret_cast<const double2*>(targets)[(int64_t)active[s] * 16 + e];
     }
 }
 
-// reset the results of targets [first, first + n) and (optionally) write their indices as the
-// initial active list
+// single-stage calls: the host knows the target count
+__global__ void set_n_active_kernel(StageCtl* ctl, int32_t n) { ctl->n_active = n; }
+
+// reset the results of targets [first, first + n), (optionally) write their indices as the initial
+// active list, and publish n as the first stage's target count
 __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int32_t* active, int64_t first,
-                                    int64_t n) {
+                                    int64_t n, StageCtl* first_stage) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) first_stage->n_active = (int32_t)n;
     if (t < n) {
         best_loss[first + t] = INFINITY;
         best_cycles[first + t] = -1;
@@ -491,12 +515,13 @@ __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int
 // Ordered compaction of the targets that still need a longer template:
 // keep t iff !(best_loss[t] < threshold)   (optimizer.py:301: break when best < threshold).
 // Single workgroup, chunked scan: n is at most a few million.
-__global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* active_in, int64_t n_in,
+__global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* active_in, const StageCtl* ctl,
                                                              const double* best_loss, double threshold,
-                                                             int32_t* active_out, int32_t* n_out) {
+                                                             int32_t* active_out, StageCtl* next) {
     __shared__ int32_t counts[1024];
     __shared__ int32_t offs[1025];
     const int tid = threadIdx.x;
+    const int64_t n_in = ctl->n_active;
     const int64_t chunk = (n_in + 1023) / 1024;
     const int64_t lo = tid * chunk;
     const int64_t hi = (lo + chunk < n_in) ? lo + chunk : n_in;
@@ -511,7 +536,7 @@ __global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* act
         int32_t acc = 0;
         for (int i = 0; i < 1024; ++i) { offs[i] = acc; acc += counts[i]; }
         offs[1024] = acc;
-        *n_out = acc;
+        next->n_active = acc;
     }
     __syncthreads();
     int32_t o = offs[tid];
