@@ -30,6 +30,9 @@ STEP_MAX = 2.0  # cap on |alpha p|_2 of the first trial step (parameters are ang
 CURV_EPS = 1e-10
 STALL_DF = 1e-15
 STALL_GNORM = 1e-5
+WOLFE_C2 = 0.9     # an accepted step whose slope along p fell by less than (1 - c2) was too short ...
+GROW_FACTOR = 4.0  # ... the next first trial step is this much longer (compounding while it keeps happening)
+GROW_MAX = 1048576.0
 
 
 def minimize_port(
@@ -55,6 +58,7 @@ def minimize_port(
     if maxiter <= 0:
         return f, x, 0, 1, nev
     alpha = min(1.0, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
+    grow = 1.0
     it = 0
     nback = 0
     nstall = 0
@@ -76,6 +80,9 @@ def minimize_port(
         if ft <= f + ARMIJO_C1 * alpha * gp:
             y = gt - g
             sy = s @ y
+            # weak-Wolfe curvature condition violated (in particular: negative curvature along p, where the
+            # update below is skipped and H never learns to take longer steps): lengthen the next trial step
+            short = sy < (1.0 - WOLFE_C2) * alpha * (-gp)
             q = (H @ gt.astype(h_dtype)).astype(np.float64)
             if sy > CURV_EPS * np.sqrt((s @ s) * (y @ y)):
                 rho = 1.0 / sy
@@ -108,12 +115,14 @@ def minimize_port(
                 status = 4
                 break
             p = pn
-            alpha = min(1.0, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
+            grow = min(grow * GROW_FACTOR, GROW_MAX) if short else 1.0
+            alpha = min(grow, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
         else:
             # safeguarded quadratic interpolation backtrack
             denom = 2.0 * (ft - f - gp * alpha)
             a_new = -gp * alpha * alpha / denom if denom > 0 and np.isfinite(denom) else 0.5 * alpha
             alpha = min(max(a_new, 0.1 * alpha), 0.5 * alpha)
+            grow = 1.0
             nback += 1
             if nback > MAX_BACKTRACK:
                 status = 4 if gnorm < STALL_GNORM else 2

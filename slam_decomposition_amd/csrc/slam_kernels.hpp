@@ -10,6 +10,9 @@ constexpr double kStepMax = 2.0;  // cap on |alpha p|_2 of the first trial step 
 constexpr double kCurvEps = 1e-10;
 constexpr double kStallDf = 1e-15;
 constexpr double kStallGnorm = 1e-5;
+constexpr double kWolfeC2 = 0.9;      // an accepted step whose slope along p fell by less than (1 - c2) was too short:
+constexpr double kGrowFactor = 4.0;   // the next first trial step is this much longer (compounding while it keeps
+constexpr double kGrowMax = 1048576.0;  // happening).  Covers negative curvature, where the update is skipped.
 
 enum : int { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_NONFINITE = 3, ST_STALLED = 4, ST_PREEMPTED = 5 };
 
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     unsigned item = 0;
     int slot = 0, tgt = 0;
     int nev = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
-    double f = 0.0, alpha = 0.0, gp = 0.0, gnorm = 0.0;
+    double f = 0.0, alpha = 0.0, gp = 0.0, gnorm = 0.0, grow = 1.0;
     const double* tcol = args.targets + q * 2;  // this lane's column of the quad's target
     double x[NA], g[NA], p[NA];
 #pragma unroll
@@ -241,7 +244,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                             p[a] = 0.0;
                             g[a] = 0.0;
                         }
-                        alpha = 0.0; gp = 0.0; f = 0.0;
+                        alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0;
                         nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
                         scaled = false; fresh = true; live = true; taken = true;
                     }
@@ -296,6 +299,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         yy = quad_sum(yy);
         ss = quad_sum(ss);
         const bool curv = step && sy > 0.0 && (sy * sy > (kCurvEps * kCurvEps) * (ss * yy));
+        const bool too_short = sy < (1.0 - kWolfeC2) * alpha * (-gp);  // weak-Wolfe curvature condition violated
         const bool first = curv && !scaled;
         scaled = scaled || curv;
         const double fac = first ? (sy * fast_rcp(yy)) : 1.0;
@@ -351,6 +355,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             f = ft;
             if (step) ++iters;
             nback = 0;
+            grow = (step && too_short) ? fmin(grow * kGrowFactor, kGrowMax) : 1.0;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const double sa = am * p[a];
@@ -369,6 +374,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                 const double denom = 2.0 * (ft - f - gp * alpha);
                 const double anew = (finite && denom > 0.0 && isfinite(denom)) ? (-gp * alpha * alpha / denom) : 0.5 * alpha;
                 alpha = fmin(fmax(anew, 0.1 * alpha), 0.5 * alpha);
+                grow = 1.0;
                 ++nback;
             }
         }
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         gp = qdot<NA>(g, p);
         const double pp = qdot<NA>(p, p);
         if (acc) {
-            alpha = (pp > 1e-300) ? fmin(1.0, kStepMax * fast_rsqrt(pp)) : 1.0;
+            alpha = (pp > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(pp)) : grow;
             if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) {
                 status = ST_CONVERGED; done = true;
             } else if (nstall >= 2) { status = ST_STALLED; done = true; }
