@@ -14,7 +14,7 @@ table = gate_table(gname)
 ctx.set_gates(table)
 ctx.set_targets(make_targets(N, 20260000))
 seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
-prm = _ffi.OptParams(restarts=R, seed=20261003, flags=_ffi.FLAG_EARLY_EXIT)
+prm = _ffi.OptParams(restarts=R, seed=20261003, flags=_ffi.FLAG_EARLY_EXIT, items_per_quad=int(os.environ.get("KB_IPQ", "0")))
 best = None
 for rep in range(reps + 1):
     ctx.reset_stats()
@@ -28,4 +28,5 @@ tf = sum(best["evals"][k] * f_eval(k) for k in (1, 2, 3)) / (best["kernel_ms"] *
 print(f"{gname} N={N} R={R}: kernel ms per span {[round(best['kernel_ms_span'][k], 2) for k in (1, 2, 3)]} total {best['kernel_ms']:.2f} ms; "
       f"evals {[best['evals'][k] for k in (1, 2, 3)]}; {tf:.2f} TF/s = {100 * tf / 78.6:.1f}% ; "
       f"quad occupancy {[round(best['evals'][k] / 16 / max(best['wave_rounds'][k], 1), 3) for k in (1, 2, 3)]}; "
+      f"wave rounds {[best['wave_rounds'][k] for k in (1, 2, 3)]}; "
       f"G evals/s per span {[round(best['evals'][k] / best['kernel_ms_span'][k] / 1e6, 3) if best['kernel_ms_span'][k] else 0 for k in (1, 2, 3)]}")
