@@ -310,16 +310,27 @@ int reserve_stage_buffers(slam_ctx* c, int64_t n_upper, int k_max, const slam_op
 // synchronisation: the stage's target count lives in its control block (stage_ctl(c, k)->n_active, at most
 // n_upper), which must have been zeroed and published on the stream before.  Leaves per-slot results in
 // ctx->stage_loss / stage_x / stage_restart and the per-item arrays.
+// What follows the optimizer kernel of a stage inside the span loop (nullptr: single-stage call, reduce only).
+struct SpanLoopStep {
+    bool inputs_ready;       // the previous kernel of the chain already prepared this stage's inputs
+    bool has_next;           // a longer span follows: compact the unsolved targets into active_out
+    double threshold;
+    int32_t* active_out;
+};
+
 int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_active, int64_t n_upper,
-                  const double* d_x0, const slam_opt_params* prm, bool merge) {
+                  const double* d_x0, const slam_opt_params* prm, const SpanLoopStep* loop) {
     const int n = 6 * (k + 1);
     const int64_t M = n_upper * (int64_t)prm->restarts;
     if (M <= 0) return SLAM_OK;
     StageCtl* ctl = stage_ctl(c, k);
-    const int64_t nt = n_upper * 16;
-    hipLaunchKernelGGL(stage_prepare_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream,
-                       c->targets.as<double>(), d_active, ctl, c->stage_targets.as<double>(), c->solved.as<int32_t>());
-    HIP_TRY(hipGetLastError());
+    const bool merge = loop != nullptr;
+    if (!(loop && loop->inputs_ready)) {
+        const int64_t nt = n_upper * 16;
+        hipLaunchKernelGGL(stage_prepare_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream,
+                           c->targets.as<double>(), d_active, ctl, c->stage_targets.as<double>(), c->solved.as<int32_t>());
+        HIP_TRY(hipGetLastError());
+    }
     const double* d_stage_targets = d_active ? c->stage_targets.as<double>() : c->targets.as<double>();
     StageLaunch sl{gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm, ctl};
     int rc;
@@ -359,9 +370,30 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
         r.best_x = c->best_x.as<double>();
         r.best_cycles = c->best_cycles.as<int32_t>();
     }
+    if (loop && n_upper <= kEpilogueMaxTargets) {
+        // small batch: reduction, bookkeeping, compaction and the next stage's inputs in one launch
+        EpilogueArgs e{};
+        e.r = r;
+        e.has_next = loop->has_next ? 1 : 0;
+        e.threshold = loop->threshold;
+        e.active_out = loop->active_out;
+        e.next = stage_ctl(c, k + 1);
+        e.targets = c->targets.as<double>();
+        e.stage_targets = c->stage_targets.as<double>();
+        e.solved = c->solved.as<int32_t>();
+        if (n_upper <= 2048) hipLaunchKernelGGL(stage_epilogue_kernel<256>, dim3(1), dim3(256), 0, c->stream, e);
+        else hipLaunchKernelGGL(stage_epilogue_kernel<1024>, dim3(1), dim3(1024), 0, c->stream, e);
+        HIP_TRY(hipGetLastError());
+        return SLAM_OK;
+    }
     const int rb = 256;
     hipLaunchKernelGGL(reduce_merge_kernel, dim3((unsigned)((n_upper + rb - 1) / rb)), dim3(rb), 0, c->stream, r);
     HIP_TRY(hipGetLastError());
+    if (loop && loop->has_next) {
+        hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, c->stream, d_active, ctl,
+                           c->best_loss.as<double>(), loop->threshold, loop->active_out, stage_ctl(c, k + 1));
+        HIP_TRY(hipGetLastError());
+    }
     return SLAM_OK;
 }
 
@@ -422,11 +454,12 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     rc = reserve_stage_buffers(c, N, k_max, prm);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), c->stream));
     const bool whole = (first == 0 && count == c->n_targets);
-    hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)(((whole ? N : N * 16) + 255) / 256)), dim3(256), 0, c->stream,
                        c->best_loss.as<double>(), c->best_cycles.as<int32_t>(),
-                       whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N, stage_ctl(c, k_min));
+                       whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N, stage_ctl(c, k_min),
+                       c->targets.as<double>(), c->stage_targets.as<double>(), c->solved.as<int32_t>(),
+                       c->counters.as<StageCtl>(), (int32_t)(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2) / 8));
     HIP_TRY(hipGetLastError());
 
     // The whole span loop is enqueued at once: a stage's target count is produced on the device by the
@@ -436,14 +469,15 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     DevBuf* cur = &c->active;
     DevBuf* nxt = &c->active2;
     const int32_t* gs = gate_seqs;
+    const bool small = N <= kEpilogueMaxTargets;
     for (int k = k_min; k <= k_max; ++k) {
-        rc = enqueue_stage(c, k, gs, d_active, N, nullptr, prm, true);
+        // the first stage's inputs come from init_results_kernel, a small batch's later ones from the
+        // previous stage's epilogue
+        SpanLoopStep step{k == k_min || small, k < k_max, success_threshold, nxt->as<int32_t>()};
+        rc = enqueue_stage(c, k, gs, d_active, N, nullptr, prm, &step);
         if (rc) return rc;
         gs += k;
         if (k < k_max) {
-            hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, c->stream, d_active, stage_ctl(c, k),
-                               c->best_loss.as<double>(), success_threshold, nxt->as<int32_t>(), stage_ctl(c, k + 1));
-            HIP_TRY(hipGetLastError());
             d_active = nxt->as<int32_t>();
             DevBuf* t = cur; cur = nxt; nxt = t;
         }
@@ -501,6 +535,7 @@ int slam_ctx_create(int device, slam_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_t1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventBlockingSync | hipEventDisableTiming);
+
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipHostMallocDefault);
     if (e == hipSuccess) e = c->counters.reserve(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2));
     if (e == hipSuccess) e = c->span_gates.reserve((size_t)64 * SLAM_MAX_SPAN_EVAL * 32 * sizeof(double));
@@ -683,7 +718,7 @@ int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), ctx->stream));
     hipLaunchKernelGGL(set_n_active_kernel, dim3(1), dim3(1), 0, ctx->stream, stage_ctl(ctx, k), (int32_t)n_active);
     HIP_TRY(hipGetLastError());
-    rc = enqueue_stage(ctx, k, gate_seq, d_active, n_active, d_x0, params, false);
+    rc = enqueue_stage(ctx, k, gate_seq, d_active, n_active, d_x0, params, nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_ctl, ctx->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, ctx->stream));

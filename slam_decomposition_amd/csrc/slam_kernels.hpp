@@ -458,10 +458,8 @@ struct ReduceArgs {
     int32_t* best_cycles;      // [n_targets]
 };
 
-__global__ void reduce_merge_kernel(ReduceArgs a) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long ev = 0;
-    if (s < a.ctl->n_active) {
+__device__ __forceinline__ void reduce_merge_slot(const ReduceArgs& a, int64_t s, unsigned long long& ev) {
+    {
         double best = INFINITY;
         int br = 0;
         for (int r = 0; r < a.restarts; ++r) {
@@ -482,6 +480,12 @@ __global__ void reduce_merge_kernel(ReduceArgs a) {
             }
         }
     }
+}
+
+__global__ void reduce_merge_kernel(ReduceArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ev = 0;
+    if (s < a.ctl->n_active) reduce_merge_slot(a, s, ev);
     // wave-level sum, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
     if ((threadIdx.x & 63) == 0 && ev) atomicAdd(&a.ctl->evals, ev);
@@ -507,28 +511,35 @@ __global__ void set_n_active_kernel(StageCtl* ctl, int32_t n) { ctl->n_active = 
 
 // reset the results of targets [first, first + n), (optionally) write their indices as the initial
 // active list, and publish n as the first stage's target count
+// ... and prepare the first stage's inputs (early-exit flags; the window's targets as a dense array when
+// the batch is a window of the resident targets).  One thread per double2 of the window's targets.
 __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int32_t* active, int64_t first,
-                                    int64_t n, StageCtl* first_stage) {
+                                    int64_t n, StageCtl* first_stage, const double* targets, double* stage_targets,
+                                    int32_t* solved, StageCtl* ctl_all, int32_t n_ctl_words) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) first_stage->n_active = (int32_t)n;
+    if (t == 0) {
+        // one thread clears all stages' control blocks, then publishes the first stage's target count
+        for (int w = 0; w < n_ctl_words; ++w) reinterpret_cast<unsigned long long*>(ctl_all)[w] = 0ull;
+        first_stage->n_active = (int32_t)n;
+    }
     if (t < n) {
         best_loss[first + t] = INFINITY;
         best_cycles[first + t] = -1;
+        solved[t] = 0;
         if (active) active[t] = (int32_t)(first + t);
     }
+    if (active && t < n * 16)
+        reinterpret_cast<double2*>(stage_targets)[t] = reinterpret_cast<const double2*>(targets)[first * 16 + t];
 }
 
 // Ordered compaction of the targets that still need a longer template:
 // keep t iff !(best_loss[t] < threshold)   (optimizer.py:301: break when best < threshold).
 // Single workgroup, chunked scan: n is at most a few million.
-__global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* active_in, const StageCtl* ctl,
-                                                             const double* best_loss, double threshold,
-                                                             int32_t* active_out, StageCtl* next) {
-    __shared__ int32_t counts[1024];
-    __shared__ int32_t offs[1025];
+template <int NT>
+__device__ __forceinline__ int32_t compact_block(const int32_t* active_in, int64_t n_in, const double* best_loss,
+                                                 double threshold, int32_t* active_out, int32_t* counts, int32_t* offs) {
     const int tid = threadIdx.x;
-    const int64_t n_in = ctl->n_active;
-    const int64_t chunk = (n_in + 1023) / 1024;
+    const int64_t chunk = (n_in + NT - 1) / NT;
     const int64_t lo = tid * chunk;
     const int64_t hi = (lo + chunk < n_in) ? lo + chunk : n_in;
     int32_t c = 0;
@@ -540,9 +551,8 @@ __global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* act
     __syncthreads();
     if (tid == 0) {
         int32_t acc = 0;
-        for (int i = 0; i < 1024; ++i) { offs[i] = acc; acc += counts[i]; }
-        offs[1024] = acc;
-        next->n_active = acc;
+        for (int i = 0; i < NT; ++i) { offs[i] = acc; acc += counts[i]; }
+        offs[NT] = acc;
     }
     __syncthreads();
     int32_t o = offs[tid];
@@ -550,6 +560,56 @@ __global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* act
         const int32_t t = active_in ? active_in[s] : (int32_t)s;
         if (!(best_loss[t] < threshold)) active_out[o++] = t;
     }
+    return offs[NT];
+}
+
+__global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* active_in, const StageCtl* ctl,
+                                                             const double* best_loss, double threshold,
+                                                             int32_t* active_out, StageCtl* next) {
+    __shared__ int32_t counts[1024];
+    __shared__ int32_t offs[1025];
+    const int32_t total = compact_block<1024>(active_in, ctl->n_active, best_loss, threshold, active_out, counts, offs);
+    if (threadIdx.x == 0) next->n_active = total;
+}
+
+// Small batches (at most kEpilogueMaxTargets targets): everything between two optimizer launches in ONE
+// single-workgroup kernel -- reduction over restarts, span-loop bookkeeping, compaction of the unsolved
+// targets and the next stage's inputs (gathered targets, cleared early-exit flags).  With several batches in
+// flight every extra kernel of the chain waits for wavefront slots held by other batches' persistent
+// optimizer waves (hundreds of microseconds each under load), so the chain is kept as short as possible.
+constexpr int64_t kEpilogueMaxTargets = 8192;
+
+struct EpilogueArgs {
+    ReduceArgs r;
+    int32_t has_next;
+    double threshold;
+    int32_t* active_out;     // [n_upper] next stage's active list
+    StageCtl* next;
+    const double* targets;   // resident targets
+    double* stage_targets;   // next stage's gathered targets
+    int32_t* solved;
+};
+
+// NT = 256 for the smallest batches: a 4-wave workgroup finds room on a busy GPU much sooner than a 16-wave one.
+template <int NT>
+__global__ void __launch_bounds__(NT) stage_epilogue_kernel(EpilogueArgs a) {
+    __shared__ int32_t counts[NT];
+    __shared__ int32_t offs[NT + 1];
+    const int tid = threadIdx.x;
+    const int64_t n_in = a.r.ctl->n_active;
+    unsigned long long ev = 0;
+    for (int64_t s = tid; s < n_in; s += NT) reduce_merge_slot(a.r, s, ev);
+    for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
+    if ((tid & 63) == 0 && ev) atomicAdd(&a.r.ctl->evals, ev);
+    if (!a.has_next) return;
+    __syncthreads();  // this workgroup wrote every best_loss the compaction reads
+    const int32_t total = compact_block<NT>(a.r.active, n_in, a.r.best_loss, a.threshold, a.active_out, counts, offs);
+    __syncthreads();  // active_out complete
+    if (tid == 0) a.next->n_active = total;
+    for (int64_t i = tid; i < (int64_t)total * 16; i += NT)
+        reinterpret_cast<double2*>(a.stage_targets)[i] =
+            reinterpret_cast<const double2*>(a.targets)[(int64_t)a.active_out[i >> 4] * 16 + (i & 15)];
+    for (int64_t i = tid; i < total; i += NT) a.solved[i] = 0;
 }
 
 }  // namespace slamdev
