@@ -765,6 +765,15 @@ int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t co
     // device -> pinned staging (asynchronous), sleep on the blocking event, then plain host copies
     const size_t b_loss = N * sizeof(double), b_x = N * nmax * sizeof(double), b_cyc = N * sizeof(int32_t);
     const size_t need = b_loss + b_x + b_cyc;
+    if (need > (size_t)1 << 20) {
+        // big windows: straight into the caller's arrays (an extra host copy of tens of MB would cost more
+        // than the runtime's own staging)
+        if (best_loss) HIP_TRY(hipMemcpyAsync(best_loss, ctx->best_loss.as<double>() + o, b_loss, hipMemcpyDeviceToHost, ctx->stream));
+        if (best_x) HIP_TRY(hipMemcpyAsync(best_x, ctx->best_x.as<double>() + o * nmax, b_x, hipMemcpyDeviceToHost, ctx->stream));
+        if (best_cycles) HIP_TRY(hipMemcpyAsync(best_cycles, ctx->best_cycles.as<int32_t>() + o, b_cyc, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return SLAM_OK;
+    }
     if (need > ctx->h_stage_cap) {
         if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
         ctx->h_stage = nullptr;
