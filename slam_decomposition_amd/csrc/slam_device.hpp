@@ -369,6 +369,14 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     using C = Cfg<K>;
     constexpr bool LEAN = lean_layout<K, GC>();
     auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
+    // the target column is requested first and consumed after the forward pass
+    double tre[4], tim[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
+        tre[r] = t.x;
+        tim[r] = t.y;
+    }
     // ---- 1. trig table: each lane handles its own parameter slots
     {
         double2* t2 = reinterpret_cast<double2*>(xq);
@@ -416,13 +424,6 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     for (int r = 0; r < 4; ++r) { Wr[r] = Fr[r]; Wi[r] = Fi[r]; }
 
     // ---- 3. t = Tr(T^+ W), loss, z = -conj(t) / (4|t|)
-    double tre[4], tim[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
-        tre[r] = t.x;
-        tim[r] = t.y;
-    }
     double pr = 0.0, pi = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     double* xchg = lds;
     double2* fhbase = reinterpret_cast<double2*>(lds + C::LDS_XCHG);
     const int lane = threadIdx.x;
-    const int q = lane & 3;
+    int q = lane & 3;
     const int quad = lane >> 2;
     double* xq = xchg + quad * C::XSTRIDE;
     float* xq32 = reinterpret_cast<float*>(xq);
@@ -172,6 +172,10 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
 
     while (true) {
+        // q is re-materialised every iteration: otherwise the lane-dependent LDS addresses derived from it
+        // (gradient gather, stash slots) are hoisted out of the loop, kept live across it, spilled to scratch
+        // and reloaded -- one exposed memory latency each -- in every round
+        if constexpr (K == 2) asm volatile("" : "+v"(q));  // (measured: pays at k = 2 only)
         // ---- 1. idle quads pull work until every quad has an item or the queue is empty
         //         (single exit, single back edge: the loop-carried state is large).
         // Items are handed out from a wave-private chunk [cur_next, cur_end) of kChunk consecutive
@@ -257,8 +261,10 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         ++rounds;
 
         // early-exit flag of this quad's target (consumed at the end of the round)
+        // (loaded for every quad -- slot 0 for idle ones -- and only looked at after the evaluation, so that
+        // the round does not start with a wait for global memory)
         int sflag = 0;
-        if ((args.flags & 1u) && live)
+        if (args.flags & 1u)
             sflag = __hip_atomic_load(&args.solved[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         // ---- 2. one fused loss + gradient evaluation at the trial point x + alpha p (x itself when
@@ -408,6 +414,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         }
         // ---- 5. early exit across the restarts of one target (optimizer.py:287-295)
         if (args.flags & 1u) {
+            asm volatile("" : "+v"(sflag));  // not to be tested (= waited for) any earlier than here
             if (active && !done && sflag) { status = ST_PREEMPTED; done = true; }
             if (active && done && status == ST_CONVERGED && f < args.stop_loss && q == 0)
                 __hip_atomic_store(&args.solved[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -16,7 +16,7 @@ ctx.set_targets(make_targets(N, 20260000))
 for k in (1, 2, 3):
     seq = [i % len(table) for i in range(k)]
     for ipq, label in ((8, "2 waves/SIMD"), (16, "1 wave/SIMD"), (32, "1 wave on half the SIMDs"))[: int(os.environ.get("WS_CASES", "3"))]:
-        prm = _ffi.OptParams(restarts=1, maxiter=iters, gtol=0.0, gtol_far=0.0, stop_loss=-1.0, seed=7, flags=0, items_per_quad=ipq)
+        prm = _ffi.OptParams(restarts=1, maxiter=iters, gtol=0.0, gtol_far=0.0, stop_loss=-1.0, seed=7, flags=int(os.environ.get("WS_FLAGS", "0")), items_per_quad=ipq)
         best = None
         for rep in range(4):
             ctx.reset_stats()
