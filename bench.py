@@ -69,11 +69,11 @@ def make_targets(n: int, seed0: int) -> np.ndarray:
 def _cpu_one(args):
     """One target through the reference path on the CPU oracle (SciPy BFGS, finite differences:
     src/slam/optimizer.py:270-278), restarts sequential with early break like the reference."""
-    seed0, idx, gname, restarts, seed = args
+    seed0, idx, gname, restarts, seed, host_targets = args
     from oracle import slam_oracle as o
 
     gates = {"cx": [o.cx_matrix()], "sqiswap": [o.riswap_matrix(0.5)], "iswap+b": [o.riswap_matrix(1.0), o.berkeley_matrix()]}[gname]
-    target = o.haar_unitary(seed0 + idx)
+    target = o.haar_unitary(seed0 + idx) if host_targets else o.haar_philox_port(seed0, idx)
     t0 = time.perf_counter()
     best, _, k, stats = o.run_reference(
         target, gates, range(1, 4), restarts, SUCCESS_LOSS, x0_fn=lambda kk, r: o.x0_philox(seed, idx, r, kk)
@@ -81,11 +81,11 @@ def _cpu_one(args):
     return best, k, time.perf_counter() - t0, stats["nfev"]
 
 
-def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int):
+def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool):
     import multiprocessing as mp
 
     cores = min(os.cpu_count() or 1, 16)
-    jobs = [(seed0, i, gname, restarts, seed) for i in range(n_sample)]
+    jobs = [(seed0, i, gname, restarts, seed, host_targets) for i in range(n_sample)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
         res = pool.map(_cpu_one, jobs, chunksize=1)
@@ -106,8 +106,8 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100 for cfg2, 4 for the big workloads)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10 for cfg2, 2 otherwise)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 320 for cfg2, 9 for the big workloads)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 32 for cfg2, 3 otherwise)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--targets", type=int, default=None, help="override targets per step per GPU")
     ap.add_argument("--restarts", type=int, default=None)
@@ -115,6 +115,7 @@ def main():
                     help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 3 otherwise")
     ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "0")),
                     help="launch shaping (slam_opt_params.items_per_quad); 0 = library default")
+    ap.add_argument("--host-targets", action="store_true", help="draw the Haar targets with SciPy on the host instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     args = ap.parse_args()
@@ -151,8 +152,8 @@ def main():
     if args.restarts:
         restarts = args.restarts
     small = n_per_step * restarts <= 65536
-    steps = args.steps if args.steps is not None else (100 if small else 4)
-    warmup = args.warmup if args.warmup is not None else (10 if small else 2)
+    steps = args.steps if args.steps is not None else (320 if small else 9)
+    warmup = args.warmup if args.warmup is not None else (32 if small else 3)
     total_steps = steps + warmup
     seed0 = 20260000 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
     opt_seed = 20261003
@@ -163,10 +164,15 @@ def main():
     ctx = ctxs[0]
     dev_name, cus, clock_khz = ctx.device_info()
     table = gate_table(gname)
-    targets = make_targets(total_steps * n_per_step, seed0)
+    # every batch resident in HBM before the timed region: Haar targets generated in place by the device
+    # sampler (slam_sample_haar; --host-targets: SciPy's sampler on the host, ~55 us per target, then uploaded)
+    targets = make_targets(total_steps * n_per_step, seed0) if args.host_targets else None
     for c in ctxs:
         c.set_gates(table)
-        c.set_targets(targets)  # every batch resident in HBM before the timed region
+        if args.host_targets:
+            c.set_targets(targets)
+        else:
+            c.sample_haar(seed0, total_steps * n_per_step)
     gate_seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
     prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=opt_seed, flags=_ffi.FLAG_EARLY_EXIT,
                           items_per_quad=args.items_per_quad)
@@ -311,7 +317,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gname, restarts, 20260000, opt_seed, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(gname, restarts, 20260000, opt_seed, args.cpu_sample, args.host_targets)
         print(json.dumps(out), flush=True)
 
     for c in ctxs:
