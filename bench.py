@@ -103,6 +103,17 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
     }
 
 
+def traffic_per_launch(workload: str):
+    """HBM bytes per optimizer-kernel launch (mean over the three spans) from the committed PMC passes
+    (profiles/r1c_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE); None for workloads that were not profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1c_traffic.json")
+    try:
+        t = json.load(open(path))[workload]
+    except (OSError, KeyError, ValueError):
+        return None
+    return sum(t.values()) / len(t)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,7 +316,7 @@ def main():
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_VALU_TFLOPS,
-                "traffic": None,
+                "traffic": traffic_per_launch(args.workload),
                 "kernel": "minimize_kernel<K> (k=1..3)",
                 "time_basis": "hip_events" if streams_used == 1 else "wall_clock_of_timed_region",
                 "kernel_ms_total": st["kernel_ms"],
