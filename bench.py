@@ -43,7 +43,20 @@ WORKLOADS = {
     "cfg2": ("cx", 1024, 16, "BASELINE configs[1]: CNOT basis span<=3, 1024 Haar targets x 16 restarts, fp64"),
     "cfg3": ("sqiswap", 65536, 32, "BASELINE configs[2]: sqrt(iSWAP) basis span<=3, 65536 Haar targets x 32 restarts, fp64"),
     "cfg4": ("iswap+b", 32768, 16, "BASELINE configs[3] per-GPU shard: iSWAP + B mixed basis, 32768 Haar targets x 16 restarts"),
+    # one step = one basis gate of this GPU's 16 (of 128) against the 4096 shared targets
+    "cfg5": ("cgsweep", 4096, 16, "BASELINE configs[4] per-GPU shard: 16 of 128 ConversionGain(0,0,gc,gg,1) bases x 4096 shared Haar targets x 16 restarts"),
 }
+SWEEP_BASES_PER_GPU = 16
+
+
+def sweep_gate(b: int) -> np.ndarray:
+    """Basis b of the 128-gate parametric-Hamiltonian sweep (SURVEY.md §8(d) cfg 5, shaped like build_gates(),
+    utils/gates/bare_candidates.py:47-69): gc = p m pi, gg = (1 - p) m pi, 16 values of m in (0, 0.5] x 8 of p in [0, 1]."""
+    from slam_decomposition_amd import gates as G
+
+    m = 0.5 * (b // 8 + 1) / 16
+    pfrac = (b % 8) / 7
+    return G.ConversionGainGate(0.0, 0.0, pfrac * m * np.pi, (1 - pfrac) * m * np.pi, 1.0).to_matrix()
 
 
 def gate_table(name: str) -> np.ndarray:
@@ -55,6 +68,8 @@ def gate_table(name: str) -> np.ndarray:
         return np.stack([G.RiSwapGate(0.5).to_matrix()])
     if name == "iswap+b":
         return np.stack([G.RiSwapGate(1.0).to_matrix(), G.BerkeleyGate().to_matrix()])
+    if name == "cgsweep":
+        return np.stack([sweep_gate(0)])
     raise ValueError(name)
 
 
@@ -69,14 +84,15 @@ def make_targets(n: int, seed0: int) -> np.ndarray:
 def _cpu_one(args):
     """One target through the reference path on the CPU oracle (SciPy BFGS, finite differences:
     src/slam/optimizer.py:270-278), restarts sequential with early break like the reference."""
-    seed0, idx, gname, restarts, seed, host_targets = args
+    seed0, idx, gname, restarts, seed, host_targets, analytic = args
     from oracle import slam_oracle as o
 
     gates = {"cx": [o.cx_matrix()], "sqiswap": [o.riswap_matrix(0.5)], "iswap+b": [o.riswap_matrix(1.0), o.berkeley_matrix()]}[gname]
     target = o.haar_unitary(seed0 + idx) if host_targets else o.haar_philox_port(seed0, idx)
     t0 = time.perf_counter()
     best, _, k, stats = o.run_reference(
-        target, gates, range(1, 4), restarts, SUCCESS_LOSS, x0_fn=lambda kk, r: o.x0_philox(seed, idx, r, kk)
+        target, gates, range(1, 4), restarts, SUCCESS_LOSS, x0_fn=lambda kk, r: o.x0_philox(seed, idx, r, kk),
+        analytic_jac=analytic,
     )
     return best, k, time.perf_counter() - t0, stats["nfev"]
 
@@ -85,13 +101,18 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
     import multiprocessing as mp
 
     cores = min(os.cpu_count() or 1, 16)
-    jobs = [(seed0, i, gname, restarts, seed, host_targets) for i in range(n_sample)]
-    t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
-        res = pool.map(_cpu_one, jobs, chunksize=1)
-    wall = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_one, [(seed0, i, gname, restarts, seed, host_targets, False) for i in range(n_sample)], chunksize=1)
+        wall = time.perf_counter() - t0
+        # second, stronger CPU line: the same loop with the oracle's analytic gradient
+        t1 = time.perf_counter()
+        res_j = pool.map(_cpu_one, [(seed0, i, gname, restarts, seed, host_targets, True) for i in range(n_sample)], chunksize=1)
+        wall_j = time.perf_counter() - t1
     ok = sum(1 for r in res if r[0] < SUCCESS_LOSS)
     cpu_s = sum(r[2] for r in res)
+    ok_j = sum(1 for r in res_j if r[0] < SUCCESS_LOSS)
+    cpu_sj = sum(r[2] for r in res_j)
     return {
         "value": ok / wall,
         "unit": "decompositions/s",
@@ -100,6 +121,8 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
         "sample": f"{n_sample} targets of the same workload (SciPy BFGS + finite differences on the NumPy oracle, "
         f"sequential restarts with early break), {cpu_s:.1f} core-seconds, {wall:.1f} s wall",
         "per_core": ok / cpu_s if cpu_s > 0 else None,
+        "analytic_jac": {"value": ok_j / wall_j, "per_core": ok_j / cpu_sj if cpu_sj > 0 else None,
+                         "note": "same sample and loop, SciPy BFGS with the oracle's analytic gradient"},
     }
 
 
@@ -178,19 +201,31 @@ def main():
     # every batch resident in HBM before the timed region: Haar targets generated in place by the device
     # sampler (slam_sample_haar; --host-targets: SciPy's sampler on the host, ~55 us per target, then uploaded)
     targets = make_targets(total_steps * n_per_step, seed0) if args.host_targets else None
+    sweep = gname == "cgsweep"
+    n_resident = n_per_step if sweep else total_steps * n_per_step  # the sweep's targets are shared by all bases
+    if sweep and args.host_targets:
+        targets = targets[:n_per_step]
     for c in ctxs:
         c.set_gates(table)
         if args.host_targets:
             c.set_targets(targets)
         else:
-            c.sample_haar(seed0, total_steps * n_per_step)
+            c.sample_haar(seed0 if not sweep else 20260000, n_resident)
     gate_seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
     prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=opt_seed, flags=_ffi.FLAG_EARLY_EXIT,
                           items_per_quad=args.items_per_quad)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
 
+    def basis_of(s: int) -> int:
+        # rank r takes column p = r of the (m, p) grid: all 16 strengths m, so every GPU has weak and strong gates
+        return (s % SWEEP_BASES_PER_GPU) * 8 + rank % 8
+
     def one_step(s: int, c):
-        best_loss, best_x, best_cycles = c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm, threshold)
+        if sweep:
+            c.set_gates(np.stack([sweep_gate(basis_of(s))]))
+            best_loss, best_x, best_cycles = c.decompose_range(0, n_per_step, 1, 3, gate_seqs, prm, threshold)
+        else:
+            best_loss, best_x, best_cycles = c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm, threshold)
         return best_loss, best_cycles
 
     def sync():
@@ -255,6 +290,17 @@ def main():
         solved += int(ok.sum())
         worst = max(worst, float(bl.max()))
         cyc_hist += np.bincount(np.clip(bc, 0, 3), minlength=4)
+    per_basis = None
+    if sweep:
+        # SURVEY.md §8(d) cfg 5 output: per-basis success fraction and mean best_cycles (rank 0's bases)
+        per_basis = {}
+        for s in range(warmup, total_steps):
+            b = basis_of(s)
+            if b in per_basis:
+                continue
+            bl, bc = res[s]
+            ok = bl < SUCCESS_LOSS
+            per_basis[b] = {"solved_fraction": float(ok.mean()), "mean_cycles": float(bc[ok].mean()) if ok.any() else None}
     sts = [c.stats() for c in ctxs]
     st = {
         "kernel_ms": sum(x["kernel_ms"] for x in sts),
@@ -302,7 +348,8 @@ def main():
                 "restarts": restarts,
                 "span_max": 3,
                 "success_threshold": threshold,
-                "parallelism": f"targets sharded over {world} GPU(s), no data-path collective",
+                "parallelism": (f"bases sharded over {world} GPU(s) ({SWEEP_BASES_PER_GPU} each), targets replicated, no data-path collective"
+                                if sweep else f"targets sharded over {world} GPU(s), no data-path collective"),
                 "batches_in_flight_per_gpu": streams_used,
                 "device": dev_name,
                 "compute_units": cus,
@@ -310,6 +357,7 @@ def main():
             "solved_fraction": solved_all / (world * steps * n_per_step),
             "best_cycles_hist_rank0": {str(k): int(cyc_hist[k]) for k in range(4)},
             "worst_loss_rank0": worst,
+            **({"per_basis_rank0": {str(b): v for b, v in sorted(per_basis.items())}} if per_basis is not None else {}),
             "roofline": {
                 "bound": "valu_fp64",
                 "achieved": achieved,

@@ -195,3 +195,35 @@ def test_square_cost_objective_like_the_reference_notebooks():
     opt2 = TemplateOptimizer(basis, BasicCost(), training_restarts=16, seed=8)
     td2 = opt2.approximate_target_U(SwapGate().to_matrix())
     assert abs(o.basic_cost(o.template_eval(td2.Xk, [o.riswap_matrix(0.5)] * td2.cycles), SwapGate().to_matrix()) - td2.loss_result) < 1e-13
+
+
+def test_config4_basis_sweep_matches_oracle_per_basis():
+    """BASELINE configs[4] at test size: a few bases of the ConversionGain(0, 0, gc, gg, 1) sweep
+    (SURVEY.md §8(d) cfg 5, utils/gates/bare_candidates.py:47-69) against shared Haar targets through
+    the Python API; per-basis success and best_cycles must equal the oracle's span loop
+    (TemplateOptimizer._run, optimizer.py:188-313, SciPy BFGS) on the same targets."""
+    import bench
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.gates import ConversionGainGate
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    n_t, R = 10, 12
+    targets = o.haar_batch(n_t, seed0=4242)
+    for b in (16, 61, 64, 123):  # weak (never succeeds), sqrt-iSWAP-like with gain, sqrt-iSWAP-like, near-iSWAP with gain
+        m = 0.5 * (b // 8 + 1) / 16
+        p = (b % 8) / 7
+        gate = ConversionGainGate(0.0, 0.0, p * m * np.pi, (1 - p) * m * np.pi, 1.0)
+        G = np.asarray(gate.to_matrix())
+        assert np.allclose(G, bench.sweep_gate(b)) and np.allclose(G, o.conversion_gain_matrix(0, 0, p * m * np.pi, (1 - p) * m * np.pi, 1.0))
+        opt = TemplateOptimizer(CircuitTemplate(base_gates=[gate], maximum_span_guess=3), BasicCost(), override_fail=True,
+                                training_restarts=R, seed=5)
+        _, _, data = opt.approximate_from_distribution(HaarBatch(seed0=4242, n_samples=n_t))
+        for t in range(n_t):
+            ref_loss, _, ref_k, _ = o.run_reference(targets[t], [G], range(1, 4), R, 1e-8, analytic_jac=True,
+                                                    x0_fn=lambda kk, r, t=t: o.x0_philox(5, t, r, kk))
+            ref_ok = ref_loss < 1e-8
+            assert (data[t].success_label == 1) == ref_ok, (b, t, data[t].loss_result, ref_loss)
+            if ref_ok:
+                assert data[t].cycles == ref_k, (b, t)
+            else:
+                assert abs(data[t].loss_result - ref_loss) < 1e-6, (b, t, data[t].loss_result, ref_loss)
