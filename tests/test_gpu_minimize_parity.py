@@ -167,3 +167,31 @@ def test_decompose_span_loop_matches_oracle_cycles(hip_ctx):
         )  # 1e-8: SciPy's default gtol = 1e-5 stops at loss ~ 1e-10 (BASELINE.json metric: loss < 1e-8)
         assert ref_k == k
         assert abs(ref_loss - best_loss[t]) < 1e-6
+
+
+@pytest.mark.parametrize(
+    "name,gate,k",
+    [
+        ("cx", CX, 1), ("cx", CX, 2), ("sqiswap", SQ, 1), ("sqiswap", SQ, 3), ("b", o.berkeley_matrix(), 2),
+        ("cg-phases", o.conversion_gain_matrix(0.3, -0.7, 0.9, 0.4, 1.0), 2),  # X-shaped, complex blocks (GC_XGEN)
+        ("dense", o.haar_unitary(31337), 2),  # no structure (GC_DENSE)
+    ],
+)
+def test_full_runs_follow_cpu_port(hip_ctx, name, gate, k):
+    """Whole optimizer runs (default tolerances, incl. the step-growth rule) against the NumPy port of the
+    same iteration, item by item: same converged loss, and -- rounding of the float32 inverse Hessian
+    aside -- the same number of evaluations."""
+    n_t, R = 6, 4
+    targets = o.haar_batch(n_t, seed0=777)
+    hip_ctx.set_targets(targets)
+    hip_ctx.set_gates(gate[None])
+    out = hip_ctx.minimize_stage([0] * k, _params(R, seed=11))
+    same_evals = 0
+    for t in range(n_t):
+        for r in range(R):
+            f, x, it, st, nev = minimize_port(o.x0_philox(11, t, r, k), [gate] * k, targets[t])
+            assert out["item_status"][t, r] in (0, 4) and st in (0, 4)
+            assert abs(out["item_loss"][t, r] - f) < 1e-6, (name, k, t, r, out["item_loss"][t, r], f)
+            same_evals += int(out["item_evals"][t, r] == nev)
+            assert abs(int(out["item_evals"][t, r]) - nev) <= max(8, nev // 4), (name, k, t, r, out["item_evals"][t, r], nev)
+    assert same_evals >= (n_t * R) // 2, (name, k, same_evals)
