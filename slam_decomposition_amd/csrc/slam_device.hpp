@@ -62,7 +62,17 @@ struct Cfg {
 template <int K, int GC>
 __host__ __device__ constexpr bool lean_layout() { return GC != 0; }  // every class but GC_DENSE
 template <int K, int GC>
-__host__ __device__ constexpr int lds_doubles() { return lean_layout<K, GC>() ? Cfg<K>::LDS_DOUBLES_LEAN : Cfg<K>::LDS_DOUBLES; }
+__host__ __device__ constexpr int lds_work_doubles() { return lean_layout<K, GC>() ? Cfg<K>::LDS_DOUBLES_LEAN : Cfg<K>::LDS_DOUBLES; }
+// ... plus the wave's copy of the 32-entry (cos, sin) table of sincos_tbl, after the working areas
+template <int K, int GC>
+__host__ __device__ constexpr int lds_doubles() { return lds_work_doubles<K, GC>() + kSincosTableDoubles; }
+
+__device__ const double kSinCosTable[kSincosTableDoubles] = SLAM_SINCOS_TABLE;
+
+// copy the table into the wave's LDS (lanes 0..31: one double2 each); the caller fences
+__device__ __forceinline__ void load_sincos_table(double2* tbl, int lane) {
+    if (lane < 32) tbl[lane] = reinterpret_cast<const double2*>(kSinCosTable)[lane];
+}
 
 // Gate matrices G_1..G_K of the launch: K x 32 doubles, row-major (re, im), in device memory.
 // They are wave-uniform, so they are read through a constant-address-space pointer with scalar
@@ -223,9 +233,9 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // shape the register allocation of the optimizer loop
 __device__ __attribute__((noinline)) void sincos_slow(double x, double* s, double* c) { sincos(x, s, c); }
 
-__device__ __forceinline__ void sincos_any(double x, double& s, double& c) {
-    if (__builtin_expect(fabs(x) < kSincosFastLimit, 1)) {
-        sincos_fast(x, s, c);
+__device__ __forceinline__ void sincos_any(double x, const double2* tbl, double& s, double& c) {
+    if (__builtin_expect(fabs(x) < kSincosTblLimit, 1)) {
+        sincos_tbl(x, tbl, s, c);
     } else {
         sincos_slow(x, &s, &c);  // huge arguments, NaN/inf propagate
     }
@@ -363,7 +373,7 @@ __device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&U
 // function call -- and none of the register save/restore traffic a call site drags in -- sits in its loop.
 template <int K, bool HUGE_ARGS, int GC>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double* tcol,
-                                          const double* gates, double* xq, double2* fh,
+                                          const double* gates, double* xq, double2* fh, const double2* tbl,
                                           int q, int cost_kind, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
                                           double (&Wi)[4]) {
     using C = Cfg<K>;
@@ -386,8 +396,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
             const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
             double s, c;
-            if (HUGE_ARGS) sincos_any(arg, s, c);
-            else sincos_fast(arg, s, c);
+            if (HUGE_ARGS) sincos_any(arg, tbl, s, c);
+            else sincos_tbl(arg, tbl, s, c);
             t2[i] = make_double2(c, s);
         }
     }

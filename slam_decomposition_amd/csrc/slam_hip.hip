@@ -706,8 +706,8 @@ int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int
     if (x0) {
         // the optimizer kernel's range reduction covers |x| < 2e9; steps are <= 2 rad each
         for (int64_t i = 0; i < M * n; ++i)
-            if (!(x0[i] > -1e9 && x0[i] < 1e9))
-                return fail(SLAM_ERR_INVALID, "x0[%lld] = %g: explicit seeds must be finite with |x| < 1e9", (long long)i, x0[i]);
+            if (!(x0[i] > -1e8 && x0[i] < 1e8))
+                return fail(SLAM_ERR_INVALID, "x0[%lld] = %g: explicit seeds must be finite with |x| < 1e8", (long long)i, x0[i]);
         HIP_TRY(ctx->x0.reserve((size_t)M * n * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(ctx->x0.p, x0, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         d_x0 = ctx->x0.as<double>();

@@ -80,6 +80,9 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
     const int lane = threadIdx.x;
     const int q = lane & 3;
     const int quad = lane >> 2;
+    double2* tbl = reinterpret_cast<double2*>(lds + lds_work_doubles<K, GC>());
+    load_sincos_table(tbl, lane);
+    lds_fence();
     const int64_t item = (int64_t)blockIdx.x * kQuadsPerWave + quad;
     const bool live = item < args.n_items;
     const int64_t it = live ? item : 0;
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad<K, true, GC>(xd, tcol, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, q, args.cost_kind, f, gd, Wr, Wi);
+    eval_quad<K, true, GC>(xd, tcol, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, tbl, q, args.cost_kind, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -131,6 +134,9 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     double* xq = xchg + quad * C::XSTRIDE;
     float* xq32 = reinterpret_cast<float*>(xq);
     double2* fh = fhbase + lane;
+    double2* tbl = reinterpret_cast<double2*>(lds + lds_work_doubles<K, GC>());
+    load_sincos_table(tbl, lane);
+    lds_fence();
     // ---- launch shape from the device-side target count (the grid is sized for the host's upper bound)
     const unsigned n_items = (unsigned)args.ctl->n_active * (unsigned)args.restarts;
     unsigned n_waves = (n_items + kQuadsPerWave - 1) / kQuadsPerWave;
@@ -275,7 +281,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, q, args.cost_kind, ft, gt, Wr, Wi);
+            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, tbl, q, args.cost_kind, ft, gt, Wr, Wi);
         }
         const bool active = live;
         if (active) ++nev;

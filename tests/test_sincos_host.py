@@ -1,5 +1,6 @@
-"""CPU: the kernel's branch-free sincos (slam_decomposition_amd/csrc/slam_sincos.hpp) compiled for the
-host with g++ and compared with long-double libm over |x| up to 1e9."""
+"""CPU: the kernels' branch-free sincos routines (slam_decomposition_amd/csrc/slam_sincos.hpp: the
+table-driven sincos_tbl the kernels use, and the table-free sincos_fast) compiled for the host with g++ and
+compared with long-double libm over |x| up to 1e8 / 1e9."""
 import os
 import shutil
 import subprocess
@@ -13,10 +14,27 @@ SRC = r"""
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+struct D2 { double x, y; };
 int main() {
+    static const double raw[slamdev::kSincosTableDoubles] = SLAM_SINCOS_TABLE;
+    const D2* tbl = reinterpret_cast<const D2*>(raw);
     srand48(1);
     const double ranges[] = {1, 10, 100, 1e4, 1e6, 1e9};
     double worst = 0;
+    for (double R : ranges)
+        for (int i = 0; i < 400000; ++i) {
+            const double x = (drand48() * 2 - 1) * (R < 1e8 ? R : 1e8);
+            double s, c;
+            slamdev::sincos_tbl(x, tbl, s, c);
+            const double es = fabs((double)(s - sinl((long double)x)));
+            const double ec = fabs((double)(c - cosl((long double)x)));
+            if (es > worst) worst = es;
+            if (ec > worst) worst = ec;
+        }
+    for (int j = 0; j < 32; ++j) {  // the table itself: correctly rounded
+        const long double a = j * 3.14159265358979323846264338327950288L / 32;
+        if (fabs((double)(tbl[j].x - cosl(a))) > 1.2e-16 || fabs((double)(tbl[j].y - sinl(a))) > 1.2e-16) return 3;
+    }
     for (double R : ranges)
         for (int i = 0; i < 400000; ++i) {
             const double x = (drand48() * 2 - 1) * R;
@@ -31,6 +49,8 @@ int main() {
     for (double x : xs) {
         double s, c;
         slamdev::sincos_fast(x, s, c);
+        if (fabs(s - sin(x)) > 3e-16 || fabs(c - cos(x)) > 3e-16) return 2;
+        slamdev::sincos_tbl(x, tbl, s, c);
         if (fabs(s - sin(x)) > 3e-16 || fabs(c - cos(x)) > 3e-16) return 2;
     }
     printf("%.3e\n", worst);
