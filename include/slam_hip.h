@@ -117,6 +117,20 @@ int slam_sample_haar(slam_ctx* ctx, uint64_t seed, int64_t first_index, int64_t 
 int slam_get_targets(slam_ctx* ctx, int64_t first, int64_t count, double* out);
 
 /*
+ * Weyl-chamber coordinates (c1, c2, c3), in units of pi, of 4x4 unitaries -- weylchamber.c1c2c3 as called by
+ * VariationalTemplate.target_invariant (src/slam/basis_abc.py:80-84) and on the optimizer's results
+ * (src/slam/optimizer.py:85,103,224) -- computed on the device, one thread per unitary.  ndigits >= 0 rounds like
+ * numpy.round (the reference uses 8); ndigits < 0 leaves the values unrounded.  out: double[count][3].
+ *   slam_c1c2c3          unitaries from the host, double[count][4][4][2]
+ *   slam_targets_c1c2c3  the resident targets [first, first + count) (nothing is uploaded)
+ *   slam_eval_c1c2c3     the template unitaries CircuitTemplate.eval(x[m]) of M parameter vectors (the unitaries
+ *                        stay on the device; needs resident targets and gates like slam_eval_unitary)
+ */
+int slam_c1c2c3(slam_ctx* ctx, const double* unitaries, int64_t count, int ndigits, double* out);
+int slam_targets_c1c2c3(slam_ctx* ctx, int64_t first, int64_t count, int ndigits, double* out);
+int slam_eval_c1c2c3(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, int64_t M, int ndigits, double* out);
+
+/*
  * Upload the table of 2Q basis-gate matrices (CircuitTemplate(base_gates=...),
  * src/slam/basis.py:52-69; matrices from src/slam/utils/gates/custom_gates.py).
  * gates: double[n_gates][4][4][2].

@@ -33,6 +33,9 @@ EXPORTED_SYMBOLS = (
     "slam_ctx_device_info",
     "slam_set_targets",
     "slam_set_gates",
+    "slam_c1c2c3",
+    "slam_targets_c1c2c3",
+    "slam_eval_c1c2c3",
     "slam_sample_haar",
     "slam_get_targets",
     "slam_eval_loss_grad",
@@ -114,6 +117,9 @@ def load_library() -> C.CDLL:
     lib.slam_ctx_device_info.argtypes = [P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.slam_set_targets.argtypes = [P, P, C.c_int64]
     lib.slam_set_gates.argtypes = [P, P, C.c_int32]
+    lib.slam_c1c2c3.argtypes = [P, P, C.c_int64, C.c_int32, P]
+    lib.slam_targets_c1c2c3.argtypes = [P, C.c_int64, C.c_int64, C.c_int32, P]
+    lib.slam_eval_c1c2c3.argtypes = [P, C.c_int32, P, P, C.c_int64, C.c_int32, P]
     lib.slam_sample_haar.argtypes = [P, C.c_uint64, C.c_int64, C.c_int64]
     lib.slam_get_targets.argtypes = [P, C.c_int64, C.c_int64, P]
     lib.slam_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P]
@@ -201,6 +207,34 @@ class Context:
             raise ValueError("targets must have shape [N, 4, 4]")
         _check(self._lib.slam_set_targets(self._h, _ptr(t), t.shape[0]))
         self.n_targets = t.shape[0]
+
+    def c1c2c3(self, unitaries: np.ndarray, ndigits: int = 8) -> np.ndarray:
+        """Weyl coordinates of ``unitaries[N, 4, 4]`` (weylchamber.c1c2c3, basis_abc.py:80-84) -> float64[N, 3]."""
+        u = np.ascontiguousarray(unitaries, dtype=np.complex128)
+        if u.ndim != 3 or u.shape[1:] != (4, 4):
+            raise ValueError("expected an array of shape [N, 4, 4]")
+        out = np.zeros((u.shape[0], 3), dtype=np.float64)
+        _check(self._lib.slam_c1c2c3(self._h, _ptr(u.view(np.float64)), u.shape[0], int(ndigits), _ptr(out)))
+        return out
+
+    def targets_c1c2c3(self, first: int = 0, count: Optional[int] = None, ndigits: int = 8) -> np.ndarray:
+        """Weyl coordinates of the resident targets [first, first + count) -> float64[count, 3]."""
+        count = self.n_targets - first if count is None else count
+        out = np.zeros((count, 3), dtype=np.float64)
+        _check(self._lib.slam_targets_c1c2c3(self._h, int(first), int(count), int(ndigits), _ptr(out)))
+        return out
+
+    def eval_c1c2c3(self, gate_seq: Sequence[int], x: np.ndarray, ndigits: int = 8) -> np.ndarray:
+        """Weyl coordinates of CircuitTemplate.eval(x[m]) for ``x[M, n]`` (optimizer.py:85,103) -> float64[M, 3];
+        the unitaries never leave the device."""
+        k = len(gate_seq)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != 6 * (k + 1):
+            raise ValueError(f"x must have shape [M, {6 * (k + 1)}]")
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        out = np.zeros((x.shape[0], 3), dtype=np.float64)
+        _check(self._lib.slam_eval_c1c2c3(self._h, k, _ptr(gs), _ptr(x), x.shape[0], int(ndigits), _ptr(out)))
+        return out
 
     def sample_haar(self, seed: int, n_targets: int, first_index: int = 0) -> None:
         """Generate the resident batch on the device: T_i = Haar(seed, first_index + i)."""

@@ -3,6 +3,7 @@
 #include "../../include/slam_hip.h"
 #include "slam_kernels.hpp"
 #include "slam_sampler.hpp"
+#include "slam_weyl.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -103,14 +104,14 @@ struct slam_ctx {
     int compute_units = 0;
     int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1][4] = {};
     // eval buffers
-    DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary;
+    DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary, ev_weyl;
     slam_stats stats{};
     bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][4][2] = {};
 
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary};
+                         &best_x, &best_cycles, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -602,7 +603,7 @@ int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates) {
 }
 
 static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
-                     int64_t M, double* loss, double* grad, double* unitary) {
+                     int64_t M, double* loss, double* grad, double* unitary, double* weyl = nullptr, int ndigits = 8) {
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
@@ -621,12 +622,13 @@ static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
     HIP_TRY(ctx->ev_tof.reserve((size_t)M * sizeof(int32_t)));
     HIP_TRY(ctx->ev_loss.reserve((size_t)M * sizeof(double)));
     if (grad) HIP_TRY(ctx->ev_grad.reserve((size_t)M * n * sizeof(double)));
-    if (unitary) HIP_TRY(ctx->ev_unitary.reserve((size_t)M * 32 * sizeof(double)));
+    if (unitary || weyl) HIP_TRY(ctx->ev_unitary.reserve((size_t)M * 32 * sizeof(double)));
+    if (weyl) HIP_TRY(ctx->ev_weyl.reserve((size_t)M * 3 * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(ctx->ev_x.p, x, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->ev_tof.p, target_of, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     double* d_loss = ctx->ev_loss.as<double>();
     double* d_grad = grad ? ctx->ev_grad.as<double>() : nullptr;
-    double* d_unit = unitary ? ctx->ev_unitary.as<double>() : nullptr;
+    double* d_unit = (unitary || weyl) ? ctx->ev_unitary.as<double>() : nullptr;
     const double* d_x = ctx->ev_x.as<double>();
     const int32_t* d_tof = ctx->ev_tof.as<int32_t>();
     const int gc = classify_gates(ctx, k, gate_seq);
@@ -653,6 +655,24 @@ static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
     HIP_TRY(hipMemcpyAsync(loss, ctx->ev_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (grad) HIP_TRY(hipMemcpyAsync(grad, ctx->ev_grad.p, (size_t)M * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (unitary) HIP_TRY(hipMemcpyAsync(unitary, ctx->ev_unitary.p, (size_t)M * 32 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (weyl) {
+        // Weyl coordinates of the template unitaries without bringing the unitaries back (optimizer.py:85,103)
+        hipLaunchKernelGGL(c1c2c3_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, ctx->ev_unitary.as<double>(), M,
+                           ndigits, ctx->ev_weyl.as<double>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(weyl, ctx->ev_weyl.p, (size_t)M * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// Weyl coordinates of `count` unitaries that are already in device memory
+static int weyl_device(slam_ctx* ctx, const double* d_unitaries, int64_t count, int ndigits, double* out) {
+    HIP_TRY(ctx->ev_weyl.reserve((size_t)count * 3 * sizeof(double)));
+    hipLaunchKernelGGL(c1c2c3_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, d_unitaries, count, ndigits,
+                       ctx->ev_weyl.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, ctx->ev_weyl.p, (size_t)count * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
 }
@@ -804,6 +824,34 @@ int slam_decompose(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs
     int rc = decompose_impl(ctx, 0, ctx->n_targets, k_min, k_max, gate_seqs, params, success_threshold);
     if (rc) return rc;
     return slam_fetch_results(ctx, k_max, best_loss, best_x, best_cycles);
+}
+
+int slam_c1c2c3(slam_ctx* ctx, const double* unitaries, int64_t count, int ndigits, double* out) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (count < 0) return fail(SLAM_ERR_INVALID, "count < 0");
+    if (count == 0) return SLAM_OK;
+    if (!unitaries || !out) return fail(SLAM_ERR_INVALID, "unitaries and out must be non-NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->ev_unitary.reserve((size_t)count * 32 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(ctx->ev_unitary.p, unitaries, (size_t)count * 32 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return weyl_device(ctx, ctx->ev_unitary.as<double>(), count, ndigits, out);
+}
+
+int slam_targets_c1c2c3(slam_ctx* ctx, int64_t first, int64_t count, int ndigits, double* out) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (first < 0 || count < 0 || first + count > ctx->n_targets)
+        return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    if (count == 0) return SLAM_OK;
+    if (!out) return fail(SLAM_ERR_INVALID, "out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return weyl_device(ctx, ctx->targets.as<double>() + first * 32, count, ndigits, out);
+}
+
+int slam_eval_c1c2c3(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, int64_t M, int ndigits, double* out) {
+    if (!out && M > 0) return fail(SLAM_ERR_INVALID, "out is NULL");
+    std::vector<int32_t> tof((size_t)(M > 0 ? M : 0), 0);  // the loss is not wanted: any resident target will do
+    std::vector<double> loss((size_t)(M > 0 ? M : 0));
+    return eval_impl(ctx, k, gate_seq, x, tof.data(), M, loss.data(), nullptr, nullptr, out, ndigits);
 }
 
 int slam_sample_haar(slam_ctx* ctx, uint64_t seed, int64_t first_index, int64_t n_targets) {

@@ -26,7 +26,6 @@ from .basis import CircuitTemplate
 from .basis_abc import DataDictEntry, VariationalTemplate
 from .cost_function import BasicCost, SquareCost, UnitaryCostFunction
 from .sampler import SampleFunction
-from .weyl import c1c2c3_batch
 
 SUCCESS_THRESHOLD = 1e-10  # optimizer.py:18
 TRAINING_RESTARTS = 5  # optimizer.py:19
@@ -211,8 +210,8 @@ class TemplateOptimizer:
         for k in np.unique(best_cycles):
             idx = np.nonzero(best_cycles == k)[0]
             X = np.stack([best_xs[i] for i in idx])
-            W, _ = ctx.eval_unitary(self.basis.gate_sequence(int(k)), X)
-            found[idx] = c1c2c3_batch(W)
+            # template unitary and its Weyl coordinates on the device: three doubles per circuit come back
+            found[idx] = ctx.eval_c1c2c3(self.basis.gate_sequence(int(k)), X)
         return found
 
     # ------------------------------------------------------------------------------------------
@@ -235,7 +234,8 @@ class TemplateOptimizer:
             if t.shape != (4, 4):
                 raise ValueError("targets must be 4x4 unitaries")
         stacked = np.stack(targets)
-        coords = [tuple(float(v) for v in c) for c in c1c2c3_batch(stacked)]  # target_invariant, basis_abc.py:80-84
+        # target_invariant (basis_abc.py:80-84) for the whole batch, on the device
+        coords = [tuple(float(v) for v in c) for c in runtime.get_context(self.devices[0]).c1c2c3(stacked)]
         self.basis.assign_seed(None)  # optimizer.py:150-152
         spanning_range = self.basis.get_spanning_range(targets[0])
         best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "slam_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(slam_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_symbols_are_exported_and_bound():
