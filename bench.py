@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "0")),
                     help="launch shaping (slam_opt_params.items_per_quad); 0 = library default")
     ap.add_argument("--host-targets", action="store_true", help="draw the Haar targets with SciPy on the host instead of on the device")
+    ap.add_argument("--span-rules", action="store_true",
+                    help="polytope mode (CircuitTemplate(use_polytopes=True)): each target is optimised only at the template "
+                         "size the analytic span rules assign to it (device c1c2c3 + span_rules.py) instead of spans 1..3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     args = ap.parse_args()
@@ -220,7 +223,27 @@ def main():
         # rank r takes column p = r of the (m, p) grid: all 16 strengths m, so every GPU has weak and strong gates
         return (s % SWEEP_BASES_PER_GPU) * 8 + rank % 8
 
+    gate_coords = None
+    if args.span_rules:
+        from slam_decomposition_amd import span_rules
+        from slam_decomposition_amd.weyl import c1c2c3 as host_c1c2c3
+
+        if len(table) != 1:
+            raise SystemExit("--span-rules needs a single basis gate (cfg2, cfg3)")
+        gate_coords = host_c1c2c3(table[0])
+        span_rules.family_of(gate_coords)
+
     def one_step(s: int, c):
+        if args.span_rules:
+            first = s * n_per_step
+            spans = span_rules.minimal_span(c.targets_c1c2c3(first, n_per_step), gate_coords)
+            for k in np.unique(spans):
+                k = int(k)
+                if k < 1:
+                    continue  # local targets need no 2Q gate
+                c.decompose_list(first + np.nonzero(spans == k)[0], k, k, [gate_seqs[k - 1]], prm, threshold, k_layout=3)
+            best_loss, best_x, best_cycles = c.fetch_results_range(3, first, n_per_step)
+            return best_loss, best_cycles
         if sweep:
             c.set_gates(np.stack([sweep_gate(basis_of(s))]))
             best_loss, best_x, best_cycles = c.decompose_range(0, n_per_step, 1, 3, gate_seqs, prm, threshold)
@@ -347,6 +370,7 @@ def main():
                 "targets_per_step_per_gpu": n_per_step,
                 "restarts": restarts,
                 "span_max": 3,
+                "span_selection": "analytic span rules (use_polytopes mode)" if args.span_rules else "brute force 1..3 (reference default)",
                 "success_threshold": threshold,
                 "parallelism": (f"bases sharded over {world} GPU(s) ({SWEEP_BASES_PER_GPU} each), targets replicated, no data-path collective"
                                 if sweep else f"targets sharded over {world} GPU(s), no data-path collective"),

@@ -214,6 +214,13 @@ int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best
 int slam_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max,
                          const int32_t* gate_seqs, const slam_opt_params* params,
                          double success_threshold);
+/* The same for an explicit list of resident-target indices (e.g. the targets a span predictor assigns to one
+ * template size: CircuitTemplate.get_spanning_range with use_polytopes, src/slam/basis.py:95-100).  Results land
+ * in the per-target resident arrays like those of slam_decompose_range; fetch them with
+ * slam_fetch_results_range(ctx, k_layout, ...): rows of best_x are 6 (k_layout + 1) wide, so that lists with
+ * different k_max can share one resident result set (k_layout = 0 means k_max). */
+int slam_decompose_list(slam_ctx* ctx, const int32_t* targets, int64_t count, int k_min, int k_max, int k_layout,
+                        const int32_t* gate_seqs, const slam_opt_params* params, double success_threshold);
 int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t count,
                              double* best_loss, double* best_x, int32_t* best_cycles);
 

@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "slam_decompose_resident",
     "slam_fetch_results",
     "slam_decompose_range",
+    "slam_decompose_list",
     "slam_fetch_results_range",
     "slam_set_cost",
     "slam_synchronize",
@@ -129,6 +130,7 @@ def load_library() -> C.CDLL:
     lib.slam_decompose_resident.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results.argtypes = [P, C.c_int, P, P, P]
     lib.slam_decompose_range.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
+    lib.slam_decompose_list.argtypes = [P, P, C.c_int64, C.c_int, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results_range.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, P, P]
     lib.slam_set_cost.argtypes = [P, C.c_int]
     lib.slam_synchronize.argtypes = [P]
@@ -363,6 +365,14 @@ class Context:
         if fetch:
             return self.fetch_results_range(k_max, first, count)
         return None
+
+    def decompose_list(self, targets, k_min, k_max, gate_seqs, params: OptParams, success_threshold: float, k_layout: int = 0):
+        """Span loop for an explicit list of resident-target indices (slam_decompose_list); results stay in the
+        per-target resident arrays (row width 6 (k_layout + 1)): fetch with ``fetch_results_range(k_layout, ...)``."""
+        idx = np.ascontiguousarray(targets, dtype=np.int32)
+        flat = self._flat_gate_seqs(gate_seqs, k_min, k_max)
+        _check(self._lib.slam_decompose_list(self._h, _ptr(idx), idx.shape[0], k_min, k_max, int(k_layout), _ptr(flat),
+                                              C.byref(params), float(success_threshold)))
 
     def fetch_results_range(self, k_max: int, first: int, count: int):
         nmax = 6 * (k_max + 1)

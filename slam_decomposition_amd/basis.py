@@ -11,7 +11,7 @@ from typing import List, Sequence
 
 import numpy as np
 
-from . import runtime
+from . import runtime, span_rules
 from .basis_abc import VariationalTemplate
 from .gates import RiSwapGate, gate_matrix
 
@@ -35,11 +35,6 @@ class CircuitTemplate(VariationalTemplate):
             edge_params = [[(0, 1)]]
         if n_qubits != 2:
             raise NotImplementedError("the HIP template optimizer handles 2-qubit templates only")
-        if use_polytopes:
-            raise NotImplementedError(
-                "use_polytopes needs the monodromy package (reference: utils/polytopes/polytope_wrap.py); "
-                "out of scope, see SURVEY.md §8(f) row 4"
-            )
         if no_exterior_1q:
             raise NotImplementedError("no_exterior_1q=True is not implemented on the HIP path")
         for el in edge_params:
@@ -58,8 +53,18 @@ class CircuitTemplate(VariationalTemplate):
         self.bounds_list = None
         self.using_constraints = False
         self.constraint_func = None
-        self.spanning_range = range(1, maximum_span_guess + 1)  # basis.py:84-85
+        # basis.py:82-86: the brute-force range exists only without polytopes
+        self.spanning_range = None if use_polytopes else range(1, maximum_span_guess + 1)
+        self.maximum_span_guess = maximum_span_guess
         self.coverage = None
+        if use_polytopes:
+            # the reference needs monodromy's precomputed coverage sets; here: analytic rules (span_rules.py)
+            if len(self.base_gates) != 1:
+                raise NotImplementedError("use_polytopes: analytic span rules cover templates with one basis gate")
+            from .weyl import c1c2c3
+
+            self._gate_coords = c1c2c3(self.gate_matrices[0])
+            span_rules.family_of(self._gate_coords)  # NotImplementedError for unsupported gates
         super().__init__(preseed=preseed, use_polytopes=use_polytopes)
         self._reset()
         self.trotter = False
@@ -87,7 +92,20 @@ class CircuitTemplate(VariationalTemplate):
         return 6 * (self.cycles + 1)
 
     def get_spanning_range(self, target_u):
-        return self.spanning_range  # basis.py:95-97 (no polytopes)
+        """basis.py:95-100: the brute-force range, or -- with polytopes -- only the template size the target
+        needs (``range(k, k + 1)``, polytope_wrap.py:39-94; here from the analytic rules of span_rules.py)."""
+        if not self.use_polytopes:
+            return self.spanning_range
+        from .weyl import c1c2c3
+
+        k = int(span_rules.minimal_span(np.array([c1c2c3(target_u)]), self._gate_coords)[0])
+        return range(k, k + 1)
+
+    def minimal_spans(self, target_coords) -> np.ndarray:
+        """Batched form of the polytope lookup: minimal template size per target from its Weyl coordinates."""
+        if not self.use_polytopes:
+            raise ValueError("minimal_spans needs use_polytopes=True")
+        return span_rules.minimal_span(target_coords, self._gate_coords)
 
     # ---- numerics -----------------------------------------------------------------------------
     def eval(self, Xk):

@@ -423,8 +423,9 @@ int ensure_results(slam_ctx* c, int k_max) {
     return SLAM_OK;
 }
 
+// h_list != nullptr: the batch is the explicit list of resident-target indices h_list[0..count) (first ignored)
 int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
-                   const slam_opt_params* prm, double success_threshold) {
+                   const slam_opt_params* prm, double success_threshold, const int32_t* h_list = nullptr, int k_layout = 0) {
     if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
@@ -442,12 +443,20 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
             gs += k;
         }
     }
-    if (first < 0 || count <= 0 || first + count > c->n_targets)
+    if (h_list) {
+        if (count <= 0) return fail(SLAM_ERR_INVALID, "empty target list");
+        for (int64_t i = 0; i < count; ++i)
+            if (h_list[i] < 0 || h_list[i] >= c->n_targets)
+                return fail(SLAM_ERR_INVALID, "targets[%lld] = %d outside [0, %lld)", (long long)i, h_list[i], (long long)c->n_targets);
+        first = 0;
+    } else if (first < 0 || count <= 0 || first + count > c->n_targets)
         return fail(SLAM_ERR_INVALID, "target window [%lld, %lld) outside [0, %lld)", (long long)first,
                     (long long)(first + count), (long long)c->n_targets);
-    if (c->result_nmax != 0 && c->result_nmax != 6 * (k_max + 1) && !(first == 0 && count == c->n_targets))
+    if (k_layout == 0) k_layout = k_max;
+    if (k_layout < k_max || k_layout > SLAM_MAX_SPAN_MINIMIZE) return fail(SLAM_ERR_INVALID, "k_layout must be in [k_max, %d]", SLAM_MAX_SPAN_MINIMIZE);
+    if (c->result_nmax != 0 && c->result_nmax != 6 * (k_layout + 1) && (h_list || !(first == 0 && count == c->n_targets)))
         return fail(SLAM_ERR_STATE, "resident results were produced with a different k_max");
-    rc = ensure_results(c, k_max);
+    rc = ensure_results(c, k_layout);
     if (rc) return rc;
     const int64_t N = count;
     HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
@@ -455,12 +464,13 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     rc = reserve_stage_buffers(c, N, k_max, prm);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
-    const bool whole = (first == 0 && count == c->n_targets);
+    const bool whole = !h_list && (first == 0 && count == c->n_targets);
+    if (h_list) HIP_TRY(hipMemcpyAsync(c->active.p, h_list, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)(((whole ? N : N * 16) + 255) / 256)), dim3(256), 0, c->stream,
                        c->best_loss.as<double>(), c->best_cycles.as<int32_t>(),
                        whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N, stage_ctl(c, k_min),
                        c->targets.as<double>(), c->stage_targets.as<double>(), c->solved.as<int32_t>(),
-                       c->counters.as<StageCtl>(), (int32_t)(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2) / 8));
+                       c->counters.as<StageCtl>(), (int32_t)(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2) / 8), h_list ? 1 : 0);
     HIP_TRY(hipGetLastError());
 
     // The whole span loop is enqueued at once: a stage's target count is produced on the device by the
@@ -768,6 +778,13 @@ int slam_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min,
                          const int32_t* gate_seqs, const slam_opt_params* params, double success_threshold) {
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     return decompose_impl(ctx, first, count, k_min, k_max, gate_seqs, params, success_threshold);
+}
+
+int slam_decompose_list(slam_ctx* ctx, const int32_t* targets, int64_t count, int k_min, int k_max, int k_layout,
+                        const int32_t* gate_seqs, const slam_opt_params* params, double success_threshold) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (!targets) return fail(SLAM_ERR_INVALID, "targets is NULL");
+    return decompose_impl(ctx, 0, count, k_min, k_max, gate_seqs, params, success_threshold, targets, k_layout);
 }
 
 int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t count, double* best_loss,

@@ -526,9 +526,11 @@ __global__ void set_n_active_kernel(StageCtl* ctl, int32_t n) { ctl->n_active = 
 // active list, and publish n as the first stage's target count
 // ... and prepare the first stage's inputs (early-exit flags; the window's targets as a dense array when
 // the batch is a window of the resident targets).  One thread per double2 of the window's targets.
+// list_mode: the batch is an explicit list of target indices already in `active` (slam_decompose_list)
+// instead of the window [first, first + n).
 __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int32_t* active, int64_t first,
                                     int64_t n, StageCtl* first_stage, const double* targets, double* stage_targets,
-                                    int32_t* solved, StageCtl* ctl_all, int32_t n_ctl_words) {
+                                    int32_t* solved, StageCtl* ctl_all, int32_t n_ctl_words, int32_t list_mode) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) {
         // one thread clears all stages' control blocks, then publishes the first stage's target count
@@ -536,13 +538,16 @@ __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int
         first_stage->n_active = (int32_t)n;
     }
     if (t < n) {
-        best_loss[first + t] = INFINITY;
-        best_cycles[first + t] = -1;
+        const int64_t tgt = list_mode ? (int64_t)active[t] : first + t;
+        best_loss[tgt] = INFINITY;
+        best_cycles[tgt] = -1;
         solved[t] = 0;
-        if (active) active[t] = (int32_t)(first + t);
+        if (active && !list_mode) active[t] = (int32_t)tgt;
     }
-    if (active && t < n * 16)
-        reinterpret_cast<double2*>(stage_targets)[t] = reinterpret_cast<const double2*>(targets)[first * 16 + t];
+    if (active && t < n * 16) {
+        const int64_t src = list_mode ? (int64_t)active[t >> 4] * 16 + (t & 15) : first * 16 + t;
+        reinterpret_cast<double2*>(stage_targets)[t] = reinterpret_cast<const double2*>(targets)[src];
+    }
 }
 
 // Ordered compaction of the targets that still need a longer template:

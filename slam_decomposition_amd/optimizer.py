@@ -123,6 +123,8 @@ class TemplateOptimizer:
         ks = list(spanning_range)
         if not ks:
             raise ValueError("empty spanning range")
+        if ks[0] <= 0:
+            raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
         if ks != list(range(ks[0], ks[-1] + 1)):
             raise NotImplementedError("spanning range must be contiguous")
         if ks[-1] > _ffi.MAX_SPAN_MINIMIZE:
@@ -183,6 +185,31 @@ class TemplateOptimizer:
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
         return best_loss, xs, best_cycles
 
+    def _run_batch_by_span(self, targets: np.ndarray, spans: np.ndarray):
+        """Polytope mode: every target is optimised only at the template size ``spans[t]`` it needs.  The batch is
+        resident once; each size is one ``slam_decompose_list`` call over the list of its targets."""
+        if np.any(spans <= 0):
+            raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
+        k_top = int(spans.max())
+        if k_top > _ffi.MAX_SPAN_MINIMIZE:
+            raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path")
+        prm = self._opt_params()
+        ctx = runtime.get_context(self.devices[0])
+        if self._device_sampler is not None:
+            self._device_sampler.fill(ctx)
+        else:
+            ctx.set_targets(targets)
+        ctx.set_gates(self.basis.gate_matrices)
+        ctx.set_cost(self._cost_kind)
+        ctx.reset_stats()
+        for k in np.unique(spans):
+            k = int(k)
+            ctx.decompose_list(np.nonzero(spans == k)[0], k, k, [self.basis.gate_sequence(k)], prm, self.success_threshold, k_layout=k_top)
+        best_loss, best_x, best_cycles = ctx.fetch_results_range(k_top, 0, len(targets))
+        self.last_stats = ctx.stats()
+        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(len(targets))]
+        return best_loss, xs, best_cycles
+
     def _finish_target(self, target_coordinates, best_result, best_Xk, best_cycles, found_coordinates) -> DataDictEntry:
         """Labelling / logging / exception of approximate_target_U (optimizer.py:80-119)."""
         logging.info(f"Overall Best Loss={best_result}")
@@ -237,8 +264,14 @@ class TemplateOptimizer:
         # target_invariant (basis_abc.py:80-84) for the whole batch, on the device
         coords = [tuple(float(v) for v in c) for c in runtime.get_context(self.devices[0]).c1c2c3(stacked)]
         self.basis.assign_seed(None)  # optimizer.py:150-152
-        spanning_range = self.basis.get_spanning_range(targets[0])
-        best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)
+        if self.basis.use_polytopes:
+            # get_spanning_range per target (optimizer.py:233 with basis.py:95-100): only the template size
+            # the target needs.  Targets are grouped by that size; each group is one batch.
+            spans = self.basis.minimal_spans(np.array(coords))
+            best_loss, best_xs, best_cycles = self._run_batch_by_span(stacked, spans)
+        else:
+            spanning_range = self.basis.get_spanning_range(targets[0])
+            best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)
         found = self._found_coordinates(best_xs, np.asarray(best_cycles))
         self.basis.build(n_repetitions=int(best_cycles[-1]))  # the reference leaves the template at the last size
         out = []

@@ -227,3 +227,43 @@ def test_config4_basis_sweep_matches_oracle_per_basis():
                 assert data[t].cycles == ref_k, (b, t)
             else:
                 assert abs(data[t].loss_result - ref_loss) < 1e-6, (b, t, data[t].loss_result, ref_loss)
+
+
+def test_use_polytopes_analytic_span_rules_match_brute_force():
+    """``use_polytopes=True`` (reference: monodromy coverage lookup, polytope_wrap.py:39-94; here the analytic
+    rules of span_rules.py): the predicted template size equals the size the brute-force span loop ends with,
+    for Haar targets and for targets on the measure-zero faces, and the polytope mode returns the same cycles."""
+    from slam_decomposition_amd import span_rules
+    from slam_decomposition_amd.weyl import c1c2c3_batch
+    from scipy.stats import unitary_group
+
+    rng = np.random.default_rng(1)
+
+    def local():
+        return np.kron(unitary_group.rvs(2, random_state=rng), unitary_group.rvs(2, random_state=rng))
+
+    haar = list(o.haar_batch(24, seed0=9000))
+    # special targets: c3 = 0 faces, the basis gates themselves, a sqrt(iSWAP) boundary case
+    special = [local() @ o.canonical_matrix(a, b, 0.0) @ local() for a, b in ((0.37, 0.11), (0.5, 0.3), (0.21, 0.21))]
+    special += [local() @ g @ local() for g in (o.cx_matrix(), o.riswap_matrix(0.5), o.berkeley_matrix())]
+    targets = np.stack(haar + special)
+    coords = c1c2c3_batch(targets)
+    for gate in (CXGate(), RiSwapGate(0.5), BerkeleyGate()):
+        brute = TemplateOptimizer(CircuitTemplate(base_gates=[gate], maximum_span_guess=3), BasicCost(),
+                                  override_fail=True, training_restarts=16, seed=2)
+        data_b = brute._approximate_batch(list(targets), log_index=False)
+        poly_basis = CircuitTemplate(base_gates=[gate], maximum_span_guess=3, use_polytopes=True)
+        spans = poly_basis.minimal_spans(coords)
+        assert np.array_equal(spans, span_rules.minimal_span(coords, o.c1c2c3(np.asarray(gate.to_matrix()))))
+        for t in range(len(targets)):
+            assert data_b[t].success_label == 1, (type(gate).__name__, t, data_b[t].loss_result)
+            assert data_b[t].cycles == spans[t], (type(gate).__name__, t, coords[t], data_b[t].cycles, spans[t])
+            assert poly_basis.get_spanning_range(targets[t]) == range(spans[t], spans[t] + 1)
+        poly = TemplateOptimizer(poly_basis, BasicCost(), training_restarts=16, seed=2)
+        data_p = poly._approximate_batch(list(targets), log_index=False)
+        assert [d.cycles for d in data_p] == [int(k) for k in spans]
+        assert all(d.success_label == 1 for d in data_p)
+    with pytest.raises(NotImplementedError, match="analytic span rules"):
+        CircuitTemplate(base_gates=[RiSwapGate(1.0)], use_polytopes=True)
+    with pytest.raises(ValueError):  # a local target needs 0 gates: build(0), basis.py:127-128
+        TemplateOptimizer(CircuitTemplate(base_gates=[CXGate()], use_polytopes=True), BasicCost()).approximate_target_U(local())

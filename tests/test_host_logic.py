@@ -5,6 +5,7 @@ import pytest
 
 from oracle import slam_oracle as o
 from slam_decomposition_amd import gates as G
+from slam_decomposition_amd.gates import CXGate, RiSwapGate
 from slam_decomposition_amd.basis import CircuitTemplate
 from slam_decomposition_amd.basis_abc import DataDictEntry
 from slam_decomposition_amd.cost_function import BasicCost
@@ -85,9 +86,31 @@ def test_circuit_template_structure():
     assert gl[0] == ("u", 0, (0.0, 1.0, 2.0)) and gl[1] == ("u", 1, (3.0, 4.0, 5.0)) and gl[3] == ("u", 0, (6.0, 7.0, 8.0))
     assert t.target_invariant(o.cx_matrix()) == (0.5, 0.0, 0.0)
     assert t.target_invariant(np.eye(8)) == (-1, -1, -1, -1)
-    for kwargs in (dict(use_polytopes=True), dict(no_exterior_1q=True), dict(n_qubits=3), dict(edge_params=[[(1, 0)]])):
+    for kwargs in (dict(no_exterior_1q=True), dict(n_qubits=3), dict(edge_params=[[(1, 0)]]),
+                   dict(use_polytopes=True, base_gates=[RiSwapGate(1.0)]),  # no analytic rule for iSWAP
+                   dict(use_polytopes=True, base_gates=[RiSwapGate(0.5), CXGate()])):
         with pytest.raises(NotImplementedError):
             CircuitTemplate(**kwargs)
+
+
+def test_span_rules_and_polytope_mode_ranges():
+    """use_polytopes=True: analytic stand-in for monodromy_range_from_target (polytope_wrap.py:39-94)."""
+    from slam_decomposition_amd import span_rules
+
+    cx, sq, b = (0.5, 0.0, 0.0), (0.25, 0.25, 0.0), (0.5, 0.25, 0.0)
+    coords = np.array([(0, 0, 0), (1.0, 0, 0), cx, sq, b, (0.37, 0.11, 0.0), (0.4, 0.3, 0.2), (0.7, 0.2, 0.05), (0.3, 0.1, 0.1),
+                       (0.5, 0.5, 0.5)])
+    assert span_rules.minimal_span(coords, cx).tolist() == [0, 0, 1, 2, 2, 2, 3, 3, 3, 3]
+    # sqrt(iSWAP): 2 iff |z| <= x - y in the folded chamber (weyl_decompose.py:348); (0.7, 0.2, 0.05) folds to (0.3, 0.2, -0.05)
+    assert span_rules.minimal_span(coords, sq).tolist() == [0, 0, 2, 1, 2, 2, 3, 2, 2, 3]
+    assert span_rules.minimal_span(coords, b).tolist() == [0, 0, 2, 2, 1, 2, 2, 2, 2, 2]
+    assert span_rules.family_of((0.75, 0.25, 0.0)) == "sqiswap"  # mirror image of (0.25, 0.25, 0)
+    t = CircuitTemplate(base_gates=[RiSwapGate(0.5)], use_polytopes=True)
+    assert t.spanning_range is None and t.use_polytopes  # basis.py:82-86
+    assert t.get_spanning_range(o.riswap_matrix(0.5)) == range(1, 2)
+    assert t.get_spanning_range(o.cx_matrix()) == range(2, 3)
+    assert t.get_spanning_range(np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex)) == range(3, 4)
+    assert t.get_spanning_range(np.eye(4)) == range(0, 1)  # polytope_wrap.py:55-56
 
 
 def test_qiskit_parameter_order_helpers():
