@@ -98,7 +98,7 @@ struct slam_ctx {
     DevBuf solved;
     DevBuf stage_targets;
     DevBuf span_gates;  // 64 slots x [SLAM_MAX_SPAN_EVAL][32] doubles
-    int gate_slot = 0;
+    struct StagedSeq { bool valid = false; int32_t seq[SLAM_MAX_SPAN_EVAL] = {}; } staged[SLAM_MAX_SPAN_EVAL + 1];
     int cost_kind = 0;  // SLAM_COST_*
     std::vector<double> gates_host;
     int compute_units = 0;
@@ -132,15 +132,20 @@ constexpr size_t lds_bytes() { return sizeof(double) * lds_doubles<K, GC>(); }
 
 // copy G_1..G_K of this span, in order, into the context's small device buffer (stream-ordered)
 int stage_gates(slam_ctx* c, int k, const int32_t* gate_seq, const double** d_out) {
-    // a rotating set of slots so that an in-flight kernel never sees its matrices overwritten.  The host
-    // side of a slot is pinned: a copy from pageable memory would make the calling thread wait (spinning)
-    // for everything enqueued before it, i.e. for the previous stage of the span loop.
-    c->gate_slot = (c->gate_slot + 1) % 64;
-    double* tmp = c->h_gates + (size_t)c->gate_slot * SLAM_MAX_SPAN_EVAL * 32;
-    for (int j = 0; j < k; ++j) std::memcpy(tmp + 32 * j, c->gates_host.data() + (size_t)gate_seq[j] * 32, 32 * sizeof(double));
-    double* dst = c->span_gates.as<double>() + (size_t)c->gate_slot * SLAM_MAX_SPAN_EVAL * 32;
-    HIP_TRY(hipMemcpyAsync(dst, tmp, (size_t)k * 32 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // One device slot per span k, cached: as long as the gate table and the span's sequence do not change (the
+    // normal case: one basis, many batches) nothing is copied -- a copy inside the span loop's chain of kernels
+    // costs as much as a kernel there (it waits its turn on a busy GPU).  Every API call ends with the stream
+    // drained, so a slot is never rewritten under a running kernel.  The host side of a slot is pinned: a copy
+    // from pageable memory would make the calling thread wait (spinning) for everything enqueued before it.
+    double* dst = c->span_gates.as<double>() + (size_t)k * SLAM_MAX_SPAN_EVAL * 32;
     *d_out = dst;
+    slam_ctx::StagedSeq& st = c->staged[k];
+    if (st.valid && std::memcmp(st.seq, gate_seq, (size_t)k * sizeof(int32_t)) == 0) return SLAM_OK;
+    double* tmp = c->h_gates + (size_t)k * SLAM_MAX_SPAN_EVAL * 32;
+    for (int j = 0; j < k; ++j) std::memcpy(tmp + 32 * j, c->gates_host.data() + (size_t)gate_seq[j] * 32, 32 * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(dst, tmp, (size_t)k * 32 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    std::memcpy(st.seq, gate_seq, (size_t)k * sizeof(int32_t));
+    st.valid = true;
     return SLAM_OK;
 }
 
@@ -609,6 +614,7 @@ int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->gates_host.assign(gates, gates + (size_t)n_gates * 32);
     ctx->n_gates = n_gates;
+    for (auto& st : ctx->staged) st.valid = false;
     return SLAM_OK;
 }
 
