@@ -47,6 +47,7 @@ WORKLOADS = {
     "cfg5": ("cgsweep", 4096, 16, "BASELINE configs[4] per-GPU shard: 16 of 128 ConversionGain(0,0,gc,gg,1) bases x 4096 shared Haar targets x 16 restarts"),
 }
 SWEEP_BASES_PER_GPU = 16
+SWEEP_CPU_BASIS = 64  # m = 9/32, p = 0: the basis the CPU baseline of cfg5 runs
 
 
 def sweep_gate(b: int) -> np.ndarray:
@@ -87,7 +88,10 @@ def _cpu_one(args):
     seed0, idx, gname, restarts, seed, host_targets, analytic = args
     from oracle import slam_oracle as o
 
-    gates = {"cx": [o.cx_matrix()], "sqiswap": [o.riswap_matrix(0.5)], "iswap+b": [o.riswap_matrix(1.0), o.berkeley_matrix()]}[gname]
+    if gname == "cgsweep":
+        gates = [sweep_gate(SWEEP_CPU_BASIS)]  # one representative basis of the sweep (sqrt(iSWAP)-like strength)
+    else:
+        gates = {"cx": [o.cx_matrix()], "sqiswap": [o.riswap_matrix(0.5)], "iswap+b": [o.riswap_matrix(1.0), o.berkeley_matrix()]}[gname]
     target = o.haar_unitary(seed0 + idx) if host_targets else o.haar_philox_port(seed0, idx)
     t0 = time.perf_counter()
     best, _, k, stats = o.run_reference(
@@ -118,7 +122,8 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
         "unit": "decompositions/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n_sample} targets of the same workload (SciPy BFGS + finite differences on the NumPy oracle, "
+        "sample": f"{n_sample} targets of the same workload{' (sweep basis %d only)' % SWEEP_CPU_BASIS if gname == 'cgsweep' else ''} "
+        f"(SciPy BFGS + finite differences on the NumPy oracle, "
         f"sequential restarts with early break), {cpu_s:.1f} core-seconds, {wall:.1f} s wall",
         "per_core": ok / cpu_s if cpu_s > 0 else None,
         "analytic_jac": {"value": ok_j / wall_j, "per_core": ok_j / cpu_sj if cpu_sj > 0 else None,
@@ -128,8 +133,8 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
 
 def traffic_per_launch(workload: str):
     """HBM bytes per optimizer-kernel launch (mean over the three spans) from the committed PMC passes
-    (profiles/r1c_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE); None for workloads that were not profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1c_traffic.json")
+    (profiles/r1d_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE); None for workloads that were not profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_traffic.json")
     try:
         t = json.load(open(path))[workload]
     except (OSError, KeyError, ValueError):
