@@ -5,7 +5,6 @@ import pytest
 from scipy import stats
 
 from oracle import slam_oracle as o
-from slam_decomposition_amd import _ffi
 from slam_decomposition_amd.sampler import DeviceHaarBatch
 
 pytestmark = pytest.mark.gpu

@@ -1,7 +1,7 @@
 """Dev tool: per-span kernel time of one resident batch, best of several repeats (GPU)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+
 from slam_decomposition_amd import _ffi
 from bench import gate_table, make_targets, f_eval
 

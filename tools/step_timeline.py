@@ -1,7 +1,6 @@
 """Dev tool: wall-clock timeline of overlapped bench steps (per thread)."""
 import sys, os, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from slam_decomposition_amd import _ffi
 from bench import gate_table, make_targets
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8

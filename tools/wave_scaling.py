@@ -2,7 +2,7 @@
 same number of iterations (maxiter small, tolerances off), so there is no straggler tail."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+
 from slam_decomposition_amd import _ffi
 from bench import gate_table, make_targets, f_eval
 
