@@ -9,6 +9,8 @@ closed form the same answer comes from a few comparisons on (c1, c2, c3) (SURVEY
 
 * CX class (0.5, 0, 0): 0 gates for a local target, 1 for the CX class, 2 iff c3 = 0, otherwise 3
   (Shende-Bullock-Markov / Vidal-Dawson);
+* iSWAP class (0.5, 0.5, 0): the same thresholds -- two applications also span exactly the c3 = 0 face
+  (checked against the brute-force span loop on the GPU, tests/test_gpu_api.py);
 * sqrt(iSWAP) class (0.25, 0.25, 0): 2 iff |z| <= x - y in the folded chamber x >= y >= |z|, x <= 1/2 --
   the test of the reference's own ``riswapWeylDecomp``
   (src/slam/utils/transpiler_pass/weyl_decompose.py:343-387, arXiv:2105.06074) -- otherwise 3;
@@ -24,6 +26,7 @@ _TOL = 2e-8  # coordinates are rounded to 8 digits
 
 FAMILIES = {
     "cx": (0.5, 0.0, 0.0),
+    "iswap": (0.5, 0.5, 0.0),
     "sqiswap": (0.25, 0.25, 0.0),
     "b": (0.5, 0.25, 0.0),
 }
@@ -57,7 +60,7 @@ def minimal_span(target_coords, gate_coords) -> np.ndarray:
     x, y, z = c[:, 0], c[:, 1], c[:, 2]
     local = (np.abs(x) < _TOL) & (np.abs(y) < _TOL) & (np.abs(z) < _TOL)
     same = np.max(np.abs(np.abs(c) - np.array(FAMILIES[fam])), axis=1) < _TOL
-    if fam == "cx":
+    if fam in ("cx", "iswap"):
         k = np.where(np.abs(z) < _TOL, 2, 3)
     elif fam == "sqiswap":
         k = np.where(np.abs(z) <= x - y + _TOL, 2, 3)

@@ -248,7 +248,10 @@ def test_use_polytopes_analytic_span_rules_match_brute_force():
     special += [local() @ g @ local() for g in (o.cx_matrix(), o.riswap_matrix(0.5), o.berkeley_matrix())]
     targets = np.stack(haar + special)
     coords = c1c2c3_batch(targets)
-    for gate in (CXGate(), RiSwapGate(0.5), BerkeleyGate()):
+    special.append(local() @ o.riswap_matrix(1.0) @ local())
+    targets = np.stack(haar + special)
+    coords = c1c2c3_batch(targets)
+    for gate in (CXGate(), RiSwapGate(0.5), BerkeleyGate(), RiSwapGate(1.0)):
         brute = TemplateOptimizer(CircuitTemplate(base_gates=[gate], maximum_span_guess=3), BasicCost(),
                                   override_fail=True, training_restarts=16, seed=2)
         data_b = brute._approximate_batch(list(targets), log_index=False)
@@ -264,6 +267,6 @@ def test_use_polytopes_analytic_span_rules_match_brute_force():
         assert [d.cycles for d in data_p] == [int(k) for k in spans]
         assert all(d.success_label == 1 for d in data_p)
     with pytest.raises(NotImplementedError, match="analytic span rules"):
-        CircuitTemplate(base_gates=[RiSwapGate(1.0)], use_polytopes=True)
+        CircuitTemplate(base_gates=[RiSwapGate(0.3)], use_polytopes=True)
     with pytest.raises(ValueError):  # a local target needs 0 gates: build(0), basis.py:127-128
         TemplateOptimizer(CircuitTemplate(base_gates=[CXGate()], use_polytopes=True), BasicCost()).approximate_target_U(local())

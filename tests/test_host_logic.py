@@ -87,7 +87,7 @@ def test_circuit_template_structure():
     assert t.target_invariant(o.cx_matrix()) == (0.5, 0.0, 0.0)
     assert t.target_invariant(np.eye(8)) == (-1, -1, -1, -1)
     for kwargs in (dict(no_exterior_1q=True), dict(n_qubits=3), dict(edge_params=[[(1, 0)]]),
-                   dict(use_polytopes=True, base_gates=[RiSwapGate(1.0)]),  # no analytic rule for iSWAP
+                   dict(use_polytopes=True, base_gates=[RiSwapGate(0.3)]),  # no analytic rule for a generic XY gate
                    dict(use_polytopes=True, base_gates=[RiSwapGate(0.5), CXGate()])):
         with pytest.raises(NotImplementedError):
             CircuitTemplate(**kwargs)
@@ -104,6 +104,7 @@ def test_span_rules_and_polytope_mode_ranges():
     # sqrt(iSWAP): 2 iff |z| <= x - y in the folded chamber (weyl_decompose.py:348); (0.7, 0.2, 0.05) folds to (0.3, 0.2, -0.05)
     assert span_rules.minimal_span(coords, sq).tolist() == [0, 0, 2, 1, 2, 2, 3, 2, 2, 3]
     assert span_rules.minimal_span(coords, b).tolist() == [0, 0, 2, 2, 1, 2, 2, 2, 2, 2]
+    assert span_rules.minimal_span(coords, (0.5, 0.5, 0.0)).tolist() == [0, 0, 2, 2, 2, 2, 3, 3, 3, 3]  # iSWAP
     assert span_rules.family_of((0.75, 0.25, 0.0)) == "sqiswap"  # mirror image of (0.25, 0.25, 0)
     t = CircuitTemplate(base_gates=[RiSwapGate(0.5)], use_polytopes=True)
     assert t.spanning_range is None and t.use_polytopes  # basis.py:82-86
