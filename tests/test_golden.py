@@ -43,6 +43,19 @@ def test_hip_matches_golden(hip_ctx):
             assert np.max(np.abs(grad[0] - GOLD[f"grad_{name}_{k}"])) < 1e-12
             W, _ = hip_ctx.eval_unitary([0] * k, x, tof)
             assert np.max(np.abs(W[0] - GOLD[f"W_{name}_{k}"])) < 1e-13
+    # golden Weyl coordinates of the targets and of the golden template unitaries: device kernel = fixture
+    from slam_decomposition_amd.weyl import c1c2c3 as host_c1c2c3
+
+    assert np.array_equal(hip_ctx.c1c2c3(GOLD["targets"]), GOLD["target_c1c2c3"])
+    assert np.array_equal(hip_ctx.targets_c1c2c3(), GOLD["target_c1c2c3"])
+    for name in NAMES:
+        hip_ctx.set_gates(GOLD[f"gate_{name}"][None])
+        for k in (1, 2, 3):
+            c = hip_ctx.eval_c1c2c3([0] * k, GOLD[f"x_{name}_{k}"][None], ndigits=-1)[0]
+            ref = np.array(host_c1c2c3(GOLD[f"W_{name}_{k}"], ndigits=15))  # LAPACK-based host version (weyl.py)
+            if ref[2] < 1e-9:  # c3 = 0 face (e.g. every k = 1 template): (c1, c2, 0) == (1 - c1, c2, 0)
+                c[0], ref[0] = min(c[0], 1 - c[0]), min(ref[0], 1 - ref[0])
+            assert np.max(np.abs(c - ref)) < 1e-12
     # converged (loss, best_cycles) per target, 6 restarts seeded like the golden run
     for name in ("cx", "sqiswap", "b"):
         hip_ctx.set_gates(GOLD[f"gate_{name}"][None])
