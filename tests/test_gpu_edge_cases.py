@@ -124,3 +124,61 @@ def test_stats_accounting(hip_ctx):
     st = hip_ctx.stats()
     assert st["evals"][2] == int(out["item_evals"].sum()) and st["items"][2] == 32
     assert st["kernel_launches"] == 1 and st["kernel_ms"] > 0 and st["kernel_ms_span"][2] == st["kernel_ms"]
+
+
+def test_concurrent_contexts_give_the_single_context_results():
+    """Six host threads, one context / stream each, the same batch at the same time (the bench's mode of
+    operation): without early exit every thread must return bit for bit what a lone context returns."""
+    import threading
+
+    targets = o.haar_batch(200, seed0=77)
+    prm = _prm(restarts=8, flags=0, seed=9)
+
+    def run(ctx, items_per_quad=0):
+        ctx.set_targets(targets)
+        ctx.set_gates(SQ[None])
+        p = _ffi.OptParams(restarts=8, flags=0, seed=9, items_per_quad=items_per_quad)
+        return ctx.decompose(1, 3, SEQS, p, 1e-10)
+
+    lone = run(_ffi.Context(0))
+    out = [None] * 6
+    ctxs = [_ffi.Context(0) for _ in range(6)]
+
+    def work(i):
+        for _ in range(3):
+            out[i] = run(ctxs[i], items_per_quad=i % 4)  # launch shaping does not change results either
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for res in out:
+        for u, v in zip(lone, res):
+            assert np.array_equal(u, v)
+    for c in ctxs:
+        c.close()
+
+
+def test_decompose_list_and_weyl_error_paths(hip_ctx):
+    targets = o.haar_batch(12, seed0=5)
+    hip_ctx.set_targets(targets)
+    hip_ctx.set_gates(SQ[None])
+    prm = _prm(restarts=8)
+    # an explicit list in arbitrary order == the same targets through the window call
+    whole = hip_ctx.decompose(1, 3, SEQS, prm, 1e-10)
+    hip_ctx.decompose_list([7, 2, 9], 1, 3, SEQS, prm, 1e-10)
+    bl, bx, bc = hip_ctx.fetch_results_range(3, 0, 12)
+    for t in (7, 2, 9):
+        assert bc[t] == whole[2][t] and bl[t] < 1e-10
+    with pytest.raises(_ffi.SlamHipError, match="outside"):
+        hip_ctx.decompose_list([0, 12], 1, 3, SEQS, prm, 1e-10)
+    with pytest.raises(_ffi.SlamHipError, match="empty target list"):
+        hip_ctx.decompose_list([], 1, 3, SEQS, prm, 1e-10)
+    with pytest.raises(_ffi.SlamHipError, match="k_layout"):
+        hip_ctx.decompose_list([1], 2, 2, [[0, 0]], prm, 1e-10, k_layout=1)
+    # non-finite input does not hang the Jacobi sweeps; the answer is non-finite or arbitrary, not an error
+    bad = targets[:2].copy()
+    bad[0, 0, 0] = np.nan
+    c = hip_ctx.c1c2c3(bad)
+    assert c.shape == (2, 3) and np.all(np.isfinite(c[1]))
+    with pytest.raises(ValueError):
+        hip_ctx.c1c2c3(np.zeros((3, 4, 3), dtype=complex))
