@@ -214,6 +214,12 @@ int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best
 int slam_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max,
                          const int32_t* gate_seqs, const slam_opt_params* params,
                          double success_threshold);
+/* slam_decompose_range followed by slam_fetch_results_range(ctx, k_max, first, count, ...) with one host wait
+ * instead of two: the result copies are enqueued behind the last stage. */
+int slam_decompose_range_fetch(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                               const slam_opt_params* params, double success_threshold, double* best_loss, double* best_x,
+                               int32_t* best_cycles);
+
 /* The same for an explicit list of resident-target indices (e.g. the targets a span predictor assigns to one
  * template size: CircuitTemplate.get_spanning_range with use_polytopes, src/slam/basis.py:95-100).  Results land
  * in the per-target resident arrays like those of slam_decompose_range; fetch them with

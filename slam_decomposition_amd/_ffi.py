@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "slam_fetch_results",
     "slam_decompose_range",
     "slam_decompose_list",
+    "slam_decompose_range_fetch",
     "slam_fetch_results_range",
     "slam_set_cost",
     "slam_synchronize",
@@ -130,6 +131,8 @@ def load_library() -> C.CDLL:
     lib.slam_decompose_resident.argtypes = [P, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results.argtypes = [P, C.c_int, P, P, P]
     lib.slam_decompose_range.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
+    if hasattr(lib, "slam_decompose_range_fetch"):  # (absent from older A/B builds selected with SLAM_HIP_LIB)
+        lib.slam_decompose_range_fetch.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P, P]
     lib.slam_decompose_list.argtypes = [P, P, C.c_int64, C.c_int, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results_range.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, P, P]
     lib.slam_set_cost.argtypes = [P, C.c_int]
@@ -138,6 +141,8 @@ def load_library() -> C.CDLL:
     lib.slam_reset_stats.argtypes = [P]
     lib.slam_best_loss_device_ptr.argtypes = [P, C.POINTER(P), C.POINTER(C.c_int64)]
     for name in EXPORTED_SYMBOLS:
+        if "SLAM_HIP_LIB" in os.environ and not hasattr(lib, name):
+            continue  # an older A/B build: newer entry points are simply not used
         fn = getattr(lib, name)
         if name not in ("slam_last_error", "slam_version"):
             fn.restype = C.c_int
@@ -361,10 +366,16 @@ class Context:
 
     def decompose_range(self, first, count, k_min, k_max, gate_seqs, params: OptParams, success_threshold: float, fetch=True):
         flat = self._flat_gate_seqs(gate_seqs, k_min, k_max)
-        _check(self._lib.slam_decompose_range(self._h, int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params), float(success_threshold)))
-        if fetch:
-            return self.fetch_results_range(k_max, first, count)
-        return None
+        if not fetch or not hasattr(self._lib, "slam_decompose_range_fetch"):
+            _check(self._lib.slam_decompose_range(self._h, int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params), float(success_threshold)))
+            return self.fetch_results_range(k_max, first, count) if fetch else None
+        nmax = 6 * (k_max + 1)
+        best_loss = np.empty(count, dtype=np.float64)
+        best_x = np.zeros((count, nmax), dtype=np.float64)
+        best_cycles = np.empty(count, dtype=np.int32)
+        _check(self._lib.slam_decompose_range_fetch(self._h, int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params),
+                                                     float(success_threshold), _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
+        return best_loss, best_x, best_cycles
 
     def decompose_list(self, targets, k_min, k_max, gate_seqs, params: OptParams, success_threshold: float, k_layout: int = 0):
         """Span loop for an explicit list of resident-target indices (slam_decompose_list); results stay in the

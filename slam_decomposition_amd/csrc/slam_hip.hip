@@ -428,9 +428,64 @@ int ensure_results(slam_ctx* c, int k_max) {
     return SLAM_OK;
 }
 
+// Results of the window [first, first + count) on their way to the host: small windows go through pinned
+// staging (asynchronous copies, no spinning inside the runtime's pageable path), big ones straight into the
+// caller's arrays.  enqueue_fetch only enqueues; finish_fetch runs after the stream has drained.
+struct FetchReq {
+    double* best_loss;
+    double* best_x;
+    int32_t* best_cycles;
+    size_t b_loss = 0, b_x = 0, b_cyc = 0;
+    bool staged = false;
+};
+
+int enqueue_fetch(slam_ctx* ctx, int k_layout, int64_t first, int64_t count, FetchReq& fr) {
+    const int nmax = 6 * (k_layout + 1);
+    if (ctx->result_nmax != nmax || ctx->n_targets <= 0)
+        return fail(SLAM_ERR_STATE, "no resident results for k_max = %d", k_layout);
+    if (first < 0 || count < 0 || first + count > ctx->n_targets)
+        return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    const size_t N = (size_t)count;
+    const size_t o = (size_t)first;
+    fr.b_loss = N * sizeof(double);
+    fr.b_x = N * nmax * sizeof(double);
+    fr.b_cyc = N * sizeof(int32_t);
+    if (N == 0) return SLAM_OK;
+    const size_t need = fr.b_loss + fr.b_x + fr.b_cyc;
+    char* h = nullptr;
+    if (need <= (size_t)1 << 20) {
+        if (need > ctx->h_stage_cap) {
+            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr;
+            ctx->h_stage_cap = 0;
+            HIP_TRY(hipHostMalloc(&ctx->h_stage, need + need / 4, hipHostMallocDefault));
+            ctx->h_stage_cap = need + need / 4;
+        }
+        h = static_cast<char*>(ctx->h_stage);
+        fr.staged = true;
+    }
+    // (big windows: an extra host copy of tens of MB would cost more than the runtime's own staging)
+    if (fr.best_loss)
+        HIP_TRY(hipMemcpyAsync(h ? (void*)h : (void*)fr.best_loss, ctx->best_loss.as<double>() + o, fr.b_loss, hipMemcpyDeviceToHost, ctx->stream));
+    if (fr.best_x)
+        HIP_TRY(hipMemcpyAsync(h ? (void*)(h + fr.b_loss) : (void*)fr.best_x, ctx->best_x.as<double>() + o * nmax, fr.b_x, hipMemcpyDeviceToHost, ctx->stream));
+    if (fr.best_cycles)
+        HIP_TRY(hipMemcpyAsync(h ? (void*)(h + fr.b_loss + fr.b_x) : (void*)fr.best_cycles, ctx->best_cycles.as<int32_t>() + o, fr.b_cyc, hipMemcpyDeviceToHost, ctx->stream));
+    return SLAM_OK;
+}
+
+void finish_fetch(slam_ctx* ctx, const FetchReq& fr) {
+    if (!fr.staged) return;
+    const char* h = static_cast<const char*>(ctx->h_stage);
+    if (fr.best_loss) std::memcpy(fr.best_loss, h, fr.b_loss);
+    if (fr.best_x) std::memcpy(fr.best_x, h + fr.b_loss, fr.b_x);
+    if (fr.best_cycles) std::memcpy(fr.best_cycles, h + fr.b_loss + fr.b_x, fr.b_cyc);
+}
+
 // h_list != nullptr: the batch is the explicit list of resident-target indices h_list[0..count) (first ignored)
 int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
-                   const slam_opt_params* prm, double success_threshold, const int32_t* h_list = nullptr, int k_layout = 0) {
+                   const slam_opt_params* prm, double success_threshold, const int32_t* h_list = nullptr, int k_layout = 0,
+                   FetchReq* fetch = nullptr) {
     if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
@@ -499,9 +554,14 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
         }
     }
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    if (fetch) {  // the results ride on the same wait as the span loop
+        rc = enqueue_fetch(c, k_layout, h_list ? 0 : first, h_list ? c->n_targets : count, *fetch);
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemcpyAsync(c->h_ctl, c->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_done, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev_done));
+    if (fetch) finish_fetch(c, *fetch);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
     c->stats.total_ms = ms;
@@ -797,43 +857,21 @@ int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t co
                              double* best_x, int32_t* best_cycles) {
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const int nmax = 6 * (k_max + 1);
-    if (ctx->result_nmax != nmax || ctx->n_targets <= 0)
-        return fail(SLAM_ERR_STATE, "no resident results for k_max = %d", k_max);
-    if (first < 0 || count < 0 || first + count > ctx->n_targets)
-        return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
-    const size_t N = (size_t)count;
-    const size_t o = (size_t)first;
-    if (N == 0) return SLAM_OK;
-    // device -> pinned staging (asynchronous), sleep on the blocking event, then plain host copies
-    const size_t b_loss = N * sizeof(double), b_x = N * nmax * sizeof(double), b_cyc = N * sizeof(int32_t);
-    const size_t need = b_loss + b_x + b_cyc;
-    if (need > (size_t)1 << 20) {
-        // big windows: straight into the caller's arrays (an extra host copy of tens of MB would cost more
-        // than the runtime's own staging)
-        if (best_loss) HIP_TRY(hipMemcpyAsync(best_loss, ctx->best_loss.as<double>() + o, b_loss, hipMemcpyDeviceToHost, ctx->stream));
-        if (best_x) HIP_TRY(hipMemcpyAsync(best_x, ctx->best_x.as<double>() + o * nmax, b_x, hipMemcpyDeviceToHost, ctx->stream));
-        if (best_cycles) HIP_TRY(hipMemcpyAsync(best_cycles, ctx->best_cycles.as<int32_t>() + o, b_cyc, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        return SLAM_OK;
-    }
-    if (need > ctx->h_stage_cap) {
-        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-        ctx->h_stage = nullptr;
-        ctx->h_stage_cap = 0;
-        HIP_TRY(hipHostMalloc(&ctx->h_stage, need + need / 4, hipHostMallocDefault));
-        ctx->h_stage_cap = need + need / 4;
-    }
-    char* h = static_cast<char*>(ctx->h_stage);
-    if (best_loss) HIP_TRY(hipMemcpyAsync(h, ctx->best_loss.as<double>() + o, b_loss, hipMemcpyDeviceToHost, ctx->stream));
-    if (best_x) HIP_TRY(hipMemcpyAsync(h + b_loss, ctx->best_x.as<double>() + o * nmax, b_x, hipMemcpyDeviceToHost, ctx->stream));
-    if (best_cycles) HIP_TRY(hipMemcpyAsync(h + b_loss + b_x, ctx->best_cycles.as<int32_t>() + o, b_cyc, hipMemcpyDeviceToHost, ctx->stream));
+    FetchReq fr{best_loss, best_x, best_cycles};
+    int rc = enqueue_fetch(ctx, k_max, first, count, fr);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_done, ctx->stream));
     HIP_TRY(hipEventSynchronize(ctx->ev_done));
-    if (best_loss) std::memcpy(best_loss, h, b_loss);
-    if (best_x) std::memcpy(best_x, h + b_loss, b_x);
-    if (best_cycles) std::memcpy(best_cycles, h + b_loss + b_x, b_cyc);
+    finish_fetch(ctx, fr);
     return SLAM_OK;
+}
+
+int slam_decompose_range_fetch(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                               const slam_opt_params* params, double success_threshold, double* best_loss, double* best_x,
+                               int32_t* best_cycles) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    FetchReq fr{best_loss, best_x, best_cycles};
+    return decompose_impl(ctx, first, count, k_min, k_max, gate_seqs, params, success_threshold, nullptr, 0, &fr);
 }
 
 int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best_x, int32_t* best_cycles) {
