@@ -286,14 +286,18 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         const bool active = live;
         if (active) ++nev;
         const bool finite = isfinite(ft);
+        // a non-finite trial point is never accepted; its gradient is zeroed here once so that everything below
+        // stays finite without per-element guards (0 * NaN would otherwise leak into H through w and v)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) gt[a] = finite ? gt[a] : 0.0;
         const bool armijo = finite && (ft <= f + kArmijoC1 * alpha * gp);
         const bool acc = active && (fresh ? finite : armijo);
         const bool step = acc && !fresh;  // a real quasi-Newton step (not the initial evaluation)
 
-        // ---- 3. quasi-Newton update.  s = am p and y = ym (g' - g) are formed on the fly; for quads
-        //         that do not step, am = ym = 0 and (by select) w = v = 0, so H is left unchanged.
+        // ---- 3. quasi-Newton update.  s = am p and y = g' - g are formed on the fly; for quads that do not
+        //         step, am = 0 and curv = false, hence rho = cf = 0 and w = v = 0: H is left unchanged (their
+        //         y-dependent scalars are finite garbage that is multiplied by zero).
         const double am = step ? alpha : 0.0;
-        const double ym = step ? 1.0 : 0.0;
         double qv[NA];
         __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: interleaving them only adds live registers
         h_matvec<NA>(H, gt, xq32, q, qv);
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             const double sa = am * p[a];
-            const double ya = ym * (gt[a] - g[a]);
+            const double ya = gt[a] - g[a];
             sy = fma(sa, ya, sy);
             yy = fma(ya, ya, yy);
             ss = fma(sa, sa, ss);
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         for (int a = 0; a < NA; ++a) {
             qv[a] *= fac;
             const double ua = fma(fac, p[a], qv[a]);
-            yu = fma(ym * (gt[a] - g[a]), ua, yu);
+            yu = fma(gt[a] - g[a], ua, yu);
         }
         yu = quad_sum(yu);
         const double rho = curv ? fast_rcp(sy) : 0.0;
@@ -344,9 +348,8 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             for (int a = 0; a < NA; ++a) {
                 const double sa = am * p[a];
                 const double ua = fma(fac, p[a], qv[a]);
-                // selects, not products with rho = 0: u may be non-finite after a rejected trial point
-                const double wa = curv ? (cf * sa - rho * ua) : 0.0;
-                const double va = curv ? (-rho * ua) : 0.0;
+                const double wa = cf * sa - rho * ua;  // rho = cf = 0 unless curv: w = v = 0, H unchanged
+                const double va = -rho * ua;
                 s32[a] = (float)sa;
                 w32[a] = (float)wa;
                 v32[a] = (float)va;
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             for (int a = 0; a < NA; ++a) {
                 const double sa = am * p[a];
                 const double ua = fma(fac, p[a], qv[a]);
-                const double va = curv ? (-rho * ua) : 0.0;
+                const double va = -rho * ua;
                 x[a] += sa;
                 g[a] = gt[a];
                 p[a] = -(qv[a] + sa * wg + va * sg);
