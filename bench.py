@@ -3,12 +3,18 @@
 
 One "step" = one pass of the hot path (TemplateOptimizer._run span loop k = 1..3, R restarts per
 span, BasicCost + analytic gradient + in-kernel BFGS) over one batch of synthetic Haar targets.
-Default workload = BASELINE.json configs[1]: CNOT basis, span <= 3, 1024 targets x 16 restarts,
-fp64, per GPU (weak scaling: every rank gets its own 1024-target batches).  All target batches
-are uploaded before the timed region; each step ends with the per-target results on the host.
-Several batches are kept in flight per GPU (host threads, one context + HIP stream each) so that
-the straggler tail of one batch overlaps the next.  For N > 1 the job ends with ONE collective:
-the min-all-reduce of the best-loss vector over RCCL.
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration: sqrt(iSWAP)
+basis, span <= 3, 65 536 targets x 32 restarts, fp64, per GPU (weak scaling: every rank gets its
+own batches).  All target batches are resident in HBM before the timed region; each step ends with
+the per-target results on the host.  Several batches are kept in flight per GPU (host threads, one
+context + HIP stream each) so that the straggler tail of one batch overlaps the next.
+
+N > 1: one process per GPU.  `python bench.py --gpus N` launches its N ranks itself (fresh
+processes, before anything touches a GPU); under `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N` it is one of the ranks (RANK / LOCAL_RANK / WORLD_SIZE from the environment).
+Either way the ranks meet through libslamhip's RCCL communicator (slam_comm_*, no torch): barrier on
+both sides of the timed region, MAX over ranks of the time, and the job's ONE collective -- the
+final min-all-reduce of the best-loss vector over xGMI.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
 """
@@ -17,7 +23,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -31,11 +40,18 @@ if ROOT not in sys.path:
 
 PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
 SUCCESS_LOSS = 1e-8  # BASELINE.json metric: loss < 1e-8
+TARGET_SEED0 = 20260000
+OPT_SEED = 20261003
 
 
 def f_eval(k: int) -> int:
-    """Algorithmic flops of one fused loss+gradient evaluation."""
+    """Algorithmic flops of one fused loss+gradient evaluation: dense accounting."""
     return 3036 * k + 1247
+
+
+def f_forward(k: int) -> int:
+    """Forward chain + loss only (what a rejected line-search trial is worth)."""
+    return 1080 * k + 251
 
 
 WORKLOADS = {
@@ -75,13 +91,15 @@ def gate_table(name: str) -> np.ndarray:
 
 
 def make_targets(n: int, seed0: int) -> np.ndarray:
-    """T_i = unitary_group.rvs(4, default_rng(seed0 + i)); generated with a small
-    process pool because SciPy draws them one at a time."""
+    """T_i = unitary_group.rvs(4, default_rng(seed0 + i))."""
     from slam_decomposition_amd.sampler import random_unitary
 
     return np.stack([random_unitary(4, seed=seed0 + i) for i in range(n)])
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle; allowed here and only here)
+# ------------------------------------------------------------------------------------------------
 def _cpu_one(args):
     """One target through the reference path on the CPU oracle (SciPy BFGS, finite differences:
     src/slam/optimizer.py:270-278), restarts sequential with early break like the reference."""
@@ -104,8 +122,11 @@ def _cpu_one(args):
 def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool):
     import multiprocessing as mp
 
-    cores = min(os.cpu_count() or 1, 16)
+    cores = min(os.cpu_count() or 1, 32)
+    if n_sample <= 0:
+        n_sample = 4 * cores  # every core busy for several targets: `value` is a whole-box number
     with mp.get_context("spawn").Pool(cores) as pool:
+        pool.map(abs, range(cores))  # workers up (interpreter + NumPy/SciPy import) before the clock starts
         t0 = time.perf_counter()
         res = pool.map(_cpu_one, [(seed0, i, gname, restarts, seed, host_targets, False) for i in range(n_sample)], chunksize=1)
         wall = time.perf_counter() - t0
@@ -124,7 +145,7 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
         "kind": "port",
         "sample": f"{n_sample} targets of the same workload{' (sweep basis %d only)' % SWEEP_CPU_BASIS if gname == 'cgsweep' else ''} "
         f"(SciPy BFGS + finite differences on the NumPy oracle, "
-        f"sequential restarts with early break), {cpu_s:.1f} core-seconds, {wall:.1f} s wall",
+        f"sequential restarts with early break, one target per task over {cores} processes), {cpu_s:.1f} core-seconds, {wall:.1f} s wall",
         "per_core": ok / cpu_s if cpu_s > 0 else None,
         "analytic_jac": {"value": ok_j / wall_j, "per_core": ok_j / cpu_sj if cpu_sj > 0 else None,
                          "note": "same sample and loop, SciPy BFGS with the oracle's analytic gradient"},
@@ -133,97 +154,90 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
 
 def traffic_per_launch(workload: str):
     """HBM bytes per optimizer-kernel launch (mean over the three spans) from the committed PMC passes
-    (profiles/r1d_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE); None for workloads that were not profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1d_traffic.json")
-    try:
-        t = json.load(open(path))[workload]
-    except (OSError, KeyError, ValueError):
-        return None
-    return sum(t.values()) / len(t)
+    (profiles/r2_traffic.json, else r1d_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
+    None for workloads that were not profiled."""
+    for name in ("r2_traffic.json", "r1d_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload]
+            return sum(t.values()) / len(t)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 320 for cfg2, 9 for the big workloads)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 32 for cfg2, 3 otherwise)")
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--targets", type=int, default=None, help="override targets per step per GPU")
-    ap.add_argument("--restarts", type=int, default=None)
-    ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 3 otherwise")
-    ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "-1")),
-                    help="launch shaping (slam_opt_params.items_per_quad); 0 = library default (one item per quad, lowest "
-                         "latency); default here: 3 for small batches with several in flight (+4.7 %% measured), else 0")
-    ap.add_argument("--host-targets", action="store_true", help="draw the Haar targets with SciPy on the host instead of on the device")
-    ap.add_argument("--span-rules", action="store_true",
-                    help="polytope mode (CircuitTemplate(use_polytopes=True)): each target is optimised only at the template "
-                         "size the analytic span rules assign to it (device c1c2c3 + span_rules.py) instead of spans 1..3")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8)
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    """Start the N ranks as fresh processes (nothing in this process has touched the GPU: no exec-after-HIP-init,
+    no fork of an initialised runtime) and return the worst exit code.  Rank 0 prints the JSON line."""
+    with tempfile.TemporaryDirectory(prefix="slam_bench_") as tmp:
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SLAM_COMM_FILE=os.path.join(tmp, "rccl.id"),
+                       SLAM_COMM_DIR=os.path.join(tmp, "filecomm"), SLAM_BENCH_RANK_PROCESS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = 0
+        try:
+            for p in procs:
+                code = p.wait()
+                rc = rc or code
+        finally:
+            for p in procs:  # a rank that died leaves the others waiting in the rendezvous: end them by pid
+                if p.poll() is None:
+                    p.terminate()
+        return rc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
 
-        # "nccl" is RCCL over xGMI; SLAM_BENCH_BACKEND=gloo rehearses the N > 1 path on a one-GPU box
-        backend = os.environ.get("SLAM_BENCH_BACKEND", "nccl")
-        ndev = torch.cuda.device_count()
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            tdev = "cuda"
-        else:
-            local_rank = local_rank % max(1, ndev)
-            dist.init_process_group(backend)
-            tdev = "cpu"
+def make_comm(rank: int, world: int, local_rank: int):
+    from slam_decomposition_amd import parallel
 
+    if world == 1 and not os.environ.get("SLAM_BENCH_RANK_PROCESS"):
+        return parallel.LocalComm()
+    if os.environ.get("SLAM_BENCH_COMM", "rccl") == "file":
+        # rehearsal of the N > 1 path on a one-GPU box (RCCL refuses several ranks on one device)
+        return parallel.FileComm(rank, world, os.environ.get("SLAM_COMM_DIR") or parallel.rendezvous_path() + ".d")
+    return parallel.RcclComm(local_rank, rank, world, parallel.rendezvous_path())
+
+
+# ------------------------------------------------------------------------------------------------
+def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool):
+    """Run `warmup` untimed + `steps` timed steps of one workload; returns the dict of measurements."""
     from slam_decomposition_amd import _ffi
 
-    gname, n_per_step, restarts, desc = WORKLOADS[args.workload]
-    if args.targets:
+    gname, n_per_step, restarts, desc = WORKLOADS[workload]
+    if main and args.targets:
         n_per_step = args.targets
-    if args.restarts:
+    if main and args.restarts:
         restarts = args.restarts
     small = n_per_step * restarts <= 65536
-    steps = args.steps if args.steps is not None else (320 if small else 9)
-    warmup = args.warmup if args.warmup is not None else (32 if small else 3)
     total_steps = steps + warmup
-    seed0 = 20260000 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
-    opt_seed = 20261003
+    seed0 = TARGET_SEED0 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
+    ndev = _ffi.device_count()
+    device = local_rank % max(1, ndev) if os.environ.get("SLAM_BENCH_COMM") == "file" else local_rank
 
-    n_streams = args.streams if args.streams else (16 if n_per_step * restarts <= 65536 else 3)
+    n_streams = n_streams_arg if n_streams_arg else (16 if small else 3)
     n_streams = max(1, min(n_streams, steps))
-    ctxs = [_ffi.Context(local_rank) for _ in range(n_streams)]
-    ctx = ctxs[0]
-    dev_name, cus, clock_khz = ctx.device_info()
+    ctxs = [_ffi.Context(device) for _ in range(n_streams)]
+    dev_name, cus, _ = ctxs[0].device_info()
     table = gate_table(gname)
+    sweep = gname == "cgsweep"
+    host_targets = main and args.host_targets
+    span_rules_mode = main and args.span_rules
     # every batch resident in HBM before the timed region: Haar targets generated in place by the device
     # sampler (slam_sample_haar; --host-targets: SciPy's sampler on the host, ~55 us per target, then uploaded)
-    targets = make_targets(total_steps * n_per_step, seed0) if args.host_targets else None
-    sweep = gname == "cgsweep"
     n_resident = n_per_step if sweep else total_steps * n_per_step  # the sweep's targets are shared by all bases
-    if sweep and args.host_targets:
-        targets = targets[:n_per_step]
+    targets = make_targets(n_resident, seed0 if not sweep else TARGET_SEED0) if host_targets else None
     for c in ctxs:
         c.set_gates(table)
-        if args.host_targets:
+        if host_targets:
             c.set_targets(targets)
         else:
-            c.sample_haar(seed0 if not sweep else 20260000, n_resident)
+            c.sample_haar(seed0 if not sweep else TARGET_SEED0, n_resident)
     gate_seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
-    ipq = args.items_per_quad if args.items_per_quad >= 0 else (3 if (small and n_streams > 1) else 0)
-    prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=opt_seed, flags=_ffi.FLAG_EARLY_EXIT,
-                          items_per_quad=ipq)
+    ipq = args.items_per_quad if (main and args.items_per_quad >= 0) else (3 if (small and n_streams > 1) else 0)
+    flags = _ffi.FLAG_EARLY_EXIT | (0 if args.fast_exit else _ffi.FLAG_ORDERED)
+    prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=flags, items_per_quad=ipq)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
 
     def basis_of(s: int) -> int:
@@ -231,7 +245,7 @@ def main():
         return (s % SWEEP_BASES_PER_GPU) * 8 + rank % 8
 
     gate_coords = None
-    if args.span_rules:
+    if span_rules_mode:
         from slam_decomposition_amd import span_rules
         from slam_decomposition_amd.weyl import c1c2c3 as host_c1c2c3
 
@@ -241,15 +255,20 @@ def main():
         span_rules.family_of(gate_coords)
 
     def one_step(s: int, c):
-        if args.span_rules:
+        if span_rules_mode:
             first = s * n_per_step
             spans = span_rules.minimal_span(c.targets_c1c2c3(first, n_per_step), gate_coords)
+            # targets that need no 2Q gate (span 0) are never optimised: their slots read (+inf, -1) from the library;
+            # a local target is solved by definition
             for k in np.unique(spans):
                 k = int(k)
                 if k < 1:
-                    continue  # local targets need no 2Q gate
+                    continue
                 c.decompose_list(first + np.nonzero(spans == k)[0], k, k, [gate_seqs[k - 1]], prm, threshold, k_layout=3)
             best_loss, best_x, best_cycles = c.fetch_results_range(3, first, n_per_step)
+            local = spans < 1
+            best_loss[local] = 0.0
+            best_cycles[local] = 0
             return best_loss, best_cycles
         if sweep:
             c.set_gates(np.stack([sweep_gate(basis_of(s))]))
@@ -259,16 +278,17 @@ def main():
         return best_loss, best_cycles
 
     def sync():
+        # barrier + device synchronisation on both sides of the timed region (all streams of this rank drained,
+        # then all ranks arrived, then drained again)
         for c in ctxs:
             c.synchronize()
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        comm.barrier()
+        for c in ctxs:
+            c.synchronize()
 
-    import threading
+    resident_merge = world > 1 and hasattr(comm, "raw") and not sweep and not span_rules_mode
 
-    def run_steps(step_ids, results):
+    def run_steps(step_ids, results, first_step):
         # steps are dealt round-robin to n_streams host threads, each with its own context / HIP stream,
         # so the tail of one batch (a stage lasts as long as its slowest work item) overlaps the next batch
         def worker(w):
@@ -287,11 +307,18 @@ def main():
             # the job's one collective: final best-loss all-reduce (min) over RCCL / xGMI.  Every rank
             # contributes +inf outside its shard and ends with the whole job's per-target losses.
             n_loc = len(step_ids) * n_per_step
-            merged = torch.full((world * n_loc,), float("inf"), dtype=torch.float64, device=tdev)
-            mine = np.concatenate([results[s][0] for s in step_ids])
-            merged[rank * n_loc : (rank + 1) * n_loc] = torch.from_numpy(mine).to(tdev)
-            dist.all_reduce(merged, op=dist.ReduceOp.MIN)
-            results["merged_solved"] = int((merged < SUCCESS_LOSS).sum().item())
+            if resident_merge:
+                # device to device: each context's resident best_loss windows -> this rank's slice of the job vector
+                comm.raw.merge_begin(world * n_loc)
+                for w in range(n_streams):
+                    for s in step_ids[w::n_streams]:
+                        comm.raw.merge_add(ctxs[w], s * n_per_step, n_per_step, rank * n_loc + (s - first_step) * n_per_step)
+                results["merged_solved"], _ = comm.raw.allreduce_min_merged(SUCCESS_LOSS)
+            else:
+                merged = np.full(world * n_loc, np.inf)
+                merged[rank * n_loc : (rank + 1) * n_loc] = np.concatenate([results[s][0] for s in step_ids])
+                comm.allreduce_min(merged)
+                results["merged_solved"] = int((merged < SUCCESS_LOSS).sum())
 
     # set-up, not a step: every context runs one batch once so that its device buffers exist and its
     # kernels are loaded (with 8 contexts, W < 8 warm-up steps would leave some of them cold)
@@ -302,18 +329,20 @@ def main():
         for t in prime:
             t.join()
     res = {}
-    run_steps(list(range(warmup)), res)
+    if warmup:
+        run_steps(list(range(warmup)), res, 0)
     sync()
     for c in ctxs:
         c.reset_stats()
+    res = {}
+    t0 = time.perf_counter()
+    run_steps(list(range(warmup, total_steps)), res, warmup)
+    sync()
+    elapsed = time.perf_counter() - t0
+
     solved = 0
     cyc_hist = np.zeros(4, dtype=np.int64)
     worst = 0.0
-    res = {}
-    t0 = time.perf_counter()
-    run_steps(list(range(warmup, total_steps)), res)
-    sync()
-    elapsed = time.perf_counter() - t0
     for s in range(warmup, total_steps):
         bl, bc = res[s]
         ok = bl < SUCCESS_LOSS
@@ -331,90 +360,209 @@ def main():
             bl, bc = res[s]
             ok = bl < SUCCESS_LOSS
             per_basis[b] = {"solved_fraction": float(ok.mean()), "mean_cycles": float(bc[ok].mean()) if ok.any() else None}
-    sts = [c.stats() for c in ctxs]
-    st = {
-        "kernel_ms": sum(x["kernel_ms"] for x in sts),
-        "kernel_launches": sum(x["kernel_launches"] for x in sts),
-        "evals": [sum(x["evals"][k] for x in sts) for k in range(6)],
-        "items": [sum(x["items"][k] for x in sts) for k in range(6)],
-    }
-    streams_used = n_streams
 
+    def sum_stats():
+        sts = [c.stats() for c in ctxs]
+        out = {"kernel_ms": sum(x["kernel_ms"] for x in sts), "kernel_launches": sum(x["kernel_launches"] for x in sts)}
+        for key in ("evals", "items", "evals_accepted", "evals_preempted", "kernel_ms_span", "wave_rounds"):
+            out[key] = [sum(x[key][k] for x in sts) for k in range(6)]
+        return out
+
+    st = sum_stats()
+
+    # max over ranks of the time; solved targets counted on the all-reduced vector (same on every rank)
+    tt = np.array([elapsed])
+    comm.allreduce_max(tt)
+    elapsed = float(tt[0])
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        solved_all = res["merged_solved"]  # counted on the all-reduced loss vector (same on every rank)
-        cnt = torch.tensor([solved], dtype=torch.float64, device=tdev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        assert int(cnt.item()) == solved_all, "merged best-loss vector disagrees with the per-rank counts"
+        solved_all = res["merged_solved"]
+        cnt = np.array([float(solved)])
+        comm.allreduce_sum(cnt)
+        assert int(cnt[0]) == solved_all, "merged best-loss vector disagrees with the per-rank counts"
     else:
         solved_all = solved
 
+    # per-span pass, ONE batch in flight: launches do not overlap, so every frac below is evals x F_eval(k) / the HIP
+    # events around that launch -- the figure `rocprofv3 --kernel-trace --stats` reports for the same launches
+    # (profiles/r2_*_single_stream_kernel_stats.csv).  Not part of `value`.
+    per_span = None
+    if main and rank == 0 and not span_rules_mode and args.per_span_steps > 0:
+        c = ctxs[0]
+        c.reset_stats()
+        for s in range(min(args.per_span_steps, total_steps)):
+            one_step(s, c)
+        ps = c.stats()
+        per_span = {}
+        for k in (1, 2, 3):
+            ms = ps["kernel_ms_span"][k]
+            n_launch = args.per_span_steps if ps["items"][k] else 0
+            if not n_launch or ms <= 0:
+                continue
+            per_span[str(k)] = {
+                "launches": n_launch,
+                "evals_per_launch": ps["evals"][k] / n_launch,
+                "hip_event_ms": ms / n_launch,
+                "achieved": ps["evals"][k] * f_eval(k) / (ms * 1e-3) / 1e12,
+                "frac": ps["evals"][k] * f_eval(k) / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "quad_occupancy": ps["evals"][k] / 16 / max(1, ps["wave_rounds"][k]),
+            }
+        tot_ms = sum(ps["kernel_ms_span"][k] for k in (1, 2, 3))
+        tot_fl = sum(ps["evals"][k] * f_eval(k) for k in (1, 2, 3))
+        per_span["all"] = {"hip_event_ms_per_step": tot_ms / args.per_span_steps,
+                           "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if tot_ms > 0 else None}
+
+    for c in ctxs:
+        c.close()
+
+    flops = sum(st["evals"][k] * f_eval(k) for k in (1, 2, 3))
+    rejected = [st["evals"][k] - st["evals_accepted"][k] - st["evals_preempted"][k] for k in range(6)]
+    flops_accepted = sum(st["evals_accepted"][k] * f_eval(k) for k in (1, 2, 3))
+    flops_strict = flops_accepted + sum(rejected[k] * f_forward(k) for k in (1, 2, 3))
+    # one batch in flight: launches do not overlap, achieved = flops / sum of HIP-event launch durations.
+    # several batches in flight: launches of different streams share the chip and their event
+    # durations overlap, so the denominator is the wall time of the timed region instead.
+    kernel_s = st["kernel_ms"] * 1e-3 if n_streams == 1 else elapsed
+    achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
+    return {
+        "desc": desc, "gname": gname, "n_per_step": n_per_step, "restarts": restarts, "threshold": threshold, "sweep": sweep,
+        "n_streams": n_streams, "ipq": ipq, "dev_name": dev_name, "cus": cus, "elapsed": elapsed, "solved_all": solved_all,
+        "cyc_hist": cyc_hist, "worst": worst, "per_basis": per_basis, "st": st, "achieved": achieved, "kernel_s": kernel_s,
+        "rejected": rejected, "flops_accepted": flops_accepted, "flops_strict": flops_strict, "per_span": per_span,
+        "resident_merge": resident_merge,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 320 for cfg2-sized batches)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 5; 32 for cfg2-sized batches)")
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS),
+                    help="cfg3 = BASELINE configs[2] (default: the largest single-GPU configuration); cfg2 = configs[1]; "
+                         "cfg4 / cfg5 = one GPU's shard of configs[3] / configs[4] (targets / bases sharded over --gpus ranks)")
+    ap.add_argument("--targets", type=int, default=None, help="override targets per step per GPU")
+    ap.add_argument("--restarts", type=int, default=None)
+    ap.add_argument("--streams", type=int, default=None,
+                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 3 otherwise")
+    ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "-1")),
+                    help="launch shaping (slam_opt_params.items_per_quad); 0 = library default (one item per quad, lowest "
+                         "latency); default here: 3 for small batches with several in flight (+4.7 %% measured), else 0")
+    ap.add_argument("--host-targets", action="store_true", help="draw the Haar targets with SciPy on the host instead of on the device")
+    ap.add_argument("--span-rules", action="store_true",
+                    help="polytope mode (CircuitTemplate(use_polytopes=True)): each target is optimised only at the template "
+                         "size the analytic span rules assign to it (device c1c2c3 + span_rules.py) instead of spans 1..3")
+    ap.add_argument("--fast-exit", action="store_true",
+                    help="drop SLAM_FLAG_ORDERED: the first restart to FINISH below stop_loss wins (timing-dependent winner) instead of "
+                         "the lowest-index successful restart (the reference's sequential semantics, bitwise reproducible; default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="targets of the CPU baseline sample (default 4 x host cores)")
+    ap.add_argument("--per-span-steps", type=int, default=3, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 measurement")
+    args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):
+        # plain `python bench.py --gpus N`: become the launcher (no GPU call has happened in this process)
+        raise SystemExit(launch_ranks(args.gpus))
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
+
+    _, n_default, r_default, _ = WORKLOADS[args.workload]
+    small = (args.targets or n_default) * (args.restarts or r_default) <= 65536
+    steps = args.steps if args.steps is not None else (320 if small else 20)
+    warmup = args.warmup if args.warmup is not None else (32 if small else 5)
+
+    comm = make_comm(rank, world, local_rank)
+    m = run_workload(args, args.workload, rank, world, local_rank, comm, steps, warmup, args.streams, main=True)
+    secondary = None
+    if not args.no_secondary and args.workload == "cfg3" and not args.span_rules and not args.targets and not args.restarts:
+        # BASELINE configs[1] (1024 x 16 CNOT, the latency-bound small-batch regime) beside the headline
+        s2 = run_workload(args, "cfg2", rank, world, local_rank, comm, 320, 32, None, main=False)
+        fl2 = sum(s2["st"]["evals"][k] * f_eval(k) for k in (1, 2, 3))
+        secondary = {"cfg2": {
+            "workload": s2["desc"], "value": s2["solved_all"] / s2["elapsed"], "unit": "decompositions/s", "steps": 320, "warmup": 32,
+            "ms_per_step": 1e3 * s2["elapsed"] / 320, "batches_in_flight_per_gpu": s2["n_streams"], "items_per_quad": s2["ipq"],
+            "solved_fraction": s2["solved_all"] / (world * 320 * s2["n_per_step"]),
+            "roofline_frac": fl2 / s2["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
+        }}
+
     if rank == 0:
-        flops = sum(st["evals"][k] * f_eval(k) for k in (1, 2, 3))
-        # one batch in flight: launches do not overlap, achieved = flops / sum of HIP-event launch durations.
-        # several batches in flight: launches of different streams share the chip and their event
-        # durations overlap, so the denominator is the wall time of the timed region instead.
-        kernel_s = st["kernel_ms"] * 1e-3 if streams_used == 1 else elapsed
-        achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
+        st = m["st"]
+        n_launch = max(1, st["kernel_launches"])
         out = {
             "metric": "Haar 2-qubit decompositions/sec (span<=3, loss<1e-8)",
-            "value": solved_all / elapsed,
+            "value": m["solved_all"] / m["elapsed"],
             "unit": "decompositions/s",
             "n_gpus": world,
             "steps": steps,
             "warmup": warmup,
-            "ms_per_step": 1e3 * elapsed / steps,
+            "ms_per_step": 1e3 * m["elapsed"] / steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": desc,
-                "basis": gname,
-                "targets_per_step_per_gpu": n_per_step,
-                "restarts": restarts,
+                "workload": m["desc"],
+                "basis": m["gname"],
+                "targets_per_step_per_gpu": m["n_per_step"],
+                "restarts": m["restarts"],
                 "span_max": 3,
                 "span_selection": "analytic span rules (use_polytopes mode)" if args.span_rules else "brute force 1..3 (reference default)",
-                "success_threshold": threshold,
+                "success_threshold": m["threshold"],
+                "restart_early_exit": "first restart to finish below stop_loss wins (timing-dependent)" if args.fast_exit
+                else "ordered: lowest-index successful restart wins (reference semantics, bitwise reproducible)",
                 "parallelism": (f"bases sharded over {world} GPU(s) ({SWEEP_BASES_PER_GPU} each), targets replicated, no data-path collective"
-                                if sweep else f"targets sharded over {world} GPU(s), no data-path collective"),
-                "batches_in_flight_per_gpu": streams_used,
-                "items_per_quad": ipq,
-                "device": dev_name,
-                "compute_units": cus,
+                                if m["sweep"] else f"targets sharded over {world} GPU(s), one process per GPU, no data-path collective"),
+                "final_collective": (None if world == 1 else
+                                     ("slam_allreduce_min: ncclAllReduce(min) of the resident best-loss windows, device to device (RCCL via C ABI)"
+                                      if m["resident_merge"] else f"min-all-reduce of the best-loss vector ({type(comm).__name__})")),
+                "batches_in_flight_per_gpu": m["n_streams"],
+                "items_per_quad": m["ipq"],
+                "device": m["dev_name"],
+                "compute_units": m["cus"],
             },
-            "solved_fraction": solved_all / (world * steps * n_per_step),
-            "best_cycles_hist_rank0": {str(k): int(cyc_hist[k]) for k in range(4)},
-            "worst_loss_rank0": worst,
-            **({"per_basis_rank0": {str(b): v for b, v in sorted(per_basis.items())}} if per_basis is not None else {}),
+            "solved_fraction": m["solved_all"] / (world * steps * m["n_per_step"]),
+            "best_cycles_hist_rank0": {str(k): int(m["cyc_hist"][k]) for k in range(4)},
+            "worst_loss_rank0": m["worst"],
+            **({"per_basis_rank0": {str(b): v for b, v in sorted(m["per_basis"].items())}} if m["per_basis"] is not None else {}),
             "roofline": {
                 "bound": "valu_fp64",
-                "achieved": achieved,
+                "achieved": m["achieved"],
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_VALU_TFLOPS,
+                "frac": m["achieved"] / PEAK_FP64_VALU_TFLOPS,
                 "traffic": traffic_per_launch(args.workload),
                 "kernel": "minimize_kernel<K> (k=1..3)",
-                "time_basis": "hip_events" if streams_used == 1 else "wall_clock_of_timed_region",
+                "scope": "rank 0's GPU",
+                "time_basis": "hip_events" if m["n_streams"] == 1 else "wall_clock_of_timed_region",
                 "kernel_ms_total": st["kernel_ms"],
                 "kernel_launches": st["kernel_launches"],
-                "avg_launch_ms": st["kernel_ms"] / max(1, st["kernel_launches"]),
+                "avg_launch_ms": st["kernel_ms"] / n_launch,
                 "evals_per_span": {str(k): st["evals"][k] for k in (1, 2, 3)},
+                "evals_accepted": {str(k): st["evals_accepted"][k] for k in (1, 2, 3)},
+                "evals_rejected": {str(k): m["rejected"][k] for k in (1, 2, 3)},
+                "evals_preempted": {str(k): st["evals_preempted"][k] for k in (1, 2, 3)},
                 "items_per_span": {str(k): st["items"][k] for k in (1, 2, 3)},
                 "flops_per_eval": {str(k): f_eval(k) for k in (1, 2, 3)},
+                # the same time, stricter numerators: accepted points only; accepted at F_eval + rejected line-search
+                # trials at the forward-only count, pre-empted restarts not counted at all
+                "frac_accepted": m["flops_accepted"] / m["kernel_s"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "frac_accepted_plus_rejected_forward": m["flops_strict"] / m["kernel_s"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "numerator_note": "dense flop accounting of SURVEY.md 8(d) for every lock-step evaluation; structured gates (CX = a swap) "
+                                  "count at the dense 4x4 product's cost",
+                **({"per_span": m["per_span"]} if m["per_span"] else {}),
             },
         }
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gname, restarts, 20260000, opt_seed, args.cpu_sample, args.host_targets)
+            out["cpu_baseline"] = cpu_baseline(m["gname"], m["restarts"], TARGET_SEED0, OPT_SEED, args.cpu_sample, args.host_targets)
         print(json.dumps(out), flush=True)
-
-    for c in ctxs:
-        c.close()
-    if world > 1:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@
  *   - functions return 0 on success or a negative SLAM_ERR_* code;
  *     slam_last_error() gives the message for the calling thread.
  *   - one context = one GPU = one host thread at a time.  Multi-GPU = one context
- *     per device (one process per GPU in bench.py).
+ *     per device, one process per GPU, merged through slam_comm_* (RCCL) at the end.
  */
 #ifndef SLAM_HIP_H
 #define SLAM_HIP_H
@@ -41,6 +41,7 @@ extern "C" {
 #define SLAM_MAX_SPAN_EVAL 5     /* reference default maximum_span_guess, src/slam/basis.py:59 */
 #define SLAM_MAX_SPAN_MINIMIZE 5 /* spans the quasi-Newton kernel is instantiated for (1..3 are the tuned ones) */
 #define SLAM_MAX_GATES 256
+#define SLAM_MAX_MAXITER 4000    /* per-restart iteration cap accepted by the kernels (reference: 2500) */
 
 /* per-item optimizer status (slam_minimize_stage: item_status) */
 #define SLAM_ST_CONVERGED 0 /* loss < stop_loss or |g|_inf < gtol */
@@ -53,6 +54,13 @@ extern "C" {
 
 /* flags for slam_minimize_stage / slam_decompose */
 #define SLAM_FLAG_EARLY_EXIT 1u /* stop a target's other restarts once one reaches stop_loss */
+#define SLAM_FLAG_ORDERED 2u    /* with EARLY_EXIT: a successful restart (final loss < the span loop's success threshold;
+                                   stop_loss in slam_minimize_stage) only stops the restarts with a HIGHER index, and the
+                                   stage result is the lowest-index successful restart -- exactly the restart at which
+                                   the reference's sequential loop breaks (src/slam/optimizer.py:287-295).  Results are
+                                   then independent of scheduling, shard layout and items_per_quad (bitwise
+                                   reproducible for a fixed seed); without it the first restart to FINISH wins, which
+                                   runs fewer evaluations but depends on timing. */
 
 typedef struct slam_ctx slam_ctx;
 
@@ -72,6 +80,8 @@ typedef struct slam_opt_params {
     double far_loss;      /* stationary point that is clearly not a zero of the loss.  gtol_far = 1e-5 is SciPy's
                              default gtol, which is what the reference runs with (optimizer.py:270-278);
                              set gtol_far = 0 to disable */
+    int64_t target_base;  /* added to a target's index within the context's resident batch in the Philox key, so that a
+                             shard holding targets [base, base + n) of a larger job draws the seeds the whole job would */
 } slam_opt_params;
 
 typedef struct slam_stats {
@@ -83,6 +93,11 @@ typedef struct slam_stats {
     double kernel_ms_span[SLAM_MAX_SPAN_EVAL + 1]; /* kernel_ms split per span k */
     int64_t wave_rounds[SLAM_MAX_SPAN_EVAL + 1];   /* lock-step evaluation rounds summed over wavefronts, per span:
                                                       evals / (16 * wave_rounds) = fraction of quads that held an item */
+    /* split of evals[k]: evaluations whose point was accepted (a restart's initial point or an Armijo-accepted
+       step), evaluations of restarts that ended pre-empted by a successful sibling (all of them, accepted or not);
+       the rest, evals - accepted - preempted, are rejected line-search trials */
+    int64_t evals_accepted[SLAM_MAX_SPAN_EVAL + 1];
+    int64_t evals_preempted[SLAM_MAX_SPAN_EVAL + 1];
 } slam_stats;
 
 /* Thread-local message of the last failing call on this thread. */
@@ -252,6 +267,41 @@ int slam_reset_stats(slam_ctx* ctx);
  * (double[n_targets]); used by the multi-GPU merge to hand the buffer to RCCL
  * without a host round trip. */
 int slam_best_loss_device_ptr(slam_ctx* ctx, void** ptr, int64_t* n);
+
+/*
+ * Multi-GPU: one process per GPU, RCCL over xGMI, reached through this ABI (no torch, no MPI).  The path shards by
+ * target, every rank keeps all restarts of its targets, so the only exchange is the FINAL min-all-reduce of the
+ * best-loss vector -- the running minimum of TemplateOptimizer._run (src/slam/optimizer.py:281-284) taken over the
+ * ranks -- plus a few scalars (barrier, slowest rank's time, counts).  librccl.so is dlopen'ed by the first of these
+ * calls; a single-GPU process never loads it.
+ *   slam_comm_get_unique_id   rank 0 creates the 128-byte id and hands it to the other ranks (file, env, socket:
+ *                             the caller's business; bench.py / parallel.py use a file)
+ *   slam_comm_init            ncclCommInitRank on `device` (collective: every rank calls it with the same id)
+ *   slam_comm_allreduce_f64   in-place all-reduce of a small host array (staged through device memory)
+ *   slam_comm_barrier         all ranks have arrived
+ *   slam_comm_merge_begin     start a job-wide best-loss vector of n_global entries on this rank's GPU, all +inf
+ *   slam_comm_merge_add       min-merge the context's RESIDENT best_loss[first_local, first_local + count) -- the
+ *                             buffer slam_best_loss_device_ptr exposes -- into [first_global, first_global + count)
+ *                             of that vector, device to device (call once per context / window of the rank)
+ *   slam_comm_merge_add_host  the same from a host array (results that were fetched already)
+ *   slam_allreduce_min        ncclAllReduce(min) of the vector in place over xGMI; n_below (may be NULL) = number of
+ *                             entries < threshold counted on the device, merged (may be NULL) = host copy [n_global]
+ */
+#define SLAM_COMM_ID_BYTES 128
+#define SLAM_OP_SUM 0
+#define SLAM_OP_MAX 2
+#define SLAM_OP_MIN 3
+typedef struct slam_comm slam_comm;
+int slam_comm_get_unique_id(void* id);
+int slam_comm_init(int device, int rank, int world, const void* id, slam_comm** out);
+int slam_comm_destroy(slam_comm* comm);
+int slam_comm_rank(slam_comm* comm, int* rank, int* world);
+int slam_comm_allreduce_f64(slam_comm* comm, double* inout, int64_t n, int op);
+int slam_comm_barrier(slam_comm* comm);
+int slam_comm_merge_begin(slam_comm* comm, int64_t n_global);
+int slam_comm_merge_add(slam_comm* comm, slam_ctx* ctx, int64_t first_local, int64_t count, int64_t first_global);
+int slam_comm_merge_add_host(slam_comm* comm, const double* loss, int64_t count, int64_t first_global);
+int slam_allreduce_min(slam_comm* comm, double threshold, int64_t* n_below, double* merged);
 
 /* Library version string. */
 const char* slam_version(void);

@@ -21,6 +21,10 @@ MAX_SPAN_MINIMIZE = 5
 
 ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED = range(6)
 FLAG_EARLY_EXIT = 1
+FLAG_ORDERED = 2  # with EARLY_EXIT: the lowest-index successful restart wins (reference semantics, reproducible)
+MAX_MAXITER = 4000
+OP_SUM, OP_MAX, OP_MIN = 0, 2, 3
+COMM_ID_BYTES = 128
 COST_BASIC, COST_SQUARE = 0, 1
 
 # every symbol include/slam_hip.h declares (checked by tests/test_abi.py)
@@ -53,6 +57,16 @@ EXPORTED_SYMBOLS = (
     "slam_get_stats",
     "slam_reset_stats",
     "slam_best_loss_device_ptr",
+    "slam_comm_get_unique_id",
+    "slam_comm_init",
+    "slam_comm_destroy",
+    "slam_comm_rank",
+    "slam_comm_allreduce_f64",
+    "slam_comm_barrier",
+    "slam_comm_merge_begin",
+    "slam_comm_merge_add",
+    "slam_comm_merge_add_host",
+    "slam_allreduce_min",
 )
 
 
@@ -75,12 +89,13 @@ class OptParams(C.Structure):
         ("items_per_quad", C.c_uint32),
         ("gtol_far", C.c_double),
         ("far_loss", C.c_double),
+        ("target_base", C.c_int64),
     ]
 
     def __init__(self, restarts=5, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=0, flags=0, gtol_far=1e-5, far_loss=1e-6,
-                 items_per_quad=0):
+                 items_per_quad=0, target_base=0):
         super().__init__(int(restarts), int(maxiter), float(gtol), float(stop_loss), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                         int(flags), int(items_per_quad), float(gtol_far), float(far_loss))
+                         int(flags), int(items_per_quad), float(gtol_far), float(far_loss), int(target_base))
 
 
 class Stats(C.Structure):
@@ -92,6 +107,8 @@ class Stats(C.Structure):
         ("total_ms", C.c_double),
         ("kernel_ms_span", C.c_double * (MAX_SPAN_EVAL + 1)),
         ("wave_rounds", C.c_int64 * (MAX_SPAN_EVAL + 1)),
+        ("evals_accepted", C.c_int64 * (MAX_SPAN_EVAL + 1)),
+        ("evals_preempted", C.c_int64 * (MAX_SPAN_EVAL + 1)),
     ]
 
 
@@ -140,6 +157,17 @@ def load_library() -> C.CDLL:
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.slam_reset_stats.argtypes = [P]
     lib.slam_best_loss_device_ptr.argtypes = [P, C.POINTER(P), C.POINTER(C.c_int64)]
+    if hasattr(lib, "slam_comm_init"):
+        lib.slam_comm_get_unique_id.argtypes = [P]
+        lib.slam_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, P, C.POINTER(P)]
+        lib.slam_comm_destroy.argtypes = [P]
+        lib.slam_comm_rank.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.slam_comm_allreduce_f64.argtypes = [P, P, C.c_int64, C.c_int]
+        lib.slam_comm_barrier.argtypes = [P]
+        lib.slam_comm_merge_begin.argtypes = [P, C.c_int64]
+        lib.slam_comm_merge_add.argtypes = [P, P, C.c_int64, C.c_int64, C.c_int64]
+        lib.slam_comm_merge_add_host.argtypes = [P, P, C.c_int64, C.c_int64]
+        lib.slam_allreduce_min.argtypes = [P, C.c_double, C.POINTER(C.c_int64), P]
     for name in EXPORTED_SYMBOLS:
         if "SLAM_HIP_LIB" in os.environ and not hasattr(lib, name):
             continue  # an older A/B build: newer entry points are simply not used
@@ -411,6 +439,8 @@ class Context:
             "total_ms": s.total_ms,
             "kernel_ms_span": list(s.kernel_ms_span),
             "wave_rounds": list(s.wave_rounds),
+            "evals_accepted": list(s.evals_accepted),
+            "evals_preempted": list(s.evals_preempted),
         }
 
     def reset_stats(self) -> None:
@@ -420,3 +450,70 @@ class Context:
         p, n = C.c_void_p(), C.c_int64(0)
         _check(self._lib.slam_best_loss_device_ptr(self._h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
+
+
+class Comm:
+    """RCCL communicator of one rank (``slam_comm``): one process per GPU, xGMI underneath.  Only the job's final
+    best-loss min-all-reduce and a few scalars go through it."""
+
+    def __init__(self, device: int, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _check(self._lib.slam_comm_init(int(device), int(rank), int(world), buf, C.byref(self._h)))
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """``ncclGetUniqueId`` (rank 0 calls this and hands the bytes to the other ranks)."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(load_library().slam_comm_get_unique_id(buf))
+        return buf.raw
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.slam_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _allreduce(self, a: np.ndarray, op: int) -> None:
+        if a.dtype != np.float64 or not a.flags.c_contiguous:
+            raise ValueError("all-reduce buffers must be C-contiguous float64")
+        _check(self._lib.slam_comm_allreduce_f64(self._h, _ptr(a), a.size, op))
+
+    def allreduce_min(self, a: np.ndarray) -> None:
+        self._allreduce(a, OP_MIN)
+
+    def allreduce_max(self, a: np.ndarray) -> None:
+        self._allreduce(a, OP_MAX)
+
+    def allreduce_sum(self, a: np.ndarray) -> None:
+        self._allreduce(a, OP_SUM)
+
+    def barrier(self) -> None:
+        _check(self._lib.slam_comm_barrier(self._h))
+
+    def merge_begin(self, n_global: int) -> None:
+        _check(self._lib.slam_comm_merge_begin(self._h, int(n_global)))
+
+    def merge_add(self, ctx: "Context", first_local: int, count: int, first_global: int) -> None:
+        """Min-merge the context's resident best_loss window into the job-wide vector, device to device."""
+        _check(self._lib.slam_comm_merge_add(self._h, ctx._h, int(first_local), int(count), int(first_global)))
+
+    def merge_add_host(self, loss: np.ndarray, first_global: int) -> None:
+        loss = np.ascontiguousarray(loss, dtype=np.float64)
+        _check(self._lib.slam_comm_merge_add_host(self._h, _ptr(loss), loss.size, int(first_global)))
+
+    def allreduce_min_merged(self, threshold: float, n_global: Optional[int] = None):
+        """The job's one collective.  Returns (number of entries < threshold, merged vector or None)."""
+        nb = C.c_int64(0)
+        merged = np.empty(int(n_global), dtype=np.float64) if n_global else None
+        _check(self._lib.slam_allreduce_min(self._h, float(threshold), C.byref(nb), _ptr(merged)))
+        return int(nb.value), merged

@@ -21,6 +21,12 @@ class VariationalTemplate(ABC):
         if not self.use_polytopes and self.spanning_range is None:
             raise NotImplementedError
         self.preseeded = preseed and self.use_polytopes  # basis_abc.py:41-43
+        if self.preseeded:
+            # the reference would now load its pickle cache, seed restarts from the KD-tree neighbour and save every
+            # result (basis_abc.py:27-29,60-77; optimizer.py:107-118,126-149).  None of that exists here: refuse
+            # rather than silently run unseeded.  (preseed=True without polytopes is a no-op in the reference too.)
+            raise NotImplementedError("preseed=True with use_polytopes=True (pickle cache + KD-tree neighbour seeding) "
+                                      "is not implemented on the HIP path")
         self.seed = None
 
     def eval(self, Xk):

@@ -32,6 +32,13 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+// slam_comm.hip reports its errors through the same thread-local message (library-internal, not exported)
+extern "C" __attribute__((visibility("hidden"))) void slam_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
+
+namespace {
+
 #define HIP_TRY(expr)                                                                            \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \
@@ -89,11 +96,12 @@ struct slam_ctx {
     DevBuf targets, gates;
     // stage work buffers
     DevBuf active, active2, x0;
-    DevBuf item_loss, item_x, item_iters, item_status, item_evals;
+    DevBuf item_loss, item_x, item_iters, item_status, item_evals, item_acc;
     DevBuf stage_loss, stage_x, stage_restart;
     // decompose results
     DevBuf best_loss, best_x, best_cycles;
     int32_t result_nmax = 0;
+    int64_t result_filled = 0;  // targets whose resident results have been initialised (+inf / -1) for result_nmax
     DevBuf counters;  // StageCtl[SLAM_MAX_SPAN_EVAL + 2]: one control block per span stage (slam_kernels.hpp)
     DevBuf solved;
     DevBuf stage_targets;
@@ -110,7 +118,7 @@ struct slam_ctx {
 
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
-                         &item_status, &item_evals, &stage_loss, &stage_x, &stage_restart, &best_loss,
+                         &item_status, &item_evals, &item_acc, &stage_loss, &stage_x, &stage_restart, &best_loss,
                          &best_x, &best_cycles, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
@@ -126,6 +134,21 @@ struct slam_ctx {
 };
 
 namespace {
+
+// Every API call leaves the context's stream drained: the per-span gate slots, the pinned staging buffers and
+// DevBuf::reserve's hipFree rely on it.  A call that fails after it has enqueued work therefore waits for that work
+// (ignoring the result: the error being reported is the first one) and forgets the cached gate slots.
+int drained(slam_ctx* c, int rc) {
+    if (rc != SLAM_OK && c && c->stream) {
+        const std::string keep = g_err;
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        for (auto& st : c->staged) st.valid = false;
+        g_err = keep;
+    }
+    return rc;
+}
 
 template <int K, int GC>
 constexpr size_t lds_bytes() { return sizeof(double) * lds_doubles<K, GC>(); }
@@ -212,6 +235,7 @@ int launch_eval(slam_ctx* c, const int32_t* gate_seq, const double* d_x, const i
 }
 
 struct StageLaunch {
+    double exit_loss;               // a finished restart below this pre-empts its siblings
     const int32_t* gate_seq;
     const double* d_stage_targets;  // [n_active][32]
     const int32_t* d_active;        // original target index per slot, or nullptr = first_target + slot
@@ -248,7 +272,9 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.stop_loss = prm->stop_loss;
     a.gtol_far = prm->gtol_far;
     a.far_loss = prm->far_loss;
+    a.exit_loss = sl.exit_loss;
     a.seed = prm->seed;
+    a.target_base = prm->target_base;
     a.flags = prm->flags;
     a.items_per_quad = prm->items_per_quad;
     a.cost_kind = c->cost_kind;
@@ -258,6 +284,7 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.item_iters = c->item_iters.as<int32_t>();
     a.item_status = c->item_status.as<int32_t>();
     a.item_evals = c->item_evals.as<int32_t>();
+    a.item_acc = c->item_acc.as<int32_t>();
     { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
     // persistent wavefronts: never more blocks than can be resident, every quad pulls items.  The grid is
     // sized for the upper bound of the item count; the kernel derives the real launch shape (waves that
@@ -287,7 +314,9 @@ int check_gate_seq(slam_ctx* c, int k, const int32_t* gate_seq) {
 int check_params(const slam_opt_params* p) {
     if (!p) return fail(SLAM_ERR_INVALID, "params is NULL");
     if (p->restarts <= 0) return fail(SLAM_ERR_INVALID, "restarts must be > 0 (got %d)", p->restarts);
-    if (p->maxiter < 0) return fail(SLAM_ERR_INVALID, "maxiter must be >= 0 (got %d)", p->maxiter);
+    if (p->maxiter < 0 || p->maxiter > SLAM_MAX_MAXITER)
+        return fail(SLAM_ERR_INVALID, "maxiter must be in 0..%d (got %d)", SLAM_MAX_MAXITER, p->maxiter);
+    if (p->target_base < 0 || p->target_base > 0x7fffffffLL) return fail(SLAM_ERR_INVALID, "target_base out of range");
     return SLAM_OK;
 }
 
@@ -303,6 +332,7 @@ int reserve_stage_buffers(slam_ctx* c, int64_t n_upper, int k_max, const slam_op
     HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
     HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
     HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->item_acc.reserve(M * sizeof(int32_t)));
     HIP_TRY(c->stage_loss.reserve(n_upper * sizeof(double)));
     HIP_TRY(c->stage_x.reserve(n_upper * n * sizeof(double)));
     HIP_TRY(c->stage_restart.reserve(n_upper * sizeof(int32_t)));
@@ -318,6 +348,7 @@ int reserve_stage_buffers(slam_ctx* c, int64_t n_upper, int k_max, const slam_op
 // ctx->stage_loss / stage_x / stage_restart and the per-item arrays.
 // What follows the optimizer kernel of a stage inside the span loop (nullptr: single-stage call, reduce only).
 struct SpanLoopStep {
+    double exit_loss;        // ordered early exit: the span loop's success threshold; otherwise params->stop_loss
     bool inputs_ready;       // the previous kernel of the chain already prepared this stage's inputs
     bool has_next;           // a longer span follows: compact the unsolved targets into active_out
     double threshold;
@@ -338,7 +369,10 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
         HIP_TRY(hipGetLastError());
     }
     const double* d_stage_targets = d_active ? c->stage_targets.as<double>() : c->targets.as<double>();
-    StageLaunch sl{gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm, ctl};
+    // which finished restart stops its siblings: in ordered mode the one the reference's loop breaks at -- best
+    // result below the success threshold (optimizer.py:287) -- otherwise one that reached stop_loss
+    const double exit_loss = ((prm->flags & SLAM_FLAG_ORDERED) && loop) ? loop->exit_loss : prm->stop_loss;
+    StageLaunch sl{exit_loss, gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm, ctl};
     int rc;
     const int gc = classify_gates(c, k, gate_seq);
 #define SLAM_MIN_CASE(KK)                                                   \
@@ -362,6 +396,10 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
     r.item_loss = c->item_loss.as<double>();
     r.item_x = c->item_x.as<double>();
     r.item_evals = c->item_evals.as<int32_t>();
+    r.item_acc = c->item_acc.as<int32_t>();
+    r.item_status = c->item_status.as<int32_t>();
+    r.exit_loss = exit_loss;
+    r.ordered = ((prm->flags & SLAM_FLAG_EARLY_EXIT) && (prm->flags & SLAM_FLAG_ORDERED)) ? 1 : 0;
     r.ctl = ctl;
     r.restarts = prm->restarts;
     r.n = n;
@@ -413,6 +451,8 @@ int collect_stats(slam_ctx* c, int k_min, int k_max, const StageCtl* h_ctl, int 
         c->stats.kernel_ms_span[k] += ms;
         c->stats.kernel_launches += 1;
         c->stats.evals[k] += (int64_t)h_ctl[k].evals;
+        c->stats.evals_accepted[k] += (int64_t)h_ctl[k].evals_accepted;
+        c->stats.evals_preempted[k] += (int64_t)h_ctl[k].evals_preempted;
         c->stats.wave_rounds[k] += (int64_t)h_ctl[k].rounds;
         c->stats.items[k] += (int64_t)h_ctl[k].n_active * restarts;
     }
@@ -421,9 +461,19 @@ int collect_stats(slam_ctx* c, int k_min, int k_max, const StageCtl* h_ctl, int 
 
 int ensure_results(slam_ctx* c, int k_max) {
     const int nmax = 6 * (k_max + 1);
+    const void* p0 = c->best_loss.p;
+    const void* p1 = c->best_cycles.p;
     HIP_TRY(c->best_loss.reserve(c->n_targets * sizeof(double)));
     HIP_TRY(c->best_x.reserve(c->n_targets * (size_t)nmax * sizeof(double)));
     HIP_TRY(c->best_cycles.reserve(c->n_targets * sizeof(int32_t)));
+    if (c->result_nmax != nmax || c->result_filled != c->n_targets || p0 != c->best_loss.p || p1 != c->best_cycles.p) {
+        // new batch, new row width or new allocation: every target starts as "nothing found yet", so that a
+        // window no call has decomposed reads as (+inf, -1) instead of uninitialised memory
+        hipLaunchKernelGGL(fill_results_kernel, dim3((unsigned)((c->n_targets + 255) / 256)), dim3(256), 0, c->stream,
+                           c->best_loss.as<double>(), c->best_cycles.as<int32_t>(), c->n_targets);
+        HIP_TRY(hipGetLastError());
+        c->result_filled = c->n_targets;
+    }
     c->result_nmax = nmax;
     return SLAM_OK;
 }
@@ -483,9 +533,9 @@ void finish_fetch(slam_ctx* ctx, const FetchReq& fr) {
 }
 
 // h_list != nullptr: the batch is the explicit list of resident-target indices h_list[0..count) (first ignored)
-int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
-                   const slam_opt_params* prm, double success_threshold, const int32_t* h_list = nullptr, int k_layout = 0,
-                   FetchReq* fetch = nullptr) {
+int decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                   const slam_opt_params* prm, double success_threshold, const int32_t* h_list, int k_layout,
+                   FetchReq* fetch) {
     if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
@@ -544,7 +594,7 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     for (int k = k_min; k <= k_max; ++k) {
         // the first stage's inputs come from init_results_kernel, a small batch's later ones from the
         // previous stage's epilogue
-        SpanLoopStep step{k == k_min || small, k < k_max, success_threshold, nxt->as<int32_t>()};
+        SpanLoopStep step{success_threshold, k == k_min || small, k < k_max, success_threshold, nxt->as<int32_t>()};
         rc = enqueue_stage(c, k, gs, d_active, N, nullptr, prm, &step);
         if (rc) return rc;
         gs += k;
@@ -566,6 +616,12 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
     c->stats.total_ms = ms;
     return collect_stats(c, k_min, k_max, c->h_ctl, prm->restarts);
+}
+
+int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                   const slam_opt_params* prm, double success_threshold, const int32_t* h_list = nullptr, int k_layout = 0,
+                   FetchReq* fetch = nullptr) {
+    return drained(c, decompose_body(c, first, count, k_min, k_max, gate_seqs, prm, success_threshold, h_list, k_layout, fetch));
 }
 
 }  // namespace
@@ -660,6 +716,7 @@ int slam_set_targets(slam_ctx* ctx, const double* targets, int64_t n_targets) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->n_targets = n_targets;
     ctx->result_nmax = 0;
+    ctx->result_filled = 0;
     return SLAM_OK;
 }
 
@@ -678,8 +735,8 @@ int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates) {
     return SLAM_OK;
 }
 
-static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
-                     int64_t M, double* loss, double* grad, double* unitary, double* weyl = nullptr, int ndigits = 8) {
+static int eval_body(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
+                     int64_t M, double* loss, double* grad, double* unitary, double* weyl, int ndigits) {
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
@@ -742,6 +799,11 @@ static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
     return SLAM_OK;
 }
 
+static int eval_impl(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of,
+                     int64_t M, double* loss, double* grad, double* unitary, double* weyl = nullptr, int ndigits = 8) {
+    return drained(ctx, eval_body(ctx, k, gate_seq, x, target_of, M, loss, grad, unitary, weyl, ndigits));
+}
+
 // Weyl coordinates of `count` unitaries that are already in device memory
 static int weyl_device(slam_ctx* ctx, const double* d_unitaries, int64_t count, int ndigits, double* out) {
     HIP_TRY(ctx->ev_weyl.reserve((size_t)count * 3 * sizeof(double)));
@@ -769,7 +831,7 @@ int slam_eval_unitary(slam_ctx* ctx, int k, const int32_t* gate_seq, const doubl
     return eval_impl(ctx, k, gate_seq, x, target_of, M, loss, nullptr, unitary);
 }
 
-int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
+static int minimize_stage_body(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
                         const double* x0, const slam_opt_params* params, double* best_loss, double* best_x,
                         int32_t* best_restart, double* item_loss, int32_t* item_iters, int32_t* item_status,
                         int32_t* item_evals) {
@@ -832,6 +894,14 @@ int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
     ctx->stats.total_ms = ms;
     return collect_stats(ctx, k, k, ctx->h_ctl, params->restarts);
+}
+
+int slam_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
+                        const double* x0, const slam_opt_params* params, double* best_loss, double* best_x,
+                        int32_t* best_restart, double* item_loss, int32_t* item_iters, int32_t* item_status,
+                        int32_t* item_evals) {
+    return drained(ctx, minimize_stage_body(ctx, k, gate_seq, active, n_active, x0, params, best_loss, best_x, best_restart,
+                                            item_loss, item_iters, item_status, item_evals));
 }
 
 int slam_decompose_resident(slam_ctx* ctx, int k_min, int k_max, const int32_t* gate_seqs,
@@ -927,6 +997,7 @@ int slam_sample_haar(slam_ctx* ctx, uint64_t seed, int64_t first_index, int64_t 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->n_targets = n_targets;
     ctx->result_nmax = 0;
+    ctx->result_filled = 0;
     return SLAM_OK;
 }
 

@@ -24,7 +24,9 @@ struct StageCtl {
     unsigned long long rounds;   // += lock-step evaluation rounds of every wavefront
     unsigned int work_counter;   // work queue of the optimizer kernel
     int32_t n_active;            // targets of this stage (written by init / the previous stage's compaction)
-    int32_t pad[10];
+    unsigned long long evals_accepted;   // += evaluations whose point was accepted (initial point or Armijo step)
+    unsigned long long evals_preempted;  // += evaluations of items that ended pre-empted by a sibling restart
+    int32_t pad[6];
 };
 static_assert(sizeof(StageCtl) == 64, "StageCtl layout");
 
@@ -41,17 +43,22 @@ struct MinimizeArgs {
     double stop_loss;
     double gtol_far;
     double far_loss;
+    double exit_loss;            // a finished restart below this pre-empts its siblings (SLAM_FLAG_EARLY_EXIT)
     uint64_t seed;
+    int64_t target_base;         // added to the target index in the Philox key (slam_opt_params.target_base)
     uint32_t flags;
     uint32_t items_per_quad;     // launch shaping (slam_opt_params.items_per_quad)
     int32_t cost_kind;           // 0 BasicCost, 1 SquareCost
-    int32_t* solved;             // [n_active], zeroed before launch (SLAM_FLAG_EARLY_EXIT)
+    // [n_active], zeroed before launch (SLAM_FLAG_EARLY_EXIT): 0 = no restart of the target has succeeded yet,
+    // else restarts - r for the lowest-index successful restart r so far (atomic max)
+    int32_t* solved;
     // per-item outputs
     double* item_loss;        // [M]
     double* item_x;           // [M][n]
     int32_t* item_iters;      // [M]
     int32_t* item_status;     // [M]
     int32_t* item_evals;      // [M]
+    int32_t* item_acc;        // [M] evaluations whose point was accepted
     const double* gates;      // [K][32]: G_1..G_K of this span
 };
 
@@ -138,7 +145,8 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     load_sincos_table(tbl, lane);
     lds_fence();
     // ---- launch shape from the device-side target count (the grid is sized for the host's upper bound)
-    const unsigned n_items = (unsigned)args.ctl->n_active * (unsigned)args.restarts;
+    const unsigned n_act = (unsigned)args.ctl->n_active;
+    const unsigned n_items = n_act * (unsigned)args.restarts;
     unsigned n_waves = (n_items + kQuadsPerWave - 1) / kQuadsPerWave;
     if (args.items_per_quad > 1) {
         n_waves = (n_items + kQuadsPerWave * args.items_per_quad - 1) / (kQuadsPerWave * args.items_per_quad);
@@ -146,16 +154,18 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
     }
     if (n_waves > gridDim.x) n_waves = gridDim.x;
     if (blockIdx.x >= n_waves) return;
-    // A wave takes `chunk` consecutive items at a time.  Big chunks keep a target's restarts in one wave
-    // (early exit then drops the rest without ever starting them); small batches need every wave busy.
-    // With at least one target per wave, give a wave whole targets: splitting a target's restarts over two
-    // waves doubles the restarts that run before the first success is seen.
+    // The work queue is RESTART-MAJOR: position idx holds restart idx / n_active of stage slot idx % n_active, so every
+    // target's restart 0 is handed out before any restart 1, and so on -- the order of the reference's sequential
+    // loop (optimizer.py:253).  By the time a target's restart r + 1 comes up, its restart r has usually finished:
+    // if it succeeded, r + 1 and all later ones are dropped when pulled (one flag load) instead of running beside
+    // it and being pre-empted half-way.  (Target-major order -- a wave holding 16 restarts of one target at once --
+    // spent 47 % of the k = 2 and 90 % of the k = 3 evaluations of the 65 536 x 32 sqrt(iSWAP) batch on restarts
+    // that a sibling then pre-empted.)  A wave takes `chunk` consecutive positions at a time: big chunks mean few
+    // atomics, small batches need every wave busy.
     unsigned kChunkV;
     {
         const unsigned per_wave = n_items / n_waves;
         kChunkV = per_wave >= 256u ? 64u : (per_wave >= 64u ? 32u : 16u);
-        const unsigned r16 = ((unsigned)args.restarts + 15u) / 16u * 16u;
-        if (r16 > kChunkV && r16 <= 64u && (unsigned)args.ctl->n_active >= n_waves) kChunkV = r16;
     }
 
     // ---- per-quad state (replicated over the quad's 4 lanes unless distributed)
@@ -202,44 +212,63 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                     if (b >= n_items) { exhausted = true; break; }
                     if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
                 }
-                const bool want = !live;
-                const unsigned long long mask = __ballot(want && q == 0);
-                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                const unsigned idx = cur_next + (unsigned)dpp_i32<0x00>(rank);
-                const unsigned sl = idx / (unsigned)args.restarts;
-                bool skip = false;
-                if ((args.flags & 1u) && want && idx < cur_end)
-                    skip = __hip_atomic_load(&args.solved[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                // the first idle quad holds item cur_next: if its target is already solved, drop all the
-                // remaining restarts of that target in this chunk at once (they are consecutive items)
-                const int leader = __ffsll((long long)mask) - 1;
-                const bool lead_skip = __builtin_amdgcn_readlane((int)skip, leader) != 0;
-                if (lead_skip) {
-                    const unsigned sl0 = cur_next / (unsigned)args.restarts;
-                    unsigned stop = (sl0 + 1u) * (unsigned)args.restarts;
-                    stop = stop < cur_end ? stop : cur_end;
-                    for (unsigned i = cur_next + (unsigned)lane; i < stop; i += kWave) {
-                        args.item_loss[i] = INFINITY;
-                        args.item_iters[i] = 0;
-                        args.item_status[i] = ST_PREEMPTED;
-                        args.item_evals[i] = 0;
-                    }
-                    cur_next = stop;
-                } else {
-                cur_next += (unsigned)__popcll(mask);
-                if (want && idx < cur_end) {
-                    if (skip) {
-                        // a sibling restart already reached stop_loss: nothing to do for this item
-                        if (q == 0) {
-                            args.item_loss[idx] = INFINITY;
-                            args.item_iters[idx] = 0;
-                            args.item_status[idx] = ST_PREEMPTED;
-                            args.item_evals[idx] = 0;
-                        }
-                    } else {
-                        item = idx;
+                // ---- scan up to 64 queue positions at once: lane l looks at position cur_next + l.  Positions whose
+                // target already has a successful restart are dropped here (one flag load for the whole window, their
+                // outputs written by the scanning lanes); the idle quads get the first positions that still need work.
+                const unsigned wlen = (cur_end - cur_next < (unsigned)kWave) ? cur_end - cur_next : (unsigned)kWave;
+                const bool valid = (unsigned)lane < wlen;
+                const unsigned pos = cur_next + (unsigned)lane;   // queue position
+                const unsigned prs = pos / n_act;                 // restart
+                const unsigned psl = pos - prs * n_act;           // stage slot (target)
+                bool skipv = false;
+                if ((args.flags & 1u) && valid) {
+                    // flag = restarts - r of the lowest-index successful restart r (0: none).  Ordered mode
+                    // (SLAM_FLAG_ORDERED): only restarts with a HIGHER index than a successful one are dropped, so the
+                    // winner is the lowest-index successful restart whatever the scheduling -- the restart the
+                    // reference's sequential loop stops at (optimizer.py:287-295).
+                    const int fl = __hip_atomic_load(&args.solved[psl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int mine = args.restarts - (int)prs;
+                    skipv = (args.flags & 2u) ? (fl > mine) : (fl != 0);
+                }
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const unsigned long long avail = __ballot(valid && !skipv);
+                const unsigned long long idle = __ballot(!live && q == 0);
+                const int n_av = __popcll(avail), n_idle_now = __popcll(idle);
+                const int n_take = n_av < n_idle_now ? n_av : n_idle_now;
+                const int myrank = __popcll(avail & lt);
+                const bool handed = valid && !skipv && myrank < n_take;
+                const unsigned long long handed_mask = __ballot(handed);
+                // the window is consumed up to the last position handed out (all of it when every position with work
+                // found a quad); the rest is looked at again next time
+                const unsigned consumed = (n_take == n_av) ? wlen : (unsigned)(64 - __builtin_clzll(handed_mask));
+                if (valid && skipv && (unsigned)lane < consumed) {
+                    // a sibling restart already succeeded: nothing to do for this item
+                    // (outputs and explicit seeds keep the [slot][restart] layout whatever the processing order)
+                    const unsigned o = psl * (unsigned)args.restarts + prs;
+                    args.item_loss[o] = INFINITY;
+                    args.item_iters[o] = 0;
+                    args.item_status[o] = ST_PREEMPTED;
+                    args.item_evals[o] = 0;
+                    args.item_acc[o] = 0;
+                }
+                int* wp = reinterpret_cast<int*>(xchg);  // wave-private, dead between rounds: [16] slots, [16] restarts
+                if (handed) {
+                    wp[myrank] = (int)psl;
+                    wp[16 + myrank] = (int)prs;
+                }
+                lds_fence();
+                const int qrank = __popcll(idle & ((1ull << (lane & ~3)) - 1ull));  // rank of this quad among the idle ones
+                const bool get = !live && qrank < n_take;
+                const unsigned sl = get ? (unsigned)wp[qrank] : 0u;
+                const unsigned rs = get ? (unsigned)wp[16 + qrank] : 0u;
+                lds_fence();
+                cur_next += consumed;
+                {
+                    if (get) {
+                        const unsigned oidx = sl * (unsigned)args.restarts + rs;
+                        item = oidx;
                         slot = (int)sl;
-                        const unsigned restart = idx - sl * (unsigned)args.restarts;
+                        const unsigned restart = rs;
                         // three independent loads (no load feeds another's address)
                         tgt = args.orig ? args.orig[sl] : args.first_target + (int)sl;
                         tcol = args.targets + (int64_t)sl * 32 + q * 2;
@@ -248,8 +277,8 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                             const int i = 4 * a + q;
                             double xv = 0.0;
                             if (i < C::N)
-                                xv = args.x0 ? args.x0[(int64_t)idx * C::N + i]
-                                             : x0_philox(args.seed, (uint32_t)tgt, restart, (uint32_t)K, (uint32_t)i);
+                                xv = args.x0 ? args.x0[(int64_t)oidx * C::N + i]
+                                             : x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), restart, (uint32_t)K, (uint32_t)i);
                             x[a] = xv;
                             p[a] = 0.0;
                             g[a] = 0.0;
@@ -258,7 +287,6 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                         nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
                         scaled = false; fresh = true; live = true; taken = true;
                     }
-                }
                 }
             }
             if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
@@ -284,7 +312,6 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
             eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, tbl, q, args.cost_kind, ft, gt, Wr, Wi);
         }
         const bool active = live;
-        if (active) ++nev;
         const bool finite = isfinite(ft);
         // a non-finite trial point is never accepted; its gradient is zeroed here once so that everything below
         // stays finite without per-element guards (0 * NaN would otherwise leak into H through w and v)
@@ -293,6 +320,9 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         const bool armijo = finite && (ft <= f + kArmijoC1 * alpha * gp);
         const bool acc = active && (fresh ? finite : armijo);
         const bool step = acc && !fresh;  // a real quasi-Newton step (not the initial evaluation)
+        // evaluation counters of the item, packed: bits 0..19 all evaluations, bits 20..31 the accepted ones
+        // (at most maxiter + 1 <= 4095: the host caps maxiter)
+        nev += active ? (acc ? 0x100001 : 1) : 0;
 
         // ---- 3. quasi-Newton update.  s = am p and y = g' - g are formed on the fly; for quads that do not
         //         step, am = 0 and curv = false, hence rho = cf = 0 and w = v = 0: H is left unchanged (their
@@ -321,7 +351,8 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         const double fac = first ? (sy * fast_rcp(yy)) : 1.0;
         {
             // fac = 1 except at a quad's first update; unconditional (42 packed multiplies at k = 3) so
-            // that H is not redefined on one side of a branch
+            // that H is not redefined on one side of a branch (measured again in round 2: under `if (__any(first))`
+            // the k = 2 kernel spills 32 B per lane and the k = 3 kernel 512 B instead of 288 B)
             const float f32 = (float)fac;
             const f32x2 f2 = f32x2{f32, f32};
 #pragma unroll
@@ -424,9 +455,11 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
         // ---- 5. early exit across the restarts of one target (optimizer.py:287-295)
         if (args.flags & 1u) {
             asm volatile("" : "+v"(sflag));  // not to be tested (= waited for) any earlier than here
-            if (active && !done && sflag) { status = ST_PREEMPTED; done = true; }
-            if (active && done && status == ST_CONVERGED && f < args.stop_loss && q == 0)
-                __hip_atomic_store(&args.solved[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int mine = args.restarts - (int)(item - (unsigned)slot * (unsigned)args.restarts);
+            const bool beaten = (args.flags & 2u) ? (sflag > mine) : (sflag != 0);
+            if (active && !done && beaten) { status = ST_PREEMPTED; done = true; }
+            if (active && done && status != ST_PREEMPTED && f < args.exit_loss && q == 0)
+                __hip_atomic_fetch_max(&args.solved[slot], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- 6. finished items leave; their quads pull new work next round
         if (active && done) {
@@ -434,7 +467,8 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                 args.item_loss[item] = f;
                 args.item_iters[item] = iters;
                 args.item_status[item] = status;
-                args.item_evals[item] = nev;
+                args.item_evals[item] = nev & 0xFFFFF;
+                args.item_acc[item] = (int)((unsigned)nev >> 20);
             }
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
@@ -459,6 +493,10 @@ struct ReduceArgs {
     const double* item_loss;   // [n_active * R]
     const double* item_x;      // [n_active * R][n]
     const int32_t* item_evals; // [n_active * R]
+    const int32_t* item_acc;   // [n_active * R]
+    const int32_t* item_status;// [n_active * R]
+    double exit_loss;          // ordered == 1: the winner is the lowest-index restart below exit_loss (else the argmin)
+    int32_t ordered;
     StageCtl* ctl;             // n_active; evals += sum of item_evals
     int32_t restarts;
     int32_t n;                 // parameters at this span
@@ -474,13 +512,23 @@ struct ReduceArgs {
     int32_t* best_cycles;      // [n_targets]
 };
 
-__device__ __forceinline__ void reduce_merge_slot(const ReduceArgs& a, int64_t s, unsigned long long& ev) {
+struct EvalCounts {
+    unsigned long long all = 0, accepted = 0, preempted = 0;
+};
+
+__device__ __forceinline__ void reduce_merge_slot(const ReduceArgs& a, int64_t s, EvalCounts& ev) {
     {
         double best = INFINITY;
         int br = 0;
+        bool hit = false;  // ordered mode: a restart below exit_loss has been seen (the lowest index wins)
         for (int r = 0; r < a.restarts; ++r) {
             const double l = a.item_loss[s * a.restarts + r];
-            ev += (unsigned long long)a.item_evals[s * a.restarts + r];
+            const unsigned long long e = (unsigned long long)a.item_evals[s * a.restarts + r];
+            ev.all += e;
+            if (a.item_status[s * a.restarts + r] == ST_PREEMPTED) ev.preempted += e;
+            else ev.accepted += (unsigned long long)a.item_acc[s * a.restarts + r];
+            if (hit) continue;
+            if (a.ordered && l < a.exit_loss) { best = l; br = r; hit = true; continue; }
             if (l < best) { best = l; br = r; }   // NaN / +inf (pre-empted) never win
         }
         a.stage_loss[s] = best;
@@ -493,18 +541,31 @@ __device__ __forceinline__ void reduce_merge_slot(const ReduceArgs& a, int64_t s
                 a.best_loss[t] = best;
                 a.best_cycles[t] = a.k;
                 for (int i = 0; i < a.n; ++i) a.best_x[t * a.nmax + i] = src[i];
+                for (int i = a.n; i < a.nmax; ++i) a.best_x[t * a.nmax + i] = 0.0;  // defined rows: nothing beyond 6 (best_cycles + 1)
             }
         }
     }
 }
 
+// wave-level sums of the evaluation counters, one atomic each per wave
+__device__ __forceinline__ void publish_eval_counts(StageCtl* ctl, EvalCounts ev, int tid) {
+    for (int off = 32; off > 0; off >>= 1) {
+        ev.all += __shfl_down(ev.all, off);
+        ev.accepted += __shfl_down(ev.accepted, off);
+        ev.preempted += __shfl_down(ev.preempted, off);
+    }
+    if ((tid & 63) == 0 && ev.all) {
+        atomicAdd(&ctl->evals, ev.all);
+        atomicAdd(&ctl->evals_accepted, ev.accepted);
+        atomicAdd(&ctl->evals_preempted, ev.preempted);
+    }
+}
+
 __global__ void reduce_merge_kernel(ReduceArgs a) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long ev = 0;
+    EvalCounts ev;
     if (s < a.ctl->n_active) reduce_merge_slot(a, s, ev);
-    // wave-level sum, one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
-    if ((threadIdx.x & 63) == 0 && ev) atomicAdd(&a.ctl->evals, ev);
+    publish_eval_counts(a.ctl, ev, threadIdx.x);
 }
 
 // stage inputs: clear the early-exit flags and gather the active targets into a dense array so that the
@@ -550,6 +611,16 @@ __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int
     if (active && t < n * 16) {
         const int64_t src = list_mode ? (int64_t)active[t >> 4] * 16 + (t & 15) : first * 16 + t;
         reinterpret_cast<double2*>(stage_targets)[t] = reinterpret_cast<const double2*>(targets)[src];
+    }
+}
+
+// freshly (re)allocated resident results: "nothing found yet" for every target, so that windows no call has
+// decomposed read as best_loss = +inf, best_cycles = -1 instead of uninitialised memory
+__global__ void fill_results_kernel(double* best_loss, int32_t* best_cycles, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        best_loss[t] = INFINITY;
+        best_cycles[t] = -1;
     }
 }
 
@@ -618,10 +689,9 @@ __global__ void __launch_bounds__(NT) stage_epilogue_kernel(EpilogueArgs a) {
     __shared__ int32_t offs[NT + 1];
     const int tid = threadIdx.x;
     const int64_t n_in = a.r.ctl->n_active;
-    unsigned long long ev = 0;
+    EvalCounts ev;
     for (int64_t s = tid; s < n_in; s += NT) reduce_merge_slot(a.r, s, ev);
-    for (int off = 32; off > 0; off >>= 1) ev += __shfl_down(ev, off);
-    if ((tid & 63) == 0 && ev) atomicAdd(&a.r.ctl->evals, ev);
+    publish_eval_counts(a.r.ctl, ev, tid);
     if (!a.has_next) return;
     __syncthreads();  // this workgroup wrote every best_loss the compaction reads
     const int32_t total = compact_block<NT>(a.r.active, n_in, a.r.best_loss, a.threshold, a.active_out, counts, offs);

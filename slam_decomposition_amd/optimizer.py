@@ -7,8 +7,11 @@ optimizer.py:233-303) runs for the whole batch of targets at once inside libslam
 every (target, restart) pair is one quasi-Newton minimisation owned by a quad of GPU lanes.
 
 Differences a caller can observe:
-  * restarts of one target run concurrently; the reference stops at the first restart below
-    the threshold, so ``loss_result`` may come from a different (equally successful) restart;
+  * restarts of one target run concurrently.  With ``deterministic=True`` (default) the result of a span is
+    the LOWEST-INDEX restart that ends below the threshold -- the restart the reference's sequential loop
+    breaks at (optimizer.py:287-295) -- and results are bitwise reproducible for a fixed ``seed``, whatever the
+    scheduling, ``devices`` sharding or batch composition.  ``deterministic=False`` lets the first restart
+    to FINISH win (fewer evaluations, timing-dependent winner among equally successful restarts);
   * multi-start seeds come from Philox keyed on ``seed`` instead of NumPy's global generator
     (``seed=None`` draws the key from that generator, keeping "unseeded" behaviour);
   * gradients are analytic, so converged losses sit near 1e-14 instead of the reference's
@@ -54,6 +57,7 @@ class TemplateOptimizer:
         seed=None,
         gtol=DEFAULT_GTOL,
         stop_loss=None,
+        deterministic=True,
     ):
         self.basis = basis
         self.objective = objective
@@ -94,6 +98,7 @@ class TemplateOptimizer:
         if not self.devices:
             raise ValueError("devices must not be empty")
         self.seed = seed
+        self.deterministic = bool(deterministic)
         self.gtol = float(gtol)
         if stop_loss is None:
             stop_loss = min(DEFAULT_STOP_LOSS, 0.1 * self.success_threshold)
@@ -114,7 +119,7 @@ class TemplateOptimizer:
             gtol=self.gtol,
             stop_loss=self.stop_loss,
             seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
-            flags=_ffi.FLAG_EARLY_EXIT,
+            flags=_ffi.FLAG_EARLY_EXIT | (_ffi.FLAG_ORDERED if self.deterministic else 0),
         )
 
     def _run_batch(self, targets: np.ndarray, spanning_range: Sequence[int]):
@@ -137,18 +142,22 @@ class TemplateOptimizer:
         n = len(targets)
 
         def run_shard(device, first, count):
-            # a private context per shard: the seeds are keyed on the index *within the context's batch*, so
-            # every shard uploads the whole batch and works on its window (targets are 512 B each)
-            ctx = runtime.get_context(device) if len(self.devices) == 1 else _ffi.Context(device)
+            # a private context per shard holding only the shard's targets; the seeds are keyed on the GLOBAL target
+            # index (target_base), so a sharded run draws exactly the seeds of the single-device run
+            single = len(self.devices) == 1
+            ctx = runtime.get_context(device) if single else _ffi.Context(device)
             try:
                 if self._device_sampler is not None:
-                    self._device_sampler.fill(ctx)  # generated in place, nothing crosses PCIe
+                    self._device_sampler.fill(ctx, first, count)  # generated in place, nothing crosses PCIe
                 else:
-                    ctx.set_targets(targets)
+                    ctx.set_targets(targets[first : first + count])
                 ctx.set_gates(self.basis.gate_matrices)
                 ctx.set_cost(self._cost_kind)
                 ctx.reset_stats()
-                out = ctx.decompose_range(first, count, ks[0], ks[-1], gate_seqs, prm, self.success_threshold)
+                sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
+                                    flags=prm.flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
+                                    target_base=first)
+                out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
                 return out, ctx.stats()
             finally:
                 if len(self.devices) > 1:

@@ -3,17 +3,26 @@
 The path shards by target: every rank owns a contiguous block of targets with all
 their restarts, so the per-target argmin over restarts is local and no collective sits on the
 data path.  The only exchange is at the very end: a min-all-reduce of the best-loss vector
-(every rank contributes +inf outside its shard), plus -- when the caller wants the winning
-parameters everywhere -- a masked sum-all-reduce of best_x / best_cycles (exactly one rank holds
-each target, the others contribute zeros).
+(every rank contributes +inf outside its shard) -- the running minimum of
+``TemplateOptimizer._run`` (src/slam/optimizer.py:281-284) taken over the ranks -- plus, when the
+caller wants the winning parameters everywhere, a masked sum-all-reduce of best_x / best_cycles
+(exactly one rank holds each target, the others contribute zeros).
 
-``comm`` is anything with ``allreduce_min(np.ndarray)`` and ``allreduce_sum(np.ndarray)`` that
-reduce in place across ranks; :class:`TorchDistComm` wraps ``torch.distributed`` (backend "nccl" is
-RCCL over xGMI on MI355X, "gloo" on CPUs for tests).  torch is imported only there.
+One process per GPU.  The collective is RCCL over xGMI reached through libslamhip's C ABI
+(``slam_comm_*``, :class:`RcclComm`) -- no torch, no MPI.  ``comm`` below is anything with
+``rank``, ``world`` and in-place ``allreduce_min / allreduce_sum / allreduce_max(np.ndarray)``;
+tests plug a gloo communicator in (tests/gloo_comm.py), :class:`LocalComm` is world size 1.
+
+Rendezvous: rank 0 creates the 128-byte ``ncclUniqueId`` and the other ranks of the node read it
+from a file (``exchange_unique_id``); the file's name comes from ``SLAM_COMM_FILE`` or, under
+``torch.distributed.run`` / ``bench.py``'s own launcher, from the launcher's pid and port.
 """
 from __future__ import annotations
 
-from typing import Tuple
+import os
+import tempfile
+import time
+from typing import Callable, Optional, Tuple
 
 import numpy as np
 
@@ -40,34 +49,155 @@ class LocalComm:
     def allreduce_sum(self, a: np.ndarray) -> None:
         pass
 
+    def allreduce_max(self, a: np.ndarray) -> None:
+        pass
 
-class TorchDistComm:
-    """``torch.distributed`` process group as the communicator (one process per GPU)."""
+    def barrier(self) -> None:
+        pass
 
-    def __init__(self, device=None):
-        import torch
-        import torch.distributed as dist
+    def close(self) -> None:
+        pass
 
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
-        self._torch = torch
-        self._dist = dist
-        self.rank = dist.get_rank()
-        self.world = dist.get_world_size()
-        self.device = device  # None = CPU tensors (gloo); "cuda" for nccl/RCCL
 
-    def _reduce(self, a: np.ndarray, op) -> None:
-        t = self._torch.from_numpy(np.ascontiguousarray(a))
-        if self.device is not None:
-            t = t.to(self.device)
-        self._dist.all_reduce(t, op=op)
-        a[...] = t.cpu().numpy()
+# ---------------------------------------------------------------------------------------------
+# rendezvous of the ranks of one node through a file
+# ---------------------------------------------------------------------------------------------
+def rendezvous_path(env=os.environ) -> str:
+    """File through which rank 0 hands the ncclUniqueId to the other ranks of this job.
+
+    ``SLAM_COMM_FILE`` if set (bench.py's own launcher sets it); otherwise derived from what all ranks
+    of one ``torch.distributed.run`` job share and no other job does: the launcher's pid (the workers'
+    parent), MASTER_PORT and the run id."""
+    path = env.get("SLAM_COMM_FILE")
+    if path:
+        return path
+    key = f"{os.getppid()}_{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'none')}"
+    key = "".join(ch if ch.isalnum() or ch in "_-" else "_" for ch in key)
+    return os.path.join(tempfile.gettempdir(), f"slam_comm_{os.getuid()}_{key}.id")
+
+
+def exchange_unique_id(rank: int, world: int, path: str, make_id: Callable[[], bytes], timeout: float = 300.0,
+                       nbytes: int = 128) -> bytes:
+    """Rank 0 writes ``make_id()`` to ``path`` atomically (temp file + rename); the others wait for it."""
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        if len(uid) != nbytes:
+            raise ValueError(f"unique id must be {nbytes} bytes")
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
+        return uid
+    t0 = time.monotonic()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == nbytes:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s (is rank 0 running?)")
+        time.sleep(0.02)
+
+
+class RcclComm:
+    """RCCL communicator of this rank through libslamhip (``_ffi.Comm``): ``backend "nccl"`` without torch."""
+
+    def __init__(self, device: int, rank: int, world: int, path: Optional[str] = None, timeout: float = 300.0):
+        from . import _ffi
+
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self.path = path or rendezvous_path()
+        uid = exchange_unique_id(self.rank, self.world, self.path, _ffi.Comm.unique_id, timeout)
+        self.raw = _ffi.Comm(device, rank, world, uid)  # collective: returns once every rank has joined
+        if self.rank == 0 and self.world > 1:
+            try:
+                os.remove(self.path)  # every rank holds the id by now
+            except OSError:
+                pass
+
+    @classmethod
+    def from_env(cls, device: Optional[int] = None, env=os.environ) -> "RcclComm":
+        """RANK / WORLD_SIZE / LOCAL_RANK as set by ``torch.distributed.run`` or bench.py's launcher."""
+        rank = int(env.get("RANK", "0"))
+        world = int(env.get("WORLD_SIZE", "1"))
+        dev = int(env.get("LOCAL_RANK", "0")) if device is None else device
+        return cls(dev, rank, world, rendezvous_path(env))
 
     def allreduce_min(self, a: np.ndarray) -> None:
-        self._reduce(a, self._dist.ReduceOp.MIN)
+        self.raw.allreduce_min(a.reshape(-1))
 
     def allreduce_sum(self, a: np.ndarray) -> None:
-        self._reduce(a, self._dist.ReduceOp.SUM)
+        self.raw.allreduce_sum(a.reshape(-1))
+
+    def allreduce_max(self, a: np.ndarray) -> None:
+        self.raw.allreduce_max(a.reshape(-1))
+
+    def barrier(self) -> None:
+        self.raw.barrier()
+
+    def close(self) -> None:
+        self.raw.close()
+
+
+class FileComm:
+    """Rehearsal communicator: the ranks of one node reduce through files in a shared directory.
+
+    For the cases RCCL cannot serve -- several ranks sharing ONE GPU (a one-GPU box rehearsing the N > 1 path of
+    bench.py: RCCL refuses duplicate devices) or no GPU at all (CPU tests).  Same interface as :class:`RcclComm`."""
+
+    def __init__(self, rank: int, world: int, directory: str, timeout: float = 300.0):
+        self.rank, self.world, self.dir, self.timeout = int(rank), int(world), directory, float(timeout)
+        self._seq = 0
+        os.makedirs(directory, exist_ok=True)
+
+    def _name(self, seq: int, rank: int) -> str:
+        return os.path.join(self.dir, f"ar_{seq}_{rank}.npy")
+
+    def _allreduce(self, a: np.ndarray, op) -> None:
+        seq, self._seq = self._seq, self._seq + 1
+        tmp = self._name(seq, self.rank) + f".tmp{os.getpid()}.npy"
+        np.save(tmp, np.ascontiguousarray(a))
+        os.replace(tmp, self._name(seq, self.rank))
+        acc = None
+        for r in range(self.world):
+            t0 = time.monotonic()
+            while True:
+                try:
+                    part = np.load(self._name(seq, r))
+                    break
+                except (FileNotFoundError, ValueError, EOFError):
+                    if time.monotonic() - t0 > self.timeout:
+                        raise TimeoutError(f"rank {self.rank}: rank {r} never arrived at all-reduce {seq}")
+                    time.sleep(0.005)
+            acc = part if acc is None else op(acc, part)
+        a[...] = acc.reshape(a.shape)
+        if seq >= 2:  # every rank has passed all-reduce seq - 1, hence finished reading seq - 2
+            try:
+                os.remove(self._name(seq - 2, self.rank))
+            except OSError:
+                pass
+
+    def allreduce_min(self, a: np.ndarray) -> None:
+        self._allreduce(a, np.minimum)
+
+    def allreduce_sum(self, a: np.ndarray) -> None:
+        self._allreduce(a, np.add)
+
+    def allreduce_max(self, a: np.ndarray) -> None:
+        self._allreduce(a, np.maximum)
+
+    def barrier(self) -> None:
+        self._allreduce(np.zeros(1), np.add)
+
+    def close(self) -> None:
+        pass
 
 
 def merge_results(comm, n_targets: int, first: int, best_loss, best_x=None, best_cycles=None):
@@ -75,7 +205,11 @@ def merge_results(comm, n_targets: int, first: int, best_loss, best_x=None, best
 
     best_loss [count], best_x [count, nmax], best_cycles [count] are this rank's shard (targets
     first .. first + count - 1).  Returns (loss[n_targets], x[n_targets, nmax] | None,
-    cycles[n_targets] | None), identical on all ranks and bit-identical to a single-rank run."""
+    cycles[n_targets] | None), identical on all ranks.  The merge itself adds nothing: every entry comes
+    from exactly one rank.  Whether a sharded job equals the single-rank job bit for bit is therefore a
+    property of the per-rank results: it does with ``SLAM_FLAG_ORDERED`` (``TemplateOptimizer``'s default,
+    ``deterministic=True``) and seeds keyed on the global target index (``OptParams.target_base``); with the
+    plain early-exit flag the winning restart of a target depends on timing."""
     count = len(best_loss)
     loss = np.full(n_targets, np.inf, dtype=np.float64)
     loss[first : first + count] = best_loss
@@ -86,8 +220,8 @@ def merge_results(comm, n_targets: int, first: int, best_loss, best_x=None, best
         x[first : first + count] = best_x
         comm.allreduce_sum(x)
     if best_cycles is not None:
-        cyc = np.zeros(n_targets, dtype=np.int64)
-        cyc[first : first + count] = best_cycles
-        comm.allreduce_sum(cyc)
-        cyc = cyc.astype(np.int32)
+        c = np.zeros(n_targets, dtype=np.float64)  # one dtype on the wire: cycles are small integers, exact in f64
+        c[first : first + count] = best_cycles
+        comm.allreduce_sum(c)
+        cyc = c.astype(np.int32)
     return loss, x, cyc

@@ -88,9 +88,11 @@ class DeviceHaarBatch(SampleFunction):
         self._cache = None
         super().__init__(n_samples=n_samples, n_qubits=n_qubits)
 
-    def fill(self, ctx) -> None:
-        """Make this batch the resident targets of ``ctx`` (generated in place)."""
-        ctx.sample_haar(self.seed, self.n_samples, self.start)
+    def fill(self, ctx, first: int = 0, count=None) -> None:
+        """Make this batch -- or its window [first, first + count), one device's shard -- the resident targets of
+        ``ctx`` (generated in place)."""
+        count = self.n_samples - first if count is None else count
+        ctx.sample_haar(self.seed, count, self.start + first)
 
     def as_array(self) -> np.ndarray:
         if self._cache is None:

@@ -29,12 +29,13 @@ def test_header_symbols_are_exported_and_bound():
 def test_version_and_struct_layout():
     lib = _ffi.load_library()
     assert b"gfx950" in lib.slam_version()
-    # slam_opt_params: i32 i32 f64 f64 u64 u32 u32 f64 f64
-    assert ctypes.sizeof(_ffi.OptParams) == 56
+    # slam_opt_params: i32 i32 f64 f64 u64 u32 u32 f64 f64 i64
+    assert ctypes.sizeof(_ffi.OptParams) == 64
+    assert _ffi.OptParams.target_base.offset == 56
     assert _ffi.OptParams.gtol_far.offset == 40
     p = _ffi.OptParams(restarts=7, seed=2**63 + 5)
     assert p.restarts == 7 and p.seed == 2**63 + 5 and p.gtol_far == 1e-5 and p.far_loss == 1e-6
-    assert ctypes.sizeof(_ffi.Stats) == 8 + 8 + 6 * 8 + 6 * 8 + 8 + 6 * 8 + 6 * 8
+    assert ctypes.sizeof(_ffi.Stats) == 8 + 8 + 6 * 8 + 6 * 8 + 8 + 6 * 8 + 6 * 8 + 6 * 8 + 6 * 8
 
 
 def test_no_gpu_fails_loudly():

@@ -1,0 +1,181 @@
+"""GPU: ordered (reference-order) early exit, evaluation accounting, resident-result initialisation, the RCCL
+communicator through the C ABI, sharded devices = single device bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as o
+from slam_decomposition_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+SQ = o.riswap_matrix(0.5)
+SEQS = [[0], [0, 0], [0, 0, 0]]
+ORDERED = _ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED
+
+
+def test_ordered_early_exit_picks_the_restart_the_sequential_loop_stops_at(hip_ctx):
+    """optimizer.py:253-295 runs the restarts one after the other and breaks at the first one below the threshold.
+    Restarts are independent here, so the run WITHOUT early exit tells what each restart ends with; with
+    SLAM_FLAG_ORDERED the stage result must be the lowest-index restart below stop_loss of that run, bit for bit,
+    whatever the launch shape."""
+    N, R, k = 24, 12, 2
+    targets = o.haar_batch(N, seed0=6100)
+    hip_ctx.set_targets(targets)
+    hip_ctx.set_gates(SQ[None])
+    stop = 1e-13
+    full = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, seed=5, flags=0, stop_loss=stop))
+    want_r = np.empty(N, dtype=np.int32)
+    for t in range(N):
+        below = np.nonzero(full["item_loss"][t] < stop)[0]
+        want_r[t] = below[0] if len(below) else int(np.argmin(full["item_loss"][t]))
+    assert np.any(want_r > 0), "test needs targets whose first restart fails"
+    for ipq in (0, 3):
+        got = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, seed=5, flags=ORDERED, stop_loss=stop, items_per_quad=ipq))
+        assert np.array_equal(got["best_restart"], want_r)
+        assert np.array_equal(got["best_loss"], full["item_loss"][np.arange(N), want_r])
+        # restarts below the winner are never pre-empted; restarts above it may be
+        for t in range(N):
+            assert np.all(got["item_status"][t, : want_r[t] + 1] != _ffi.ST_PREEMPTED)
+            assert np.array_equal(got["item_loss"][t, : want_r[t] + 1], full["item_loss"][t, : want_r[t] + 1])
+    assert np.any(got["item_status"] == _ffi.ST_PREEMPTED)
+
+
+def test_ordered_span_loop_is_bitwise_reproducible_over_runs_windows_and_launch_shapes(hip_ctx):
+    N = 40
+    hip_ctx.set_targets(o.haar_batch(N, seed0=777))
+    hip_ctx.set_gates(SQ[None])
+    prm = _ffi.OptParams(restarts=8, seed=42, flags=ORDERED)
+    whole = hip_ctx.decompose(1, 3, SEQS, prm, 1e-10)
+    again = hip_ctx.decompose(1, 3, SEQS, _ffi.OptParams(restarts=8, seed=42, flags=ORDERED, items_per_quad=4), 1e-10)
+    a = hip_ctx.decompose_range(0, 13, 1, 3, SEQS, prm, 1e-10)
+    b = hip_ctx.decompose_range(13, 27, 1, 3, SEQS, prm, 1e-10)
+    for i in range(3):
+        assert np.array_equal(whole[i], again[i])
+        assert np.array_equal(np.concatenate([a[i], b[i]]), whole[i])
+    assert np.all(whole[0] < 1e-10)
+    # the same targets as a shard of a larger job: seeds keyed on target_base + local index
+    shard = o.haar_batch(N, seed0=777)[10:25]
+    hip_ctx.set_targets(shard)
+    sh = hip_ctx.decompose(1, 3, SEQS, _ffi.OptParams(restarts=8, seed=42, flags=ORDERED, target_base=10), 1e-10)
+    for i in range(3):
+        assert np.array_equal(sh[i], whole[i][10:25])
+
+
+def test_evaluation_accounting_adds_up(hip_ctx):
+    N, R = 64, 8
+    hip_ctx.set_targets(o.haar_batch(N, seed0=4400))
+    hip_ctx.set_gates(SQ[None])
+    for flags in (0, _ffi.FLAG_EARLY_EXIT, ORDERED):
+        hip_ctx.reset_stats()
+        hip_ctx.decompose(1, 3, SEQS, _ffi.OptParams(restarts=R, seed=9, flags=flags), 1e-10)
+        st = hip_ctx.stats()
+        for k in (1, 2, 3):
+            ev, acc, pre = st["evals"][k], st["evals_accepted"][k], st["evals_preempted"][k]
+            if st["items"][k] == 0:
+                continue
+            assert ev > 0 and 0 < acc <= ev and 0 <= pre <= ev - acc
+            if flags == 0:
+                assert pre == 0
+            # at least one accepted evaluation (the initial point) per restart that ran to its own end
+            assert acc >= 1
+        if flags:
+            assert sum(st["evals_preempted"]) > 0
+    # per-item view of one stage: accepted <= evaluations, the packed counters come apart correctly
+    out = hip_ctx.minimize_stage([0, 0], _ffi.OptParams(restarts=R, seed=9, flags=0))
+    assert np.all(out["item_evals"] >= out["item_iters"] + 1)
+    assert np.all(out["item_evals"] < 1 << 20)
+
+
+def test_results_of_windows_never_decomposed_read_as_nothing_found(hip_ctx):
+    """slam_fetch_results_range of a window no call has decomposed must not return uninitialised memory."""
+    N = 50
+    hip_ctx.set_targets(o.haar_batch(N, seed0=12))
+    hip_ctx.set_gates(SQ[None])
+    prm = _ffi.OptParams(restarts=4, seed=1, flags=_ffi.FLAG_EARLY_EXIT)
+    hip_ctx.decompose_range(20, 10, 1, 3, SEQS, prm, 1e-10)
+    loss, x, cyc = hip_ctx.fetch_results_range(3, 0, N)
+    inside = np.zeros(N, bool)
+    inside[20:30] = True
+    assert np.all(np.isinf(loss[~inside])) and np.all(cyc[~inside] == -1)
+    assert np.all(np.isfinite(loss[inside])) and np.all(cyc[inside] >= 1)
+    # a list call leaves the other targets alone as well
+    hip_ctx.set_targets(o.haar_batch(N, seed0=12))
+    hip_ctx.decompose_list(np.array([3, 7, 40]), 2, 2, [[0, 0]], prm, 1e-10, k_layout=3)
+    loss, x, cyc = hip_ctx.fetch_results_range(3, 0, N)
+    assert sorted(np.nonzero(np.isfinite(loss))[0].tolist()) == [3, 7, 40]
+    assert np.all(cyc[np.isinf(loss)] == -1)
+
+
+def test_a_failing_call_leaves_the_context_usable(hip_ctx):
+    hip_ctx.set_targets(o.haar_batch(8, seed0=3))
+    hip_ctx.set_gates(SQ[None])
+    prm = _ffi.OptParams(restarts=4, seed=1, flags=_ffi.FLAG_EARLY_EXIT)
+    good = hip_ctx.decompose(1, 3, SEQS, prm, 1e-10)
+    with pytest.raises(_ffi.SlamHipError):
+        hip_ctx.decompose(1, 3, [[0], [0, 5], [0, 0, 0]], prm, 1e-10)  # gate index outside the table
+    with pytest.raises(_ffi.SlamHipError):
+        hip_ctx.decompose(1, 3, SEQS, _ffi.OptParams(restarts=4, maxiter=10**6), 1e-10)  # beyond SLAM_MAX_MAXITER
+    again = hip_ctx.decompose(1, 3, SEQS, prm, 1e-10)
+    assert np.array_equal(good[2], again[2]) and np.all(again[0] < 1e-10)
+
+
+def test_rccl_communicator_through_the_c_abi_single_rank(hip_ctx, tmp_path):
+    """slam_comm_* on a world of one rank: librccl is dlopen'ed, ncclCommInitRank / ncclAllReduce run on the GPU,
+    and the final best-loss all-reduce takes the context's RESIDENT buffer device to device.  (Several ranks need
+    several GPUs: RCCL refuses duplicate devices; the N > 1 host logic is covered by tests/test_parallel_gloo.py.)"""
+    from slam_decomposition_amd.parallel import RcclComm, merge_results
+
+    comm = RcclComm(0, 0, 1, str(tmp_path / "id"))
+    try:
+        a = np.array([3.0, -1.5, 7.25])
+        for f in (comm.allreduce_min, comm.allreduce_max, comm.allreduce_sum):
+            b = a.copy()
+            f(b)
+            assert np.array_equal(a, b)
+        comm.barrier()
+        N = 48
+        hip_ctx.set_targets(o.haar_batch(N, seed0=91))
+        hip_ctx.set_gates(SQ[None])
+        best_loss, best_x, best_cycles = hip_ctx.decompose(1, 3, SEQS, _ffi.OptParams(restarts=6, seed=2, flags=ORDERED), 1e-10)
+        # two windows of the resident results into a larger job vector, the rest stays +inf
+        comm.raw.merge_begin(N + 10)
+        comm.raw.merge_add(hip_ctx, 0, 20, 5)
+        comm.raw.merge_add(hip_ctx, 20, N - 20, 25)
+        n_below, merged = comm.raw.allreduce_min_merged(1e-8, N + 10)
+        assert np.array_equal(merged[5 : 5 + N], best_loss)
+        assert np.all(np.isinf(merged[:5])) and np.all(np.isinf(merged[5 + N :]))
+        assert n_below == int((best_loss < 1e-8).sum())
+        # host windows min-merge into the same vector
+        comm.raw.merge_begin(8)
+        comm.raw.merge_add_host(np.array([1.0, 2.0, 3.0]), 2)
+        comm.raw.merge_add_host(np.array([5.0, 0.5]), 3)
+        n_below, merged = comm.raw.allreduce_min_merged(1.5, 8)
+        assert np.array_equal(merged, [np.inf, np.inf, 1.0, 2.0, 0.5, np.inf, np.inf, np.inf]) and n_below == 2
+        with pytest.raises(_ffi.SlamHipError):
+            comm.raw.merge_add(hip_ctx, 0, N, 7)  # window beyond the merge vector
+        L, X, C = merge_results(comm, N, 0, best_loss, best_x, best_cycles)
+        assert np.array_equal(L, best_loss) and np.array_equal(X, best_x) and np.array_equal(C, best_cycles)
+    finally:
+        comm.close()
+
+
+def test_sharded_devices_equal_the_single_device_run_bit_for_bit():
+    """TemplateOptimizer(devices=[...]): every shard uploads only its own targets and keys its seeds on the global
+    target index; with the default deterministic=True the sharded job returns exactly the single-device results."""
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.gates import RiSwapGate
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    from slam_decomposition_amd.sampler import DeviceHaarBatch, HaarBatch
+
+    for sampler in (HaarBatch(seed0=4321, n_samples=13), DeviceHaarBatch(seed=5, n_samples=13)):
+        def run(**extra):
+            basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
+            opt = TemplateOptimizer(basis, BasicCost(), training_restarts=6, seed=77, **extra)
+            return opt.approximate_from_distribution(sampler)[2]
+
+        one, two, three = run(), run(devices=[0, 0]), run(devices=[0, 0, 0])
+        for a, b, c in zip(one, two, three):
+            assert a.cycles == b.cycles == c.cycles and a.success_label == b.success_label == c.success_label == 1
+            assert a.loss_result == b.loss_result == c.loss_result
+            assert np.array_equal(a.Xk, b.Xk) and np.array_equal(a.Xk, c.Xk)

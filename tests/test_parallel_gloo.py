@@ -1,7 +1,8 @@
 """CPU, world_size 2 (gloo): sharding + final merge equal the single-rank result bit for bit.
 
 The per-rank "work" here is the oracle (there is no GPU in this test); what is under test is the
-multi-GPU host logic of slam_decomposition_amd/parallel.py used by bench.py."""
+multi-GPU host logic of slam_decomposition_amd/parallel.py used by bench.py; the communicator is pluggable
+(tests/gloo_comm.py here, parallel.RcclComm -- RCCL through the C ABI -- on GPUs)."""
 import os
 import socket
 import subprocess
@@ -16,13 +17,15 @@ WORKER = textwrap.dedent(
     """
     import os, sys
     sys.path.insert(0, os.environ["SLAM_ROOT"])
+    sys.path.insert(0, os.path.join(os.environ["SLAM_ROOT"], "tests"))
     import numpy as np
     import torch.distributed as dist
     from oracle import slam_oracle as o
-    from slam_decomposition_amd.parallel import TorchDistComm, merge_results, shard_range
+    from gloo_comm import GlooComm
+    from slam_decomposition_amd.parallel import merge_results, shard_range
 
     dist.init_process_group("gloo")
-    comm = TorchDistComm()
+    comm = GlooComm()
     N = 7
     first, count = shard_range(N, comm.rank, comm.world)
     g = o.berkeley_matrix()
@@ -73,3 +76,37 @@ def test_two_rank_merge_equals_single_rank(tmp_path):
         assert r0["L"][t] == bl and r0["C"][t] == bk
         assert np.array_equal(r0["X"][t, : len(bx)], bx)
     assert np.all(r0["L"] < 1e-8) and np.all(r0["C"] == 2)
+
+
+def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path):
+    """exchange_unique_id: rank 0 publishes atomically, the others (started earlier or later) read 128 bytes."""
+    import threading
+
+    from slam_decomposition_amd.parallel import exchange_unique_id, rendezvous_path
+
+    path = str(tmp_path / "id")
+    uid = bytes(range(128))
+    got = {}
+
+    def reader(r):
+        got[r] = exchange_unique_id(r, 3, path, lambda: b"", timeout=20)
+
+    ts = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
+    ts[0].start()
+    import time
+
+    time.sleep(0.1)
+    assert exchange_unique_id(0, 3, path, lambda: uid) == uid
+    ts[1].start()
+    for t in ts:
+        t.join()
+    assert got == {1: uid, 2: uid}
+    # world 1 needs no file; ranks of one launcher derive the same path, another launcher's port a different one
+    assert exchange_unique_id(0, 1, str(tmp_path / "none"), lambda: uid) == uid
+    a = rendezvous_path({"MASTER_PORT": "29500"})
+    assert a == rendezvous_path({"MASTER_PORT": "29500"}) and a != rendezvous_path({"MASTER_PORT": "29501"})
+    assert rendezvous_path({"SLAM_COMM_FILE": "/x/y"}) == "/x/y"
+    import pytest
+
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(1, 2, str(tmp_path / "never"), lambda: uid, timeout=0.2)
