@@ -246,6 +246,30 @@ int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t co
                              double* best_loss, double* best_x, int32_t* best_cycles);
 
 /*
+ * Running best loss of resident targets [first, first + count) after every span the span loop ran for them:
+ * out[t][k - 1] = best loss after span k, NaN where the target did not run span k (solved earlier, or k outside the
+ * call's range) -- the value of the reference's "Cycle (k =...), Best Loss=..." log line (src/slam/optimizer.py:297).
+ * out: double[count][SLAM_MAX_SPAN_EVAL].
+ */
+int slam_fetch_span_losses(slam_ctx* ctx, int64_t first, int64_t count, double* out);
+
+/*
+ * slam_minimize_stage with the per-iteration trajectories the reference collects through SciPy's callback when
+ * use_callback=True (callbackF, src/slam/optimizer.py:217-224: loss and point after every BFGS iteration):
+ *   trace_loss  double[n_active][R][trace_cap]      loss after accepted step number it at [it - 1], NaN beyond item_iters
+ *   trace_x     double[n_active][R][trace_cap][n]   parameters at the same point (feed slam_eval_c1c2c3 for the
+ *                                                   coordinate trajectory of optimizer.py:223-224)
+ *   exit_loss   with SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED: a restart that ends below it stops the restarts of
+ *               HIGHER index only, so every restart up to the first successful one runs to its end -- what the
+ *               reference's sequential loop records (the span loop's success threshold, optimizer.py:287)
+ * Meant for a few targets at a time (the trace must fit 4 GiB).
+ */
+int slam_minimize_stage_trace(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
+                              const double* x0, const slam_opt_params* params, double exit_loss, int32_t trace_cap,
+                              double* best_loss, double* best_x, int32_t* best_restart, double* item_loss,
+                              int32_t* item_iters, int32_t* item_status, double* trace_loss, double* trace_x);
+
+/*
  * Objective used by every later evaluation / minimisation of this context
  * (UnitaryCostFunction subclasses, src/slam/cost_function.py):
  *   SLAM_COST_BASIC   BasicCost   1 - |Tr(T^+ U)| / d                       (cost_function.py:140-145), default

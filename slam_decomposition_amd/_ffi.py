@@ -52,6 +52,8 @@ EXPORTED_SYMBOLS = (
     "slam_decompose_list",
     "slam_decompose_range_fetch",
     "slam_fetch_results_range",
+    "slam_fetch_span_losses",
+    "slam_minimize_stage_trace",
     "slam_set_cost",
     "slam_synchronize",
     "slam_get_stats",
@@ -152,6 +154,9 @@ def load_library() -> C.CDLL:
         lib.slam_decompose_range_fetch.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P, P]
     lib.slam_decompose_list.argtypes = [P, P, C.c_int64, C.c_int, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results_range.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, P, P]
+    if hasattr(lib, "slam_minimize_stage_trace"):
+        lib.slam_fetch_span_losses.argtypes = [P, C.c_int64, C.c_int64, P]
+        lib.slam_minimize_stage_trace.argtypes = [P, C.c_int, P, P, C.c_int64, P, C.POINTER(OptParams), C.c_double, C.c_int32] + [P] * 8
     lib.slam_set_cost.argtypes = [P, C.c_int]
     lib.slam_synchronize.argtypes = [P]
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
@@ -420,6 +425,49 @@ class Context:
         best_cycles = np.empty(count, dtype=np.int32)
         _check(self._lib.slam_fetch_results_range(self._h, k_max, int(first), int(count), _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
         return best_loss, best_x, best_cycles
+
+    def fetch_span_losses(self, first: int, count: int) -> np.ndarray:
+        """Running best loss after every span the last span loop ran: float64[count, MAX_SPAN_EVAL] (NaN = span not run)."""
+        out = np.empty((count, MAX_SPAN_EVAL), dtype=np.float64)
+        _check(self._lib.slam_fetch_span_losses(self._h, int(first), int(count), _ptr(out)))
+        return out
+
+    def minimize_stage_trace(self, gate_seq: Sequence[int], params: OptParams, exit_loss: float, trace_cap: int,
+                             active: Optional[np.ndarray] = None, x0: Optional[np.ndarray] = None) -> dict:
+        """``minimize_stage`` plus the per-iteration trajectories of every restart (use_callback, optimizer.py:217-224):
+        ``trace_loss[na, R, cap]`` and ``trace_x[na, R, cap, n]`` (NaN beyond ``item_iters``)."""
+        k = len(gate_seq)
+        n = 6 * (k + 1)
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        if active is not None:
+            active = np.ascontiguousarray(active, dtype=np.int32)
+            na = active.shape[0]
+        else:
+            na = self.n_targets
+        R = int(params.restarts)
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            if x0.shape != (na, R, n):
+                raise ValueError(f"x0 must have shape [{na}, {R}, {n}]")
+        cap = int(trace_cap)
+        out = {
+            "best_loss": np.empty(na, dtype=np.float64),
+            "best_x": np.empty((na, n), dtype=np.float64),
+            "best_restart": np.empty(na, dtype=np.int32),
+            "item_loss": np.empty((na, R), dtype=np.float64),
+            "item_iters": np.empty((na, R), dtype=np.int32),
+            "item_status": np.empty((na, R), dtype=np.int32),
+            "trace_loss": np.empty((na, R, cap), dtype=np.float64),
+            "trace_x": np.empty((na, R, cap, n), dtype=np.float64),
+        }
+        _check(
+            self._lib.slam_minimize_stage_trace(
+                self._h, k, _ptr(gs), _ptr(active), na, _ptr(x0), C.byref(params), float(exit_loss), cap,
+                _ptr(out["best_loss"]), _ptr(out["best_x"]), _ptr(out["best_restart"]), _ptr(out["item_loss"]),
+                _ptr(out["item_iters"]), _ptr(out["item_status"]), _ptr(out["trace_loss"]), _ptr(out["trace_x"]),
+            )
+        )
+        return out
 
     def set_cost(self, kind: int) -> None:
         """0 = BasicCost (default), 1 = SquareCost."""

@@ -99,7 +99,10 @@ struct slam_ctx {
     DevBuf item_loss, item_x, item_iters, item_status, item_evals, item_acc;
     DevBuf stage_loss, stage_x, stage_restart;
     // decompose results
-    DevBuf best_loss, best_x, best_cycles;
+    DevBuf best_loss, best_x, best_cycles, span_loss;
+    DevBuf trace_loss, trace_x;  // slam_minimize_stage_trace
+    int32_t trace_cap = 0;       // > 0 only inside slam_minimize_stage_trace
+    double stage_exit_loss = -1.0;  // single-stage calls: >= 0 overrides stop_loss as the ordered early-exit level
     int32_t result_nmax = 0;
     int64_t result_filled = 0;  // targets whose resident results have been initialised (+inf / -1) for result_nmax
     DevBuf counters;  // StageCtl[SLAM_MAX_SPAN_EVAL + 2]: one control block per span stage (slam_kernels.hpp)
@@ -119,7 +122,7 @@ struct slam_ctx {
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &item_acc, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
+                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -285,6 +288,9 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.item_status = c->item_status.as<int32_t>();
     a.item_evals = c->item_evals.as<int32_t>();
     a.item_acc = c->item_acc.as<int32_t>();
+    a.trace_cap = c->trace_cap;
+    a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
+    a.trace_x = c->trace_cap > 0 ? c->trace_x.as<double>() : nullptr;
     { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
     // persistent wavefronts: never more blocks than can be resident, every quad pulls items.  The grid is
     // sized for the upper bound of the item count; the kernel derives the real launch shape (waves that
@@ -371,7 +377,8 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
     const double* d_stage_targets = d_active ? c->stage_targets.as<double>() : c->targets.as<double>();
     // which finished restart stops its siblings: in ordered mode the one the reference's loop breaks at -- best
     // result below the success threshold (optimizer.py:287) -- otherwise one that reached stop_loss
-    const double exit_loss = ((prm->flags & SLAM_FLAG_ORDERED) && loop) ? loop->exit_loss : prm->stop_loss;
+    const double exit_loss = ((prm->flags & SLAM_FLAG_ORDERED) && loop) ? loop->exit_loss
+                             : (((prm->flags & SLAM_FLAG_ORDERED) && c->stage_exit_loss >= 0.0) ? c->stage_exit_loss : prm->stop_loss);
     StageLaunch sl{exit_loss, gate_seq, d_stage_targets, d_active, 0, d_x0, M, prm, ctl};
     int rc;
     const int gc = classify_gates(c, k, gate_seq);
@@ -386,8 +393,8 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
         SLAM_MIN_CASE(1)
         SLAM_MIN_CASE(2)
         SLAM_MIN_CASE(3)
-        case 4: rc = launch_minimize<4, GC_DENSE>(c, sl); break;
-        case 5: rc = launch_minimize<5, GC_DENSE>(c, sl); break;
+        SLAM_MIN_CASE(4)
+        SLAM_MIN_CASE(5)
         default: return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
     }
     if (rc != SLAM_OK) return rc;
@@ -413,6 +420,7 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
         r.best_loss = c->best_loss.as<double>();
         r.best_x = c->best_x.as<double>();
         r.best_cycles = c->best_cycles.as<int32_t>();
+        r.span_loss = c->span_loss.as<double>();
     }
     if (loop && n_upper <= kEpilogueMaxTargets) {
         // small batch: reduction, bookkeeping, compaction and the next stage's inputs in one launch
@@ -466,11 +474,12 @@ int ensure_results(slam_ctx* c, int k_max) {
     HIP_TRY(c->best_loss.reserve(c->n_targets * sizeof(double)));
     HIP_TRY(c->best_x.reserve(c->n_targets * (size_t)nmax * sizeof(double)));
     HIP_TRY(c->best_cycles.reserve(c->n_targets * sizeof(int32_t)));
+    HIP_TRY(c->span_loss.reserve(c->n_targets * (size_t)kSpanLossStride * sizeof(double)));
     if (c->result_nmax != nmax || c->result_filled != c->n_targets || p0 != c->best_loss.p || p1 != c->best_cycles.p) {
         // new batch, new row width or new allocation: every target starts as "nothing found yet", so that a
         // window no call has decomposed reads as (+inf, -1) instead of uninitialised memory
         hipLaunchKernelGGL(fill_results_kernel, dim3((unsigned)((c->n_targets + 255) / 256)), dim3(256), 0, c->stream,
-                           c->best_loss.as<double>(), c->best_cycles.as<int32_t>(), c->n_targets);
+                           c->best_loss.as<double>(), c->best_cycles.as<int32_t>(), c->span_loss.as<double>(), c->n_targets);
         HIP_TRY(hipGetLastError());
         c->result_filled = c->n_targets;
     }
@@ -577,7 +586,7 @@ int decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     const bool whole = !h_list && (first == 0 && count == c->n_targets);
     if (h_list) HIP_TRY(hipMemcpyAsync(c->active.p, h_list, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)(((whole ? N : N * 16) + 255) / 256)), dim3(256), 0, c->stream,
-                       c->best_loss.as<double>(), c->best_cycles.as<int32_t>(),
+                       c->best_loss.as<double>(), c->best_cycles.as<int32_t>(), c->span_loss.as<double>(),
                        whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N, stage_ctl(c, k_min),
                        c->targets.as<double>(), c->stage_targets.as<double>(), c->solved.as<int32_t>(),
                        c->counters.as<StageCtl>(), (int32_t)(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2) / 8), h_list ? 1 : 0);
@@ -1009,6 +1018,53 @@ int slam_get_targets(slam_ctx* ctx, int64_t first, int64_t count, double* out) {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(out, ctx->targets.as<double>() + first * 32, (size_t)count * 32 * sizeof(double),
                            hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_fetch_span_losses(slam_ctx* ctx, int64_t first, int64_t count, double* out) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (ctx->result_nmax == 0 || ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no resident results");
+    if (first < 0 || count < 0 || first + count > ctx->n_targets) return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    if (count == 0) return SLAM_OK;
+    if (!out) return fail(SLAM_ERR_INVALID, "out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(out, ctx->span_loss.as<double>() + first * kSpanLossStride, (size_t)count * kSpanLossStride * sizeof(double),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+int slam_minimize_stage_trace(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
+                              const double* x0, const slam_opt_params* params, double exit_loss, int32_t trace_cap,
+                              double* best_loss, double* best_x, int32_t* best_restart, double* item_loss,
+                              int32_t* item_iters, int32_t* item_status, double* trace_loss, double* trace_x) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (!params) return fail(SLAM_ERR_INVALID, "params is NULL");
+    if (trace_cap <= 0 || !trace_loss || !trace_x) return fail(SLAM_ERR_INVALID, "trace buffers and trace_cap > 0 are required");
+    if (k < 1 || k > SLAM_MAX_SPAN_MINIMIZE) return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
+    if (!active) n_active = ctx->n_targets;
+    if (n_active <= 0 || params->restarts <= 0) return fail(SLAM_ERR_INVALID, "nothing to trace");
+    const int n = 6 * (k + 1);
+    const int64_t M = n_active * (int64_t)params->restarts;
+    const size_t rows = (size_t)M * (size_t)trace_cap;
+    if (rows * (size_t)(n + 1) * sizeof(double) > ((size_t)4 << 30))
+        return fail(SLAM_ERR_INVALID, "trace of %lld items x %d iterations exceeds 4 GiB: trace fewer targets at a time", (long long)M, trace_cap);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->trace_loss.reserve(rows * sizeof(double)));
+    HIP_TRY(ctx->trace_x.reserve(rows * n * sizeof(double)));
+    // rows that no iteration reaches read as NaN
+    HIP_TRY(hipMemsetAsync(ctx->trace_loss.p, 0xFF, rows * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->trace_x.p, 0xFF, rows * n * sizeof(double), ctx->stream));
+    ctx->trace_cap = trace_cap;
+    ctx->stage_exit_loss = exit_loss;
+    int rc = slam_minimize_stage(ctx, k, gate_seq, active, n_active, x0, params, best_loss, best_x, best_restart, item_loss, item_iters,
+                                 item_status, nullptr);
+    ctx->trace_cap = 0;
+    ctx->stage_exit_loss = -1.0;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(trace_loss, ctx->trace_loss.p, rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(trace_x, ctx->trace_x.p, rows * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
 }

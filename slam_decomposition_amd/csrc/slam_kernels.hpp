@@ -60,6 +60,11 @@ struct MinimizeArgs {
     int32_t* item_evals;      // [M]
     int32_t* item_acc;        // [M] evaluations whose point was accepted
     const double* gates;      // [K][32]: G_1..G_K of this span
+    // optional per-iteration trace (use_callback, optimizer.py:217-224): after accepted quasi-Newton step number
+    // it >= 1 of item m, trace_loss[m][it - 1] = loss and trace_x[m][it - 1][:] = parameters; nullptr = off
+    double* trace_loss;       // [M][trace_cap]
+    double* trace_x;          // [M][trace_cap][n]
+    int32_t trace_cap;
 };
 
 template <int K>
@@ -129,7 +134,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
 // All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
 template <int K, int GC>
-__global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args) {
+__global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args) {
     using C = Cfg<K>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -411,6 +416,15 @@ __global__ void __launch_bounds__(kWave, (K <= 3 ? 2 : 1)) minimize_kernel(Minim
                 g[a] = gt[a];
                 p[a] = -(qv[a] + sa * wg + va * sg);
             }
+            if (args.trace_loss && step && iters <= args.trace_cap) {  // wave-uniform pointer test: nothing when off
+                const int64_t row = (int64_t)item * args.trace_cap + (iters - 1);
+                if (q == 0) args.trace_loss[row] = f;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const int i = 4 * a + q;
+                    if (i < C::N) args.trace_x[row * C::N + i] = x[a];
+                }
+            }
         } else if (active) {
             if (fresh) {
                 f = ft;
@@ -510,7 +524,9 @@ struct ReduceArgs {
     double* best_loss;         // [n_targets]
     double* best_x;            // [n_targets][nmax]
     int32_t* best_cycles;      // [n_targets]
+    double* span_loss;         // [n_targets][kSpanLossStride]: running best after span k at [k - 1] ("Cycle (k =...), Best Loss")
 };
+constexpr int kSpanLossStride = 5;  // = SLAM_MAX_SPAN_EVAL
 
 struct EvalCounts {
     unsigned long long all = 0, accepted = 0, preempted = 0;
@@ -543,6 +559,7 @@ __device__ __forceinline__ void reduce_merge_slot(const ReduceArgs& a, int64_t s
                 for (int i = 0; i < a.n; ++i) a.best_x[t * a.nmax + i] = src[i];
                 for (int i = a.n; i < a.nmax; ++i) a.best_x[t * a.nmax + i] = 0.0;  // defined rows: nothing beyond 6 (best_cycles + 1)
             }
+            if (a.span_loss) a.span_loss[t * kSpanLossStride + (a.k - 1)] = a.best_loss[t];
         }
     }
 }
@@ -592,7 +609,7 @@ __global__ void set_n_active_kernel(StageCtl* ctl, int32_t n) { ctl->n_active = 
 // the batch is a window of the resident targets).  One thread per double2 of the window's targets.
 // list_mode: the batch is an explicit list of target indices already in `active` (slam_decompose_list)
 // instead of the window [first, first + n).
-__global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int32_t* active, int64_t first,
+__global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, double* span_loss, int32_t* active, int64_t first,
                                     int64_t n, StageCtl* first_stage, const double* targets, double* stage_targets,
                                     int32_t* solved, StageCtl* ctl_all, int32_t n_ctl_words, int32_t list_mode) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -605,6 +622,7 @@ __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int
         const int64_t tgt = list_mode ? (int64_t)active[t] : first + t;
         best_loss[tgt] = INFINITY;
         best_cycles[tgt] = -1;
+        for (int j = 0; j < kSpanLossStride; ++j) span_loss[tgt * kSpanLossStride + j] = NAN;
         solved[t] = 0;
         if (active && !list_mode) active[t] = (int32_t)tgt;
     }
@@ -616,11 +634,12 @@ __global__ void init_results_kernel(double* best_loss, int32_t* best_cycles, int
 
 // freshly (re)allocated resident results: "nothing found yet" for every target, so that windows no call has
 // decomposed read as best_loss = +inf, best_cycles = -1 instead of uninitialised memory
-__global__ void fill_results_kernel(double* best_loss, int32_t* best_cycles, int64_t n) {
+__global__ void fill_results_kernel(double* best_loss, int32_t* best_cycles, double* span_loss, int64_t n) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
         best_loss[t] = INFINITY;
         best_cycles[t] = -1;
+        for (int j = 0; j < kSpanLossStride; ++j) span_loss[t * kSpanLossStride + j] = NAN;
     }
 }
 

@@ -82,11 +82,8 @@ class TemplateOptimizer:
         else:
             # the reference raises this for objectives its objective_func does not know (optimizer.py:211)
             raise ValueError("Unrecognized Cost Function")
-        if use_callback:
-            raise NotImplementedError(
-                "use_callback=True (per-iteration loss / coordinate trajectories, optimizer.py:217-224) "
-                "is not available on the HIP path: only final values leave the GPU"
-            )
+        if use_callback and not deterministic:
+            raise ValueError("use_callback=True records the reference's sequential restart loop: it needs deterministic=True")
         if override_method not in (None, "BFGS"):
             raise NotImplementedError(f"override_method={override_method!r}: the HIP path implements BFGS only")
         if self.training_restarts <= 0:
@@ -158,13 +155,13 @@ class TemplateOptimizer:
                                     flags=prm.flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
                                     target_base=first)
                 out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
-                return out, ctx.stats()
+                return out + (ctx.fetch_span_losses(0, count),), ctx.stats()
             finally:
                 if len(self.devices) > 1:
                     ctx.close()
 
         if len(self.devices) == 1 or n < len(self.devices):
-            (best_loss, best_x, best_cycles), self.last_stats = run_shard(self.devices[0], 0, n)
+            (best_loss, best_x, best_cycles, self._span_losses), self.last_stats = run_shard(self.devices[0], 0, n)
         else:
             import threading
 
@@ -190,6 +187,7 @@ class TemplateOptimizer:
             best_loss = np.concatenate([p[0][0] for p in parts])
             best_x = np.concatenate([p[0][1] for p in parts])
             best_cycles = np.concatenate([p[0][2] for p in parts])
+            self._span_losses = np.concatenate([p[0][3] for p in parts])
             self.last_stats = [p[1] for p in parts]
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
         return best_loss, xs, best_cycles
@@ -215,14 +213,107 @@ class TemplateOptimizer:
             k = int(k)
             ctx.decompose_list(np.nonzero(spans == k)[0], k, k, [self.basis.gate_sequence(k)], prm, self.success_threshold, k_layout=k_top)
         best_loss, best_x, best_cycles = ctx.fetch_results_range(k_top, 0, len(targets))
+        self._span_losses = ctx.fetch_span_losses(0, len(targets))
         self.last_stats = ctx.stats()
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(len(targets))]
         return best_loss, xs, best_cycles
 
-    def _finish_target(self, target_coordinates, best_result, best_Xk, best_cycles, found_coordinates) -> DataDictEntry:
+    def _run_batch_callback(self, targets: np.ndarray, spans_per_target):
+        """``_run`` with ``use_callback=True`` (optimizer.py:217-224,238,287-292): the span loop is driven from the host,
+        one ``slam_minimize_stage_trace`` per template size, so that the loss and the point after every quasi-Newton
+        iteration of every restart come back.  With the ordered early exit every restart up to the first successful
+        one runs to its end, exactly the restarts the reference's sequential loop executes; what it would never have
+        started (restarts after the first success) is left out of the record.  Meant for a handful of targets.
+
+        Returns (best_loss, best_xs, best_cycles); fills ``self._callback_records[t]`` with the list of
+        (temp_training_loss, temp_coordinate_list) pairs the reference appends for target t."""
+        n = len(targets)
+        prm = self._opt_params()
+        ctx = runtime.get_context(self.devices[0])
+        ctx.set_targets(targets)
+        ctx.set_gates(self.basis.gate_matrices)
+        ctx.set_cost(self._cost_kind)
+        ctx.reset_stats()
+        R = int(self.training_restarts)
+        best = [None] * n
+        best_x = [None] * n
+        best_k = [-1] * n
+        temp_loss = [[] for _ in range(n)]  # one list per target, growing over the spans (optimizer.py:229,238)
+        self._callback_records = [[] for _ in range(n)]
+        self._span_losses = np.full((n, _ffi.MAX_SPAN_EVAL), np.nan)
+        all_ks = sorted({int(k) for ks in spans_per_target for k in ks})
+        for k in all_ks:
+            if k <= 0:
+                raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
+            if k > _ffi.MAX_SPAN_MINIMIZE:
+                raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path")
+            act = np.array([t for t in range(n) if k in spans_per_target[t] and not (best[t] is not None and best[t] < self.success_threshold)],
+                           dtype=np.int32)
+            if len(act) == 0:
+                continue
+            seq = self.basis.gate_sequence(k)
+            cap = 256
+            while True:
+                out = ctx.minimize_stage_trace(seq, prm, self.success_threshold, cap, active=act)
+                need = int(out["item_iters"].max())
+                if need <= cap:
+                    break
+                cap = need  # deterministic: the same run again, now with room for the longest restart
+            for j, t in enumerate(act):
+                temp_loss[t].extend([-1, k])  # flags for the plotting function (optimizer.py:238)
+                rows = []  # (restart, iterations) of the restarts the sequential loop runs
+                for r in range(R):
+                    it = int(out["item_iters"][j, r])
+                    temp_loss[t].extend(float(v) for v in out["trace_loss"][j, r, :it])
+                    rows.append((r, it))
+                    result = float(out["item_loss"][j, r])
+                    if best[t] is None or result < best[t]:  # optimizer.py:281-284
+                        best[t], best_k[t] = result, k
+                    hit = best[t] < self.success_threshold
+                    if hit or (self.override_fail and r == R - 1):
+                        X = np.concatenate([out["trace_x"][j, rr, :ii] for rr, ii in rows]) if rows else np.zeros((0, 6 * (k + 1)))
+                        coords = [tuple(float(v) for v in c) for c in ctx.eval_c1c2c3(seq, X)] if len(X) else []
+                        # the reference appends the SAME growing list object every time (optimizer.py:289-292)
+                        self._callback_records[t].append((temp_loss[t], coords))
+                    if hit:
+                        break
+                if best_k[t] == k:
+                    # the sequential best of this span is the stage's ordered winner: the first restart below the
+                    # threshold, else the lowest loss (first occurrence)
+                    assert best[t] == float(out["best_loss"][j])
+                    best_x[t] = out["best_x"][j].copy()
+                self._span_losses[t, k - 1] = best[t]
+        self.last_stats = ctx.stats()
+        if any(b is None for b in best):
+            raise ValueError("empty spanning range")
+        return np.array(best), best_x, np.array(best_k, dtype=np.int32)
+
+    def _log_span_loop(self, i: int, spans) -> None:
+        """The per-span log lines of ``_run`` (optimizer.py:234,297,302) for target i, from the running best loss
+        the device recorded after every span."""
+        sl = getattr(self, "_span_losses", None)
+        if sl is None:
+            return
+        for k in spans:
+            v = sl[i, k - 1] if 1 <= k <= sl.shape[1] else np.nan
+            if np.isnan(v):
+                continue
+            logging.info(f"Starting opt on template size {k}")
+            logging.info(f"Cycle (k ={k}), Best Loss={float(v)}")
+            if v < self.success_threshold:
+                logging.info(f"Break on cycle {k}")
+                break
+
+    def _finish_target(self, target_coordinates, best_result, best_Xk, best_cycles, found_coordinates, index=None) -> DataDictEntry:
         """Labelling / logging / exception of approximate_target_U (optimizer.py:80-119)."""
         logging.info(f"Overall Best Loss={best_result}")
-        self.training_loss.append(best_result)  # optimizer.py:307-309 (no callback)
+        if self.use_callback:
+            # optimizer.py:287-292: one (training_loss, coordinate_list) entry per firing of the break condition
+            for tl, cl in self._callback_records[index]:
+                self.training_loss.append(tl)
+                self.coordinate_list.append(cl)
+        else:
+            self.training_loss.append(best_result)  # optimizer.py:307-309 (no callback)
         self.best_cycle_list.append(best_cycles)
         if best_result <= self.success_threshold:
             success_label = 1
@@ -273,13 +364,22 @@ class TemplateOptimizer:
         # target_invariant (basis_abc.py:80-84) for the whole batch, on the device
         coords = [tuple(float(v) for v in c) for c in runtime.get_context(self.devices[0]).c1c2c3(stacked)]
         self.basis.assign_seed(None)  # optimizer.py:150-152
-        if self.basis.use_polytopes:
+        spans_of = None
+        if self.use_callback:
+            if self.basis.use_polytopes:
+                spans_of = [list(range(int(k), int(k) + 1)) for k in self.basis.minimal_spans(np.array(coords))]
+            else:
+                spans_of = [list(self.basis.get_spanning_range(targets[0]))] * len(targets)
+            best_loss, best_xs, best_cycles = self._run_batch_callback(stacked, spans_of)
+        elif self.basis.use_polytopes:
             # get_spanning_range per target (optimizer.py:233 with basis.py:95-100): only the template size
             # the target needs.  Targets are grouped by that size; each group is one batch.
             spans = self.basis.minimal_spans(np.array(coords))
+            spans_of = [[int(k)] for k in spans]
             best_loss, best_xs, best_cycles = self._run_batch_by_span(stacked, spans)
         else:
             spanning_range = self.basis.get_spanning_range(targets[0])
+            spans_of = [list(spanning_range)] * len(targets)
             best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)
         found = self._found_coordinates(best_xs, np.asarray(best_cycles))
         self.basis.build(n_repetitions=int(best_cycles[-1]))  # the reference leaves the template at the last size
@@ -288,6 +388,7 @@ class TemplateOptimizer:
             if log_index:
                 logging.info(f"Starting sample iter {i}")
             logging.info(f"Begin search: {coords[i]}")
+            self._log_span_loop(i, spans_of[i])
             fc = tuple(float(v) for v in found[i])
-            out.append(self._finish_target(coords[i], float(best_loss[i]), best_xs[i], int(best_cycles[i]), fc))
+            out.append(self._finish_target(coords[i], float(best_loss[i]), best_xs[i], int(best_cycles[i]), fc, index=i))
         return out

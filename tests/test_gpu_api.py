@@ -117,10 +117,12 @@ def test_gate_sample_target_swap():
 
 def test_unsupported_arguments_raise():
     basis = CircuitTemplate(maximum_span_guess=3)
-    with pytest.raises(NotImplementedError):
-        TemplateOptimizer(basis, BasicCost(), use_callback=True)
+    with pytest.raises(ValueError):
+        TemplateOptimizer(basis, BasicCost(), use_callback=True, deterministic=False)
     with pytest.raises(NotImplementedError):
         TemplateOptimizer(basis, BasicCost(), override_method="Nelder-Mead")
+    with pytest.raises(NotImplementedError):
+        CircuitTemplate(base_gates=[RiSwapGate(0.5)], use_polytopes=True, preseed=True)  # no silent no-op
 
     class Other:
         normalization = 1

@@ -179,3 +179,101 @@ def test_sharded_devices_equal_the_single_device_run_bit_for_bit():
             assert a.cycles == b.cycles == c.cycles and a.success_label == b.success_label == c.success_label == 1
             assert a.loss_result == b.loss_result == c.loss_result
             assert np.array_equal(a.Xk, b.Xk) and np.array_equal(a.Xk, c.Xk)
+
+
+def test_use_callback_records_the_sequential_restart_loop(caplog):
+    """use_callback=True (optimizer.py:217-224,238,287-292): training_loss entries are [-1, k, loss after every
+    iteration of every restart the sequential loop runs, -1, k + 1, ...], coordinate_list the Weyl coordinates of the
+    same points (reset per span).  Checked item by item against the NumPy port of the kernel's iteration
+    (oracle/bfgs_port.py) run sequentially with the reference's break rule."""
+    import logging
+
+    from oracle import bfgs_port
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.gates import RiSwapGate
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    from slam_decomposition_amd.sampler import HaarBatch
+
+    N, R, seed = 3, 4, 11
+    sampler = HaarBatch(seed0=2024, n_samples=N)
+    targets = list(sampler)
+    basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
+    opt = TemplateOptimizer(basis, BasicCost(), use_callback=True, override_fail=True, training_restarts=R, seed=seed)
+    with caplog.at_level(logging.INFO):
+        training_loss, coordinate_list, data = opt.approximate_from_distribution(sampler)
+    msgs = [r.getMessage() for r in caplog.records]
+    assert sum(m.startswith("Starting opt on template size") for m in msgs) == sum(td.cycles for td in data)
+    assert sum(m.startswith("Break on cycle") for m in msgs) == sum(td.success_label for td in data)
+    assert sum(m.startswith("Cycle (k =") for m in msgs) == sum(td.cycles for td in data)
+
+    # sequential emulation with the CPU port: same seeds (Philox keyed on seed, target, restart, k)
+    entry = 0
+    for t in range(N):
+        temp, best = [], None
+        fired = []  # (entry index, span, losses recorded in that span so far) each time the break condition fires
+        for k in (1, 2, 3):
+            temp.extend([-1, k])
+            n_span = 0
+            for r in range(R):
+                tr = []
+                f, x, it, status, nev = bfgs_port.minimize_port(o.x0_philox(seed, t, r, k), [SQ] * k, targets[t], trace=tr)
+                temp.extend(tr)
+                n_span += len(tr)
+                best = f if best is None or f < best else best
+                if best < 1e-10 or r == R - 1:
+                    fired.append((entry, k, n_span))
+                    entry += 1
+                if best < 1e-10:
+                    break
+            if best < 1e-10:
+                break
+        assert abs(best - data[t].loss_result) < 1e-9
+        # the reference appends the SAME growing list every time the condition fires (optimizer.py:289-292)
+        got = training_loss[fired[-1][0]]
+        assert all(training_loss[e] is got for e, _, _ in fired)
+        flags = [i for i, v in enumerate(got) if v == -1]
+        assert [got[i + 1] for i in flags] == list(range(1, fired[-1][1] + 1))  # [-1, 1, ..., -1, 2, ...] span markers
+        body = np.array([v for i, v in enumerate(got) if i not in flags and i - 1 not in flags])
+        ref = np.array([v for i, v in enumerate(temp) if not (v == -1 or (i > 0 and temp[i - 1] == -1))])
+        assert np.all(np.isfinite(body)) and np.all(body >= 0)
+        # the kernel's iteration follows the port; the fp32 metric's summation order can shift an iteration count by
+        # one here and there, which shifts everything recorded after it
+        assert abs(len(body) - len(ref)) <= 2 + 0.03 * len(ref), (t, len(body), len(ref))
+        if len(body) == len(ref):
+            # same trajectory: identical to many digits at first, within a factor of a few at the fp32 metric's noise level
+            # towards the end of a restart (losses fall by a decade per iteration there)
+            assert np.max(np.abs(np.log10(body + 1e-15) - np.log10(ref + 1e-15))) < 1.0, t
+        m = min(8, len(body), len(ref))
+        assert np.allclose(body[:m], ref[:m], rtol=1e-7, atol=1e-12)  # restart 0 of span 1: first iterations
+        # coordinate_list: one list per firing, reset per span, one Weyl-coordinate triple per recorded loss
+        for e, k, n_span in fired:
+            assert abs(len(coordinate_list[e]) - n_span) <= 2 + 0.03 * n_span
+            assert all(len(c) == 3 for c in coordinate_list[e])
+        span_counts = np.diff(flags + [len(got)]) - 2
+        assert len(coordinate_list[fired[-1][0]]) == span_counts[-1]
+    assert entry == len(training_loss) == len(coordinate_list)
+    assert all(td.success_label == 1 for td in data)
+
+
+def test_span_log_lines_without_callback(caplog):
+    import logging
+
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.gates import CXGate
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    from slam_decomposition_amd.sampler import HaarBatch
+
+    basis = CircuitTemplate(base_gates=[CXGate()], maximum_span_guess=3)
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=6, seed=5)
+    with caplog.at_level(logging.INFO):
+        _, _, data = opt.approximate_from_distribution(HaarBatch(seed0=1, n_samples=2))
+    msgs = [r.getMessage() for r in caplog.records]
+    # a Haar target needs three CNOTs: every target logs the three template sizes, improving losses, one break
+    for k in (1, 2, 3):
+        assert msgs.count(f"Starting opt on template size {k}") == 2
+    cyc = [float(m.split("Best Loss=")[1]) for m in msgs if m.startswith("Cycle (k =")]
+    assert len(cyc) == 6 and all(cyc[3 * i] >= cyc[3 * i + 1] >= cyc[3 * i + 2] for i in range(2))
+    assert msgs.count("Break on cycle 3") == 2
+    assert [td.loss_result for td in data] == [cyc[2], cyc[5]]

@@ -9,5 +9,5 @@ if [ -n "$REV" ]; then
 else
   SRC=.
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o slam_decomposition_amd/lib/ab/$NAME.so $SRC/slam_decomposition_amd/csrc/slam_hip.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o slam_decomposition_amd/lib/ab/$NAME.so $SRC/slam_decomposition_amd/csrc/slam_hip.hip $SRC/slam_decomposition_amd/csrc/slam_comm.hip -ldl
 echo built $NAME

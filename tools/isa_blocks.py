@@ -6,7 +6,7 @@ kern = sys.argv[2] if len(sys.argv) > 2 else "minimize_kernel"
 lines = open(path).read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*%s\w*:" % kern, l))
 end = next(i for i in range(start, len(lines)) if ".Lfunc_end" in lines[i])
-cats = [("fma64", r"v_fma_f64"), ("mul64", r"v_mul_f64"), ("add64", r"v_add_f64"), ("oth64", r"v_(max|min|rcp|rsq|cvt_f64|cvt_f32_f64|cvt_i32_f64|rndne|trunc|floor|fract|ldexp|cmp_\w+_f64|cmpx?_\w+_f64|div)\w*f64|v_cvt_f64"),
+cats = [("fma64", r"v_fma_f64|v_fmac_f64"), ("mul64", r"v_mul_f64"), ("add64", r"v_add_f64"), ("oth64", r"v_(max|min|rcp|rsq|cvt_f64|cvt_f32_f64|cvt_i32_f64|rndne|trunc|floor|fract|ldexp|cmp_\w+_f64|cmpx?_\w+_f64|div)\w*f64|v_cvt_f64"),
         ("pk32", r"v_pk_"), ("dpp", r"_dpp"), ("cnd", r"v_cndmask"), ("rdlane", r"v_readlane|v_readfirstlane"), ("wrlane", r"v_writelane"),
         ("mov", r"v_mov_b32|v_accvgpr"), ("valu_other", r"^\s+v_"), ("ds", r"^\s+ds_"), ("smem", r"s_load"), ("vmem", r"global_|scratch_|buffer_|flat_"),
         ("wait", r"s_waitcnt"), ("salu", r"^\s+s_")]
