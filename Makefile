@@ -17,3 +17,9 @@ clean:
 	rm -rf build $(OUT)
 
 .PHONY: all clean
+
+# host-side AddressSanitizer + UBSan build, driven through every C-ABI entry point's no-GPU paths (CPU only)
+asan:
+	bash tools/asan_host.sh
+
+.PHONY: asan

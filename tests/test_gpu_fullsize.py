@@ -88,3 +88,75 @@ def test_config2_sqiswap_65536x32_full_size(hip_ctx):
     st = hip_ctx.stats()
     assert st["items"][1] == 65536 * 32 and st["items"][2] == 65536 * 32
     assert st["items"][3] == int(np.sum(best_cycles == 3)) * 32  # only the unsolved targets reach k = 3
+
+
+def _check_mixed(ctx, gates, seq_of, best_loss, best_x, best_cycles, coords_t, solved):
+    """Size-independent checks for a batch decomposed with a gate SEQUENCE per span: independent re-evaluation of every
+    result, recovered Weyl coordinates of every solved target, a sample on the NumPy oracle."""
+    n = len(best_loss)
+    found = np.full((n, 3), np.nan)
+    for k in np.unique(best_cycles):
+        idx = np.nonzero(best_cycles == k)[0]
+        X = np.ascontiguousarray(best_x[idx, : 6 * (k + 1)])
+        loss, _ = ctx.eval_loss_grad(seq_of(int(k)), X, idx.astype(np.int32))
+        assert np.max(np.abs(loss - best_loss[idx])) < 1e-12
+        found[idx] = ctx.eval_c1c2c3(seq_of(int(k)), X, ndigits=-1)
+    a, b = found[solved].copy(), coords_t[solved].copy()
+    for c in (a, b):
+        face = np.abs(c[:, 2]) < 1e-4
+        c[face, 0] = np.minimum(c[face, 0], 1.0 - c[face, 0])
+    tol = np.maximum(1e-6, 3.0 * np.sqrt(np.maximum(best_loss[solved], 0.0)))[:, None]
+    assert np.all(np.abs(a - b) < tol), float(np.max(np.abs(a - b) / tol))
+    T = ctx.get_targets(0, 6)
+    for t in range(6):
+        k = int(best_cycles[t])
+        W = o.template_eval(best_x[t, : 6 * (k + 1)], [gates[g] for g in seq_of(k)])
+        assert abs(o.basic_cost(W, T[t]) - best_loss[t]) < 1e-12
+
+
+def test_config3_mixed_iswap_b_one_gpu_shard_32768x16(hip_ctx):
+    """BASELINE configs[3], one GPU's shard: iSWAP + B mixed basis, gate order [iSWAP, B, iSWAP][:k] (cycle restarted at
+    every build), 32 768 Haar targets x 16 restarts, ordered early exit.  One iSWAP reaches no
+    Haar target; iSWAP.B covers almost the whole chamber; the rest needs the third gate."""
+    gates = np.stack([o.riswap_matrix(1.0), o.berkeley_matrix()])
+    seqs = [[0], [0, 1], [0, 1, 0]]
+    hip_ctx.set_gates(gates)
+    hip_ctx.sample_haar(303, 32768)
+    prm = _ffi.OptParams(restarts=16, seed=304, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+    hip_ctx.reset_stats()
+    best_loss, best_x, best_cycles = hip_ctx.decompose(1, 3, seqs, prm, 1e-10)
+    coords = hip_ctx.targets_c1c2c3(ndigits=-1)
+    assert np.all(best_loss < 1e-8) and np.all(best_cycles >= 2)
+    assert np.mean(best_cycles == 2) > 0.95  # measured 97.8 % (DESIGN.md)
+    _check_mixed(hip_ctx, gates, lambda k: seqs[k - 1], best_loss, best_x, best_cycles, coords, np.ones(32768, bool))
+    st = hip_ctx.stats()
+    assert st["items"][1] == 32768 * 16 and st["items"][2] == 32768 * 16
+    assert st["items"][3] == int(np.sum(best_cycles == 3)) * 16
+    # reproducible: the same call again returns the same bits (SLAM_FLAG_ORDERED)
+    again = hip_ctx.decompose(1, 3, seqs, prm, 1e-10)
+    assert np.array_equal(again[0], best_loss) and np.array_equal(again[2], best_cycles) and np.array_equal(again[1], best_x)
+
+
+def test_config4_sweep_one_gpu_shard_16_bases_x_4096x16(hip_ctx):
+    """BASELINE configs[4], one GPU's shard: 16 of the 128 ConversionGain(0, 0, gc, gg, 1) bases (rank 0's column of the
+    (m, p) grid, bench.py:sweep_gate) x 4096 shared Haar targets x 16 restarts.  Output of the sweep: per-basis success
+    fraction and mean best_cycles.  Properties: every result re-evaluates to the same loss, every solved target's
+    circuit has the target's Weyl coordinates, success never decreases with the gate's strength m along the column, and
+    the iSWAP-strength basis (m = 1/2, p = 0 -> gg = pi/2: a gain-only iSWAP-class gate) solves every target with 3."""
+    import bench
+
+    hip_ctx.sample_haar(404, 4096)
+    coords = hip_ctx.targets_c1c2c3(ndigits=-1)
+    prm = _ffi.OptParams(restarts=16, seed=405, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+    seqs = [[0] * k for k in (1, 2, 3)]
+    frac, cyc = [], []
+    for j in range(16):
+        G = bench.sweep_gate(j * 8)[None]
+        hip_ctx.set_gates(G)
+        best_loss, best_x, best_cycles = hip_ctx.decompose(1, 3, seqs, prm, 1e-10)
+        solved = best_loss < 1e-8
+        frac.append(solved.mean())
+        cyc.append(best_cycles[solved].mean() if solved.any() else np.nan)
+        _check_mixed(hip_ctx, G, lambda k: [0] * k, best_loss, best_x, best_cycles, coords, solved)
+    assert all(frac[i] <= frac[i + 1] + 0.02 for i in range(15)), frac
+    assert frac[0] < 0.01 and frac[-1] == 1.0 and abs(cyc[-1] - 3.0) < 0.01, (frac, cyc)
