@@ -293,6 +293,48 @@ int slam_reset_stats(slam_ctx* ctx);
 int slam_best_loss_device_ptr(slam_ctx* ctx, void** ptr, int64_t* n);
 
 /*
+ * Templates whose 2Q gates carry their own optimisable parameters -- CircuitTemplateV2 (src/slam/basisv2.py:27-299):
+ * base_gates are gate classes / lambdas, every gate instance of the circuit gets its own "Q" parameters next to the "P"
+ * parameters of the U gates, optionally box-bounded (add_bound, basisv2.py:174-190; the reference then switches SciPy to
+ * L-BFGS-B, src/slam/optimizer.py:255-268).  Supported gate family: conversion-gain gates
+ *     G(a, phi_c, b, phi_g) = exp(-i t H),  H = gc (e^{i phi_c} A B^+ + h.c.) + gg (e^{i phi_g} A B + h.c.),  a = gc t,  b = gg t
+ * (ConversionGainGate, custom_gates.py:163-212; hamiltonian.py:84-111), which contains RiSwapGate(alpha) =
+ * G(-pi alpha / 2, 0, 0, 0) (custom_gates.py:534-606).  A slam_v2_gate says how the four raw angles, in the order
+ * (a, phi_c, b, phi_g), follow from the gate's n_params parameters q: raw[r] = scale[r] * q[sel[r]] + offset[r]
+ * (sel[r] = -1: the constant offset[r]).  n_params is 1, 2 or 4 and the same for every gate of a template.
+ *
+ * Parameter vectors are in index order: P0 .. P{6(k+1)-1} as for fixed-gate templates, then the parameters of gate 1,
+ * of gate 2, ...: n = 6 (k + 1) + n_params k.  Spans 1..SLAM_V2_MAX_SPAN.
+ *
+ *   slam_v2_set_gates        the table of parametrised base gates (host side only; replaces nothing resident)
+ *   slam_v2_eval_loss_grad   loss, gradient with respect to ALL n parameters (analytic, incl. the gate parameters) and
+ *                            (optional) the template unitary of M parameter vectors -- objective_func
+ *                            (optimizer.py:191-214) for a CircuitTemplateV2
+ *   slam_v2_minimize_stage   one span stage: per active target `restarts` projected quasi-Newton minimisations
+ *                            (BFGS metric, steps projected onto the box [bound_lo, bound_hi]; NULL bounds = none, which
+ *                            is plain BFGS as in optimizer.py:255).  Start points: x0, or U[init_lo, init_hi) per
+ *                            parameter from the Philox stream of params->seed (parameter_guess, basisv2.py:150-172:
+ *                            the bound of a bounded parameter, else (-4 pi, 4 pi)).  Every restart runs to its end; the
+ *                            stage result is the lowest-index restart below exit_loss, else the lowest loss -- the
+ *                            restart the reference's sequential loop ends with (optimizer.py:281-295).
+ *                            Outputs as in slam_minimize_stage with rows of n parameters.
+ */
+#define SLAM_V2_MAX_SPAN 3
+typedef struct slam_v2_gate {
+    int32_t n_params;
+    int32_t sel[4];
+    double scale[4];
+    double offset[4];
+} slam_v2_gate;
+int slam_v2_set_gates(slam_ctx* ctx, const slam_v2_gate* gates, int32_t n_gates);
+int slam_v2_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of, int64_t M,
+                           double* loss, double* grad, double* unitary);
+int slam_v2_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active, const double* x0,
+                           const double* init_lo, const double* init_hi, const double* bound_lo, const double* bound_hi,
+                           const slam_opt_params* params, double exit_loss, double* best_loss, double* best_x, int32_t* best_restart,
+                           double* item_loss, int32_t* item_iters, int32_t* item_status, int32_t* item_evals);
+
+/*
  * Multi-GPU: one process per GPU, RCCL over xGMI, reached through this ABI (no torch, no MPI).  The path shards by
  * target, every rank keeps all restarts of its targets, so the only exchange is the FINAL min-all-reduce of the
  * best-loss vector -- the running minimum of TemplateOptimizer._run (src/slam/optimizer.py:281-284) taken over the

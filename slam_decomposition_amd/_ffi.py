@@ -23,6 +23,7 @@ ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED 
 FLAG_EARLY_EXIT = 1
 FLAG_ORDERED = 2  # with EARLY_EXIT: the lowest-index successful restart wins (reference semantics, reproducible)
 MAX_MAXITER = 4000
+V2_MAX_SPAN = 3
 OP_SUM, OP_MAX, OP_MIN = 0, 2, 3
 COMM_ID_BYTES = 128
 COST_BASIC, COST_SQUARE = 0, 1
@@ -54,6 +55,9 @@ EXPORTED_SYMBOLS = (
     "slam_fetch_results_range",
     "slam_fetch_span_losses",
     "slam_minimize_stage_trace",
+    "slam_v2_set_gates",
+    "slam_v2_eval_loss_grad",
+    "slam_v2_minimize_stage",
     "slam_set_cost",
     "slam_synchronize",
     "slam_get_stats",
@@ -98,6 +102,16 @@ class OptParams(C.Structure):
                  items_per_quad=0, target_base=0):
         super().__init__(int(restarts), int(maxiter), float(gtol), float(stop_loss), int(seed) & 0xFFFFFFFFFFFFFFFF,
                          int(flags), int(items_per_quad), float(gtol_far), float(far_loss), int(target_base))
+
+
+class V2Gate(C.Structure):
+    """``slam_v2_gate``: raw angles (a, phi_c, b, phi_g)[r] = scale[r] * q[sel[r]] + offset[r] of a conversion-gain gate."""
+
+    _fields_ = [("n_params", C.c_int32), ("sel", C.c_int32 * 4), ("scale", C.c_double * 4), ("offset", C.c_double * 4)]
+
+    def __init__(self, n_params, sel, scale, offset):
+        super().__init__(int(n_params), (C.c_int32 * 4)(*[int(v) for v in sel]), (C.c_double * 4)(*[float(v) for v in scale]),
+                         (C.c_double * 4)(*[float(v) for v in offset]))
 
 
 class Stats(C.Structure):
@@ -157,6 +171,10 @@ def load_library() -> C.CDLL:
     if hasattr(lib, "slam_minimize_stage_trace"):
         lib.slam_fetch_span_losses.argtypes = [P, C.c_int64, C.c_int64, P]
         lib.slam_minimize_stage_trace.argtypes = [P, C.c_int, P, P, C.c_int64, P, C.POINTER(OptParams), C.c_double, C.c_int32] + [P] * 8
+    if hasattr(lib, "slam_v2_set_gates"):
+        lib.slam_v2_set_gates.argtypes = [P, C.POINTER(V2Gate), C.c_int32]
+        lib.slam_v2_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P, P]
+        lib.slam_v2_minimize_stage.argtypes = [P, C.c_int, P, P, C.c_int64, P, P, P, P, P, C.POINTER(OptParams), C.c_double] + [P] * 7
     lib.slam_set_cost.argtypes = [P, C.c_int]
     lib.slam_synchronize.argtypes = [P]
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
@@ -465,6 +483,68 @@ class Context:
                 self._h, k, _ptr(gs), _ptr(active), na, _ptr(x0), C.byref(params), float(exit_loss), cap,
                 _ptr(out["best_loss"]), _ptr(out["best_x"]), _ptr(out["best_restart"]), _ptr(out["item_loss"]),
                 _ptr(out["item_iters"]), _ptr(out["item_status"]), _ptr(out["trace_loss"]), _ptr(out["trace_x"]),
+            )
+        )
+        return out
+
+    # -- templates with parametrised 2Q gates (CircuitTemplateV2) ------------------------
+    def v2_set_gates(self, gates: Sequence["V2Gate"]) -> None:
+        arr = (V2Gate * len(gates))(*gates)
+        _check(self._lib.slam_v2_set_gates(self._h, arr, len(gates)))
+        self.v2_qn = int(gates[0].n_params)
+
+    def v2_eval(self, gate_seq: Sequence[int], x: np.ndarray, target_of: Optional[np.ndarray] = None, want_grad=True, want_unitary=False):
+        """Loss, gradient w.r.t. all n = 6 (k + 1) + QN k parameters and (optionally) W(x) for ``x[M, n]``."""
+        k = len(gate_seq)
+        n = 6 * (k + 1) + self.v2_qn * k
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != n:
+            raise ValueError(f"x must have shape [M, {n}]")
+        M = x.shape[0]
+        tof = np.zeros(M, np.int32) if target_of is None else np.ascontiguousarray(target_of, dtype=np.int32)
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        loss = np.empty(M, dtype=np.float64)
+        grad = np.empty((M, n), dtype=np.float64) if want_grad else None
+        w = np.empty((M, 4, 4, 2), dtype=np.float64) if want_unitary else None
+        _check(self._lib.slam_v2_eval_loss_grad(self._h, k, _ptr(gs), _ptr(x), _ptr(tof), M, _ptr(loss), _ptr(grad), _ptr(w)))
+        return loss, grad, (w.view(np.complex128).reshape(M, 4, 4) if want_unitary else None)
+
+    def v2_minimize_stage(self, gate_seq: Sequence[int], params: OptParams, exit_loss: float, init_lo, init_hi, bound_lo=None,
+                          bound_hi=None, active: Optional[np.ndarray] = None, x0: Optional[np.ndarray] = None) -> dict:
+        k = len(gate_seq)
+        n = 6 * (k + 1) + self.v2_qn * k
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        if active is not None:
+            active = np.ascontiguousarray(active, dtype=np.int32)
+            na = active.shape[0]
+        else:
+            na = self.n_targets
+        R = int(params.restarts)
+        vecs = []
+        for v in (init_lo, init_hi, bound_lo, bound_hi):
+            if v is not None:
+                v = np.ascontiguousarray(v, dtype=np.float64)
+                if v.shape != (n,):
+                    raise ValueError(f"per-parameter arrays must have shape [{n}]")
+            vecs.append(v)
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            if x0.shape != (na, R, n):
+                raise ValueError(f"x0 must have shape [{na}, {R}, {n}]")
+        out = {
+            "best_loss": np.empty(na, dtype=np.float64),
+            "best_x": np.empty((na, n), dtype=np.float64),
+            "best_restart": np.empty(na, dtype=np.int32),
+            "item_loss": np.empty((na, R), dtype=np.float64),
+            "item_iters": np.empty((na, R), dtype=np.int32),
+            "item_status": np.empty((na, R), dtype=np.int32),
+            "item_evals": np.empty((na, R), dtype=np.int32),
+        }
+        _check(
+            self._lib.slam_v2_minimize_stage(
+                self._h, k, _ptr(gs), _ptr(active), na, _ptr(x0), _ptr(vecs[0]), _ptr(vecs[1]), _ptr(vecs[2]), _ptr(vecs[3]),
+                C.byref(params), float(exit_loss), _ptr(out["best_loss"]), _ptr(out["best_x"]), _ptr(out["best_restart"]),
+                _ptr(out["item_loss"]), _ptr(out["item_iters"]), _ptr(out["item_status"]), _ptr(out["item_evals"]),
             )
         )
         return out

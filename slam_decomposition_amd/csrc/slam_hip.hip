@@ -4,6 +4,7 @@
 #include "slam_kernels.hpp"
 #include "slam_sampler.hpp"
 #include "slam_weyl.hpp"
+#include "slam_v2.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -100,6 +101,9 @@ struct slam_ctx {
     DevBuf stage_loss, stage_x, stage_restart;
     // decompose results
     DevBuf best_loss, best_x, best_cycles, span_loss;
+    DevBuf v2_maps, v2_bounds;   // slam_v2_*: staged gate maps [SLAM_MAX_SPAN_EVAL], (init_lo, init_hi, bound_lo, bound_hi)[n]
+    std::vector<V2GateMap> v2_gates_host;
+    int v2_qn = 0;
     DevBuf trace_loss, trace_x;  // slam_minimize_stage_trace
     int32_t trace_cap = 0;       // > 0 only inside slam_minimize_stage_trace
     double stage_exit_loss = -1.0;  // single-stage calls: >= 0 overrides stop_loss as the ordered early-exit level
@@ -122,7 +126,7 @@ struct slam_ctx {
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &item_acc, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
+                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -1102,6 +1106,281 @@ int slam_best_loss_device_ptr(slam_ctx* ctx, void** ptr, int64_t* n) {
     *ptr = ctx->best_loss.p;
     *n = ctx->n_targets;
     return SLAM_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// templates with parametrised 2Q gates (CircuitTemplateV2, src/slam/basisv2.py:27-299): slam_v2.hpp
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int K, int QN>
+constexpr size_t v2_lds_bytes() { return sizeof(double) * CfgV2<K, QN>::LDS_DOUBLES; }
+
+int v2_stage_maps(slam_ctx* c, int k, const int32_t* gate_seq, const V2GateMap** d_out) {
+    if (c->v2_gates_host.empty()) return fail(SLAM_ERR_STATE, "no parametrised gates: call slam_v2_set_gates first");
+    if (!gate_seq) return fail(SLAM_ERR_INVALID, "gate_seq is NULL");
+    V2GateMap tmp[SLAM_MAX_SPAN_EVAL];
+    for (int j = 0; j < k; ++j) {
+        if (gate_seq[j] < 0 || gate_seq[j] >= (int)c->v2_gates_host.size())
+            return fail(SLAM_ERR_INVALID, "gate_seq[%d] = %d outside the parametrised gate table (%d gates)", j, gate_seq[j], (int)c->v2_gates_host.size());
+        tmp[j] = c->v2_gates_host[(size_t)gate_seq[j]];
+    }
+    HIP_TRY(c->v2_maps.reserve(sizeof(V2GateMap) * SLAM_MAX_SPAN_EVAL));
+    HIP_TRY(hipMemcpyAsync(c->v2_maps.p, tmp, sizeof(V2GateMap) * (size_t)k, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // tmp is a stack buffer
+    *d_out = c->v2_maps.as<V2GateMap>();
+    return SLAM_OK;
+}
+
+template <int K, int QN>
+int v2_launch_eval(slam_ctx* c, const V2GateMap* d_maps, const double* d_x, const int32_t* d_tof, int64_t M, double* d_loss, double* d_grad,
+                   double* d_unitary) {
+    const size_t lds = v2_lds_bytes<K, QN>();
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_v2_kernel<K, QN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EvalV2Args<K, QN> a{};
+    a.targets = c->targets.as<double>();
+    a.x = d_x;
+    a.target_of = d_tof;
+    a.n_items = M;
+    a.loss = d_loss;
+    a.grad = d_grad;
+    a.unitary = d_unitary;
+    a.cost_kind = c->cost_kind;
+    a.maps = d_maps;
+    hipLaunchKernelGGL((eval_v2_kernel<K, QN>), dim3((unsigned)((M + kQuadsPerWave - 1) / kQuadsPerWave)), dim3(kWave), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+struct V2Stage {
+    const V2GateMap* d_maps;
+    const int32_t* d_active;
+    int32_t n_active;
+    const double* d_x0;
+    const double* d_bounds;  // init_lo | init_hi | bound_lo | bound_hi, n each
+    const slam_opt_params* prm;
+};
+
+template <int K, int QN>
+int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
+    const size_t lds = v2_lds_bytes<K, QN>();
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int n = CfgV2<K, QN>::N;
+    MinimizeV2Args<K, QN> a{};
+    a.targets = c->targets.as<double>();
+    a.active = sgt.d_active;
+    a.n_active = sgt.n_active;
+    a.restarts = sgt.prm->restarts;
+    a.x0 = sgt.d_x0;
+    a.init_lo = sgt.d_bounds;
+    a.init_hi = sgt.d_bounds + n;
+    a.bound_lo = sgt.d_bounds + 2 * n;
+    a.bound_hi = sgt.d_bounds + 3 * n;
+    a.maxiter = sgt.prm->maxiter;
+    a.gtol = sgt.prm->gtol;
+    a.stop_loss = sgt.prm->stop_loss;
+    a.gtol_far = sgt.prm->gtol_far;
+    a.far_loss = sgt.prm->far_loss;
+    a.seed = sgt.prm->seed;
+    a.target_base = sgt.prm->target_base;
+    a.cost_kind = c->cost_kind;
+    a.maps = sgt.d_maps;
+    a.item_loss = c->item_loss.as<double>();
+    a.item_x = c->item_x.as<double>();
+    a.item_iters = c->item_iters.as<int32_t>();
+    a.item_status = c->item_status.as<int32_t>();
+    a.item_evals = c->item_evals.as<int32_t>();
+    a.item_acc = c->item_acc.as<int32_t>();
+    a.ctl = stage_ctl(c, K);
+    const int64_t M = (int64_t)sgt.n_active * sgt.prm->restarts;
+    hipLaunchKernelGGL((minimize_v2_kernel<K, QN>), dim3((unsigned)((M + kQuadsPerWave - 1) / kQuadsPerWave)), dim3(kWave), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+#define SLAM_V2_DISPATCH(FN, ...)                                                                             \
+    do {                                                                                                      \
+        const int key = k * 10 + c->v2_qn;                                                                    \
+        switch (key) {                                                                                        \
+            case 11: rc = FN<1, 1>(__VA_ARGS__); break;                                                       \
+            case 12: rc = FN<1, 2>(__VA_ARGS__); break;                                                       \
+            case 14: rc = FN<1, 4>(__VA_ARGS__); break;                                                       \
+            case 21: rc = FN<2, 1>(__VA_ARGS__); break;                                                       \
+            case 22: rc = FN<2, 2>(__VA_ARGS__); break;                                                       \
+            case 24: rc = FN<2, 4>(__VA_ARGS__); break;                                                       \
+            case 31: rc = FN<3, 1>(__VA_ARGS__); break;                                                       \
+            case 32: rc = FN<3, 2>(__VA_ARGS__); break;                                                       \
+            case 34: rc = FN<3, 4>(__VA_ARGS__); break;                                                       \
+            default: rc = fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates: spans 1..%d with 1, 2 or 4 parameters per gate (got span %d, %d)", \
+                               SLAM_V2_MAX_SPAN, k, c->v2_qn);                                                \
+        }                                                                                                     \
+    } while (0)
+
+int v2_eval_body(slam_ctx* c, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of, int64_t M, double* loss,
+                 double* grad, double* unitary) {
+    if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
+    if (k < 1 || k > SLAM_V2_MAX_SPAN) return fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates support spans 1..%d (got %d)", SLAM_V2_MAX_SPAN, k);
+    if (M < 0) return fail(SLAM_ERR_INVALID, "M < 0");
+    if (M == 0) return SLAM_OK;
+    if (!x || !target_of || !loss) return fail(SLAM_ERR_INVALID, "x, target_of and loss must be non-NULL");
+    for (int64_t m = 0; m < M; ++m)
+        if (target_of[m] < 0 || target_of[m] >= c->n_targets) return fail(SLAM_ERR_INVALID, "target_of[%lld] outside the resident batch", (long long)m);
+    const V2GateMap* d_maps = nullptr;
+    int rc = v2_stage_maps(c, k, gate_seq, &d_maps);
+    if (rc) return rc;
+    const int n = 6 * (k + 1) + c->v2_qn * k;
+    HIP_TRY(c->ev_x.reserve((size_t)M * n * sizeof(double)));
+    HIP_TRY(c->ev_tof.reserve((size_t)M * sizeof(int32_t)));
+    HIP_TRY(c->ev_loss.reserve((size_t)M * sizeof(double)));
+    if (grad) HIP_TRY(c->ev_grad.reserve((size_t)M * n * sizeof(double)));
+    if (unitary) HIP_TRY(c->ev_unitary.reserve((size_t)M * 32 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->ev_x.p, x, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ev_tof.p, target_of, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    double* d_grad = grad ? c->ev_grad.as<double>() : nullptr;
+    double* d_unit = unitary ? c->ev_unitary.as<double>() : nullptr;
+    SLAM_V2_DISPATCH(v2_launch_eval, c, d_maps, c->ev_x.as<double>(), c->ev_tof.as<int32_t>(), M, c->ev_loss.as<double>(), d_grad, d_unit);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(loss, c->ev_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (grad) HIP_TRY(hipMemcpyAsync(grad, c->ev_grad.p, (size_t)M * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (unitary) HIP_TRY(hipMemcpyAsync(unitary, c->ev_unitary.p, (size_t)M * 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active, const double* x0,
+                     const double* init_lo, const double* init_hi, const double* bound_lo, const double* bound_hi,
+                     const slam_opt_params* prm, double exit_loss, double* best_loss, double* best_x, int32_t* best_restart,
+                     double* item_loss, int32_t* item_iters, int32_t* item_status, int32_t* item_evals) {
+    if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
+    if (k < 1 || k > SLAM_V2_MAX_SPAN) return fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates support spans 1..%d (got %d)", SLAM_V2_MAX_SPAN, k);
+    int rc = check_params(prm);
+    if (rc) return rc;
+    if (!active) n_active = c->n_targets;
+    if (n_active <= 0) return n_active == 0 ? SLAM_OK : fail(SLAM_ERR_INVALID, "n_active < 0");
+    if (!best_loss || !best_x) return fail(SLAM_ERR_INVALID, "best_loss and best_x must be non-NULL");
+    if (!init_lo || !init_hi) return fail(SLAM_ERR_INVALID, "init_lo and init_hi must be non-NULL");
+    const V2GateMap* d_maps = nullptr;
+    rc = v2_stage_maps(c, k, gate_seq, &d_maps);
+    if (rc) return rc;
+    const int n = 6 * (k + 1) + c->v2_qn * k;
+    const int64_t M = n_active * (int64_t)prm->restarts;
+    std::vector<double> b((size_t)4 * n);
+    for (int i = 0; i < n; ++i) {
+        b[i] = init_lo[i];
+        b[n + i] = init_hi[i];
+        b[2 * n + i] = bound_lo ? bound_lo[i] : -INFINITY;
+        b[3 * n + i] = bound_hi ? bound_hi[i] : INFINITY;
+        if (!(b[i] <= b[n + i]) || !std::isfinite(b[i]) || !std::isfinite(b[n + i]))
+            return fail(SLAM_ERR_INVALID, "start range of parameter %d must be finite with lo <= hi", i);
+        if (!(b[2 * n + i] <= b[3 * n + i])) return fail(SLAM_ERR_INVALID, "bounds of parameter %d: lo > hi", i);
+    }
+    const int32_t* d_active = nullptr;
+    if (active) {
+        for (int64_t s2 = 0; s2 < n_active; ++s2)
+            if (active[s2] < 0 || active[s2] >= c->n_targets) return fail(SLAM_ERR_INVALID, "active[%lld] outside the resident batch", (long long)s2);
+        HIP_TRY(c->active.reserve((size_t)n_active * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(c->active.p, active, (size_t)n_active * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        d_active = c->active.as<int32_t>();
+    }
+    const double* d_x0 = nullptr;
+    if (x0) {
+        for (int64_t i = 0; i < M * n; ++i)
+            if (!(x0[i] > -1e8 && x0[i] < 1e8)) return fail(SLAM_ERR_INVALID, "x0[%lld] = %g: explicit seeds must be finite with |x| < 1e8", (long long)i, x0[i]);
+        HIP_TRY(c->x0.reserve((size_t)M * n * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->x0.p, x0, (size_t)M * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        d_x0 = c->x0.as<double>();
+    }
+    HIP_TRY(c->v2_bounds.reserve(b.size() * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->v2_bounds.p, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // b is a local buffer
+    {
+        // stage buffers sized for n parameters per item (reserve_stage_buffers sizes for 6 (k + 1))
+        HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
+        HIP_TRY(c->item_x.reserve(M * n * sizeof(double)));
+        HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
+        HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
+        HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
+        HIP_TRY(c->item_acc.reserve(M * sizeof(int32_t)));
+        HIP_TRY(c->stage_loss.reserve(n_active * sizeof(double)));
+        HIP_TRY(c->stage_x.reserve(n_active * n * sizeof(double)));
+        HIP_TRY(c->stage_restart.reserve(n_active * sizeof(int32_t)));
+    }
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), c->stream));
+    hipLaunchKernelGGL(set_n_active_kernel, dim3(1), dim3(1), 0, c->stream, stage_ctl(c, k), (int32_t)n_active);
+    HIP_TRY(hipGetLastError());
+    V2Stage sgt{d_maps, d_active, (int32_t)n_active, d_x0, c->v2_bounds.as<double>(), prm};
+    SLAM_V2_DISPATCH(v2_launch_minimize, c, sgt);
+    if (rc) return rc;
+    ReduceArgs r{};
+    r.item_loss = c->item_loss.as<double>();
+    r.item_x = c->item_x.as<double>();
+    r.item_evals = c->item_evals.as<int32_t>();
+    r.item_acc = c->item_acc.as<int32_t>();
+    r.item_status = c->item_status.as<int32_t>();
+    r.exit_loss = exit_loss;
+    r.ordered = 1;  // every restart ran to its end: the winner is the one the reference's sequential loop breaks at
+    r.ctl = stage_ctl(c, k);
+    r.restarts = prm->restarts;
+    r.n = n;
+    r.stage_loss = c->stage_loss.as<double>();
+    r.stage_x = c->stage_x.as<double>();
+    r.stage_restart = c->stage_restart.as<int32_t>();
+    hipLaunchKernelGGL(reduce_merge_kernel, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, c->stream, r);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(best_loss, c->stage_loss.p, (size_t)n_active * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(best_x, c->stage_x.p, (size_t)n_active * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (best_restart) HIP_TRY(hipMemcpyAsync(best_restart, c->stage_restart.p, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (item_loss) HIP_TRY(hipMemcpyAsync(item_loss, c->item_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (item_iters) HIP_TRY(hipMemcpyAsync(item_iters, c->item_iters.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (item_status) HIP_TRY(hipMemcpyAsync(item_status, c->item_status.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (item_evals) HIP_TRY(hipMemcpyAsync(item_evals, c->item_evals.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slam_v2_set_gates(slam_ctx* ctx, const slam_v2_gate* gates, int32_t n_gates) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (!gates || n_gates <= 0 || n_gates > SLAM_MAX_GATES) return fail(SLAM_ERR_INVALID, "n_gates must be in 1..%d", SLAM_MAX_GATES);
+    const int qn = gates[0].n_params;
+    if (qn != 1 && qn != 2 && qn != 4) return fail(SLAM_ERR_UNSUPPORTED, "parametrised gates take 1, 2 or 4 parameters (got %d)", qn);
+    std::vector<V2GateMap> tmp((size_t)n_gates);
+    for (int g = 0; g < n_gates; ++g) {
+        if (gates[g].n_params != qn) return fail(SLAM_ERR_UNSUPPORTED, "all parametrised gates of a template must take the same number of parameters");
+        for (int r = 0; r < 4; ++r) {
+            if (gates[g].sel[r] < -1 || gates[g].sel[r] >= qn) return fail(SLAM_ERR_INVALID, "gate %d: sel[%d] = %d outside [-1, %d)", g, r, gates[g].sel[r], qn);
+            if (!std::isfinite(gates[g].scale[r]) || !std::isfinite(gates[g].offset[r])) return fail(SLAM_ERR_INVALID, "gate %d: non-finite map", g);
+            tmp[(size_t)g].sel[r] = gates[g].sel[r];
+            tmp[(size_t)g].scale[r] = gates[g].sel[r] < 0 ? 0.0 : gates[g].scale[r];
+            tmp[(size_t)g].offset[r] = gates[g].offset[r];
+            tmp[(size_t)g].pad[r] = 0;
+        }
+    }
+    ctx->v2_gates_host.swap(tmp);
+    ctx->v2_qn = qn;
+    return SLAM_OK;
+}
+
+int slam_v2_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of, int64_t M,
+                           double* loss, double* grad, double* unitary) {
+    return drained(ctx, v2_eval_body(ctx, k, gate_seq, x, target_of, M, loss, grad, unitary));
+}
+
+int slam_v2_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active, const double* x0,
+                           const double* init_lo, const double* init_hi, const double* bound_lo, const double* bound_hi,
+                           const slam_opt_params* params, double exit_loss, double* best_loss, double* best_x, int32_t* best_restart,
+                           double* item_loss, int32_t* item_iters, int32_t* item_status, int32_t* item_evals) {
+    return drained(ctx, v2_minimize_body(ctx, k, gate_seq, active, n_active, x0, init_lo, init_hi, bound_lo, bound_hi, params, exit_loss,
+                                         best_loss, best_x, best_restart, item_loss, item_iters, item_status, item_evals));
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@ import numpy as np
 
 from . import _ffi, runtime
 from .basis import CircuitTemplate
+from .basisv2 import CircuitTemplateV2
 from .basis_abc import DataDictEntry, VariationalTemplate
 from .cost_function import BasicCost, SquareCost, UnitaryCostFunction
 from .sampler import SampleFunction
@@ -73,8 +74,13 @@ class TemplateOptimizer:
         assert not (self.preseeding and self.override_fail)
         assert not (self.preseeding and self.basis.n_qubits != 2)
 
-        if not isinstance(basis, CircuitTemplate):
-            raise NotImplementedError("the HIP optimizer needs a slam_decomposition_amd CircuitTemplate")
+        if not isinstance(basis, (CircuitTemplate, CircuitTemplateV2)):
+            raise NotImplementedError("the HIP optimizer needs a slam_decomposition_amd CircuitTemplate / CircuitTemplateV2")
+        self._v2 = isinstance(basis, CircuitTemplateV2)
+        if self._v2 and (use_callback or (devices is not None and len(devices) > 1)):
+            raise NotImplementedError("CircuitTemplateV2 on the HIP path: use_callback and several devices are not implemented")
+        if self._v2 and basis.using_constraints:
+            raise NotImplementedError("cost constraints (SLSQP, optimizer.py:260-265) are not implemented on the HIP path")
         if isinstance(self.objective, SquareCost):
             self._cost_kind = _ffi.COST_SQUARE
         elif isinstance(self.objective, BasicCost):
@@ -84,7 +90,7 @@ class TemplateOptimizer:
             raise ValueError("Unrecognized Cost Function")
         if use_callback and not deterministic:
             raise ValueError("use_callback=True records the reference's sequential restart loop: it needs deterministic=True")
-        if override_method not in (None, "BFGS"):
+        if override_method not in (None, "BFGS") and not (self._v2 and override_method == "L-BFGS-B"):
             raise NotImplementedError(f"override_method={override_method!r}: the HIP path implements BFGS only")
         if self.training_restarts <= 0:
             raise ValueError("training_restarts must be positive")
@@ -218,6 +224,44 @@ class TemplateOptimizer:
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(len(targets))]
         return best_loss, xs, best_cycles
 
+    def _run_batch_v2(self, targets: np.ndarray, spanning_range):
+        """``_run`` for a CircuitTemplateV2 (optimizer.py:233-303 with method "L-BFGS-B" when the template has bounds, "BFGS"
+        otherwise, :255-268): the span loop is driven from the host, one ``slam_v2_minimize_stage`` per template size over the
+        targets still unsolved.  Every restart runs to its end on the device; a stage's result is the restart the
+        reference's sequential loop ends with (the first one below the threshold, else the lowest loss)."""
+        basis = self.basis
+        n = len(targets)
+        prm = self._opt_params()
+        ctx = runtime.get_context(self.devices[0])
+        ctx.set_targets(targets)
+        ctx.v2_set_gates(basis._gate_maps)
+        ctx.set_cost(self._cost_kind)
+        best = np.full(n, np.inf)
+        best_x = [None] * n
+        best_k = np.full(n, -1, dtype=np.int32)
+        self._span_losses = np.full((n, _ffi.MAX_SPAN_EVAL), np.nan)
+        for k in spanning_range:
+            k = int(k)
+            if k <= 0:
+                raise ValueError()  # build(n_repetitions <= 0), basisv2.py:221-222
+            if k > _ffi.V2_MAX_SPAN:
+                raise NotImplementedError(f"parametrised-gate templates run spans 1..{_ffi.V2_MAX_SPAN} on the HIP path (got {k})")
+            act = np.nonzero(~(best < self.success_threshold))[0].astype(np.int32)
+            if len(act) == 0:
+                break
+            basis.build(k)
+            _, idx, init_lo, init_hi, blo, bhi = basis.device_layout(k)
+            out = ctx.v2_minimize_stage(basis.gate_sequence(k), prm, self.success_threshold, init_lo, init_hi, blo, bhi, active=act)
+            for j, t in enumerate(act):
+                if best_k[t] < 0 or out["best_loss"][j] < best[t]:  # optimizer.py:281-284
+                    best[t], best_k[t] = out["best_loss"][j], k
+                    best_x[t] = out["best_x"][j][idx].copy()  # user parameters (index order)
+                self._span_losses[t, k - 1] = best[t]
+        if np.any(best_k < 0):
+            raise ValueError("empty spanning range")
+        self.last_stats = ctx.stats()
+        return best, best_x, best_k
+
     def _run_batch_callback(self, targets: np.ndarray, spans_per_target):
         """``_run`` with ``use_callback=True`` (optimizer.py:217-224,238,287-292): the span loop is driven from the host,
         one ``slam_minimize_stage_trace`` per template size, so that the loss and the point after every quasi-Newton
@@ -331,6 +375,14 @@ class TemplateOptimizer:
         n = len(best_xs)
         found = np.zeros((n, 3))
         ctx = runtime.get_context(self.devices[0])
+        if self._v2:
+            for k in np.unique(best_cycles):
+                idx = np.nonzero(best_cycles == k)[0]
+                self.basis.build(int(k))
+                X = self.basis.to_device_vector(np.stack([best_xs[i] for i in idx]), int(k))
+                _, _, W = ctx.v2_eval(self.basis.gate_sequence(int(k)), X, want_grad=False, want_unitary=True)
+                found[idx] = ctx.c1c2c3(W)
+            return found
         ctx.set_gates(self.basis.gate_matrices)
         if ctx.n_targets == 0:
             ctx.set_targets(np.eye(4, dtype=np.complex128)[None])
@@ -365,7 +417,11 @@ class TemplateOptimizer:
         coords = [tuple(float(v) for v in c) for c in runtime.get_context(self.devices[0]).c1c2c3(stacked)]
         self.basis.assign_seed(None)  # optimizer.py:150-152
         spans_of = None
-        if self.use_callback:
+        if self._v2:
+            spanning_range = list(self.basis.get_spanning_range(targets[0]))
+            spans_of = [spanning_range] * len(targets)
+            best_loss, best_xs, best_cycles = self._run_batch_v2(stacked, spanning_range)
+        elif self.use_callback:
             if self.basis.use_polytopes:
                 spans_of = [list(range(int(k), int(k) + 1)) for k in self.basis.minimal_spans(np.array(coords))]
             else:

@@ -1,0 +1,193 @@
+"""GPU: templates with parametrised 2Q gates -- CircuitTemplateV2 (src/slam/basisv2.py:27-299).
+Loss, template unitary and the gradient with respect to the U-gate AND the gate parameters against the NumPy oracle
+(oracle/v2_oracle.py); the projected quasi-Newton loop against SciPy's L-BFGS-B / BFGS on the oracle; the reference's own
+recorded V2 + SquareCost run (scripts/decomp_trajectory.ipynb:84-90,140-162)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.optimize as opt
+
+from oracle import slam_oracle as o
+from oracle import v2_oracle as v
+from slam_decomposition_amd import _ffi
+from slam_decomposition_amd.basisv2 import CircuitTemplateV2, gate_map
+from slam_decomposition_amd.cost_function import BasicCost, SquareCost
+from slam_decomposition_amd.gates import ConversionGainGate, RiSwapGate, SwapGate
+from slam_decomposition_amd.optimizer import TemplateOptimizer
+from slam_decomposition_amd.sampler import GateSample, HaarBatch
+
+pytestmark = pytest.mark.gpu
+
+GATE_FNS = {
+    "riswap": RiSwapGate,                                                       # 1 parameter (decomp_trajectory.ipynb cell 5)
+    "cg_gc_gg": lambda gc, gg: ConversionGainGate(0.3, -0.2, gc, gg, 1.5),      # 2: drive strengths (parallel_drive_volume.py:91-96)
+    "cg_phases": lambda p1, p2: ConversionGainGate(p1, p2, 0.9, 0.4, 1.0),      # 2: phases (family_extend.py:40-47)
+    "cg_3": lambda p1, g1, g2: ConversionGainGate(p1, 0.1, g1, g2, 0.8),        # 3 -> padded to 4 on the device
+    "cg_4": lambda p1, p2, g1, g2: ConversionGainGate(p1, p2, g1, g2, 0.7),     # 4
+}
+
+
+@pytest.mark.parametrize("name", sorted(GATE_FNS))
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("vz_only", [False, True])
+def test_v2_loss_unitary_and_full_gradient_match_the_oracle(hip_ctx, name, k, vz_only):
+    fn = GATE_FNS[name]
+    qn, sel, scale, off = gate_map(fn)
+    basis = CircuitTemplateV2(base_gates=[fn], vz_only=vz_only)
+    basis.build(k)
+    rng = np.random.default_rng(100 * k + qn)
+    M = 37
+    targets = o.haar_batch(5, seed0=31)
+    X = rng.uniform(-4 * np.pi, 4 * np.pi, (M, basis.n_params))
+    tof = rng.integers(0, 5, M).astype(np.int32)
+    hip_ctx.set_targets(targets)
+    hip_ctx.v2_set_gates(basis._gate_maps)
+    for square, kind in ((False, _ffi.COST_BASIC), (True, _ffi.COST_SQUARE)):
+        hip_ctx.set_cost(kind)
+        loss, grad, W = hip_ctx.v2_eval(basis.gate_sequence(), basis.to_device_vector(X), tof, want_unitary=True)
+        _, idx, *_ = basis.device_layout(k)
+        fns = [lambda *q: fn(*q).to_matrix()] * k
+        for m in range(M):
+            Wref = v.template_eval(X[m], fns, qn, k, vz_only)   # built from the gate OBJECTS' own matrices
+            if vz_only:
+                # rz(l) = e^{-i l / 2} U(0, 0, l): the device template differs by a global phase only
+                ph = np.vdot(Wref.ravel(), W[m].ravel())
+                assert abs(abs(ph) - 4.0) < 1e-11
+                assert np.max(np.abs(W[m] - Wref * ph / abs(ph))) < 1e-12
+            else:
+                assert np.max(np.abs(W[m] - Wref)) < 1e-12
+            f, g = v.loss_and_grad(X[m], [(sel, scale, off)] * k, qn, k, targets[tof[m]], vz_only, square)
+            assert abs(loss[m] - f) < 1e-12
+            assert np.max(np.abs(grad[m][idx] - g)) < 1e-12        # U-gate and GATE parameters
+            fixed = np.setdiff1d(np.arange(grad.shape[1]), idx)    # device slots no user parameter maps to
+            assert fixed.size == grad.shape[1] - basis.n_params
+    hip_ctx.set_cost(_ffi.COST_BASIC)
+
+
+def test_oracle_gradient_is_the_derivative_of_the_gate_objects_loss():
+    """The oracle's analytic gradient (angle maps) against central differences of the loss built from the gate callables."""
+    T = o.haar_unitary(5)
+    rng = np.random.default_rng(0)
+    for name, fn in GATE_FNS.items():
+        qn, sel, scale, off = gate_map(fn)
+        for k, vz in ((1, False), (3, True), (2, False)):
+            x = rng.uniform(-3, 3, (2 if vz else 6) * (k + 1) + qn * k)
+            fns = [lambda *q: fn(*q).to_matrix()] * k
+            f, g = v.loss_and_grad(x, [(sel, scale, off)] * k, qn, k, T, vz)
+            assert abs(f - v.loss(x, fns, qn, k, T, vz)) < 1e-14
+            assert np.max(np.abs(g - v.fd_grad(x, fns, qn, k, T, vz))) < 2e-9
+
+
+def test_recorded_v2_square_cost_run_kat1():
+    """scripts/decomp_trajectory.ipynb:84-90,140-162: CircuitTemplateV2(base_gates=[RiSwapGate]), every Q bounded to
+    [0.5, 0.5], SquareCost, target SWAP: the recorded bound parameters give the recorded loss and coordinates on the device."""
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat1.json")))
+    x = np.array(kat["params"], dtype=np.float64)
+    basis = CircuitTemplateV2(n_qubits=2, base_gates=[RiSwapGate], edge_params=[[(0, 1)]])
+    basis.build(3)
+    basis.spanning_range = range(3, 4)
+    for name in basis.parameter_names():
+        if "Q" in name:
+            basis.add_bound(name, 0.5, 0.5)
+    Xk = np.concatenate([x, [0.5, 0.5, 0.5]])
+    W = basis.eval(Xk)
+    assert abs(SquareCost().unitary_fidelity(W, SwapGate().to_matrix()) - kat["square_cost_vs_swap"]) < 1e-14  # 1 - (|t|^2 + 4) / 20 at 3.6e-9: a few ulp of 1
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    assert tuple(c1c2c3(W)) == tuple(kat["c1c2c3_full"])
+    assert abs(basis.circuit_cost(Xk) - 1.5) < 1e-12 and abs(basis.circuit_fidelity(Xk) - 0.125) < 1e-12
+    # the optimizer run of that cell: success at k = 3, Q stay at their bound
+    opt3 = TemplateOptimizer(basis=basis, objective=SquareCost(), use_callback=False, override_fail=True, success_threshold=1e-7,
+                             training_restarts=25, seed=3)
+    td = opt3.approximate_target_U(SwapGate().to_matrix())
+    assert td.success_label == 1 and td.cycles == 3 and td.loss_result < 1e-7
+    assert np.array_equal(np.asarray(td.Xk)[-3:], [0.5, 0.5, 0.5])
+    basis.build(3)
+    assert np.max(np.abs(np.array(c1c2c3(basis.eval(td.Xk))) - 0.5)) < 1e-3  # |coordinate error| ~ sqrt(loss)
+
+
+def _scipy_best(fn, qn, k, target, bounds, x0s, square=False):
+    best = np.inf
+    gm = gate_map(fn)[1:]
+    for x0 in x0s:
+        res = opt.minimize(lambda xx: v.loss_and_grad(xx, [gm] * k, qn, k, target, False, square), x0, jac=True,
+                           method="L-BFGS-B" if bounds is not None else "BFGS", bounds=bounds, options={"maxiter": 2500})
+        best = min(best, res.fun)
+    return best
+
+
+def test_free_gate_parameters_reach_what_scipy_reaches():
+    """RiSwapGate with a FREE alpha per gate, k = 2, no bounds (plain BFGS): any 2-qubit gate is two iSWAP-family gates
+    away once alpha is free (e.g. one of them iSWAP-class), so every Haar target is solved at k <= 2 -- and the device's
+    converged loss matches SciPy BFGS on the oracle from the same starts to 1e-6."""
+    N, R = 6, 8
+    sampler = HaarBatch(seed0=555, n_samples=N)
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=2)
+    optm = TemplateOptimizer(basis, BasicCost(), training_restarts=R, seed=12, override_fail=True)
+    _, _, data = optm.approximate_from_distribution(sampler)
+    targets = list(sampler)
+    for t, td in enumerate(data):
+        basis.build(td.cycles)
+        assert abs(o.basic_cost(basis.eval(td.Xk), targets[t]) - td.loss_result) < 1e-12
+        assert td.cycles == 2 and td.success_label == 1 and td.loss_result < 1e-10
+        rng = np.random.default_rng(t)
+        ref = _scipy_best(RiSwapGate, 1, 2, targets[t], None, [rng.uniform(-4 * np.pi, 4 * np.pi, 20) for _ in range(R)])
+        assert abs(ref - td.loss_result) < 1e-6
+
+
+def test_bounded_gate_parameters_match_scipy_lbfgsb():
+    """add_bound on every Q (0 <= alpha <= 0.3: gates weaker than sqrt(iSWAP), so k = 2 cannot reach a generic target and the
+    optimum sits ON the bounds): best-of-restarts loss of the projected quasi-Newton loop vs SciPy L-BFGS-B on the oracle,
+    same bounds, to 1e-6; bounds respected exactly."""
+    target = o.haar_unitary(77)
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=2)
+    basis.build(2)
+    basis.spanning_range = range(2, 3)
+    for name in basis.parameter_names():
+        if name.startswith("Q"):
+            basis.add_bound(name, 0.3, 0.0)
+    R = 24
+    optm = TemplateOptimizer(basis, BasicCost(), training_restarts=R, seed=5, override_fail=True)
+    td = optm.approximate_target_U(target)
+    x = np.asarray(td.Xk)
+    assert td.success_label == 0 and td.cycles == 2
+    assert np.all(x[-2:] >= 0.0) and np.all(x[-2:] <= 0.3) and np.all(np.abs(x[:-2]) <= 4 * np.pi)
+    basis.build(2)
+    assert abs(o.basic_cost(basis.eval(x), target) - td.loss_result) < 1e-12
+    bounds = [(-4 * np.pi, 4 * np.pi)] * 18 + [(0.0, 0.3)] * 2  # basisv2.py:160-169: every parameter is bounded once one is
+    rng = np.random.default_rng(1)
+    ref = _scipy_best(RiSwapGate, 1, 2, target, bounds, [np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, 18), rng.uniform(0, 0.3, 2)]) for _ in range(R)])
+    assert abs(ref - td.loss_result) < 1e-6, (ref, td.loss_result)
+    assert np.max(x[-2:]) > 0.3 - 1e-9  # the optimum uses the strongest gate allowed
+
+
+def test_v2_stage_restart_order_and_errors(hip_ctx):
+    fn = GATE_FNS["cg_gc_gg"]
+    basis = CircuitTemplateV2(base_gates=[fn])
+    hip_ctx.set_targets(o.haar_batch(4, seed0=9))
+    hip_ctx.v2_set_gates(basis._gate_maps)
+    _, idx, ilo, ihi, blo, bhi = basis.device_layout(2)
+    prm = _ffi.OptParams(restarts=6, seed=4)
+    out = hip_ctx.v2_minimize_stage([0, 0], prm, 1e-10, ilo, ihi, blo, bhi)
+    for t in range(4):
+        below = np.nonzero(out["item_loss"][t] < 1e-10)[0]
+        want = below[0] if len(below) else int(np.argmin(out["item_loss"][t]))
+        assert out["best_restart"][t] == want and out["best_loss"][t] == out["item_loss"][t, want]
+    again = hip_ctx.v2_minimize_stage([0, 0], prm, 1e-10, ilo, ihi, blo, bhi)
+    assert np.array_equal(again["best_x"], out["best_x"])  # static assignment: bitwise reproducible
+    with pytest.raises(_ffi.SlamHipError) as e:
+        z = np.zeros(6 * 5 + 2 * 4)
+        hip_ctx.v2_minimize_stage([0] * 4, prm, 1e-10, z, z + 1, None, None)  # span 4
+    assert e.value.code == -3
+    with pytest.raises(_ffi.SlamHipError):
+        hip_ctx.v2_minimize_stage([0, 3], prm, 1e-10, ilo, ihi, blo, bhi)  # gate index outside the table
+    with pytest.raises(NotImplementedError):
+        CircuitTemplateV2(base_gates=[ConversionGainGate])  # 5 parameters: a = gc * t is not affine
+    with pytest.raises(NotImplementedError):
+        CircuitTemplateV2(base_gates=[lambda a, b: ConversionGainGate(0, 0, a + b, b, 1)])  # an angle on two parameters
+    with pytest.raises(ValueError, match="Parameter Name not found"):
+        b2 = CircuitTemplateV2()
+        b2.build(1)
+        b2.add_bound("Q7", 1, 0)

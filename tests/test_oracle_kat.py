@@ -159,3 +159,20 @@ def test_philox_haar_port_is_unitary_and_haar_like():
     assert abs(p.mean() - 0.25) < 1e-12  # rows sum to one exactly
     assert abs((p**2).mean() - 0.1) < 4e-3
     assert not np.allclose(o.haar_philox_port(11, 0), o.haar_philox_port(12, 0))
+
+
+def test_kat1_through_the_v2_restatement():
+    """The same recorded run is a CircuitTemplateV2 one (decomp_trajectory.ipynb:84-90: base_gates=[RiSwapGate], every Q
+    bounded to [0.5, 0.5]): the V2 restatement (oracle/v2_oracle.py) with Q = 0.5 gives the recorded loss, and its
+    analytic gradient -- including d/d alpha -- is the derivative of that loss."""
+    from oracle import v2_oracle as v
+
+    x = np.concatenate([KAT1["params"], [0.5, 0.5, 0.5]])
+    fns = [lambda a: o.riswap_matrix(a)] * 3
+    W = v.template_eval(x, fns, 1, 3)
+    assert abs(o.square_cost(W, SWAP) - KAT1["square_cost_vs_swap"]) < 1e-15
+    assert o.c1c2c3(W) == tuple(KAT1["c1c2c3_full"])
+    gmap = ([0, -1, -1, -1], [-0.5 * np.pi, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0])  # RiSwap(alpha) = CG(a = -pi alpha / 2)
+    f, g = v.loss_and_grad(x, [gmap] * 3, 1, 3, SWAP, square=True)
+    assert abs(f - KAT1["square_cost_vs_swap"]) < 1e-15
+    assert np.max(np.abs(g - v.fd_grad(x, fns, 1, 3, SWAP, square=True))) < 1e-9
