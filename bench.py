@@ -216,7 +216,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     ndev = _ffi.device_count()
     device = local_rank % max(1, ndev) if os.environ.get("SLAM_BENCH_COMM") == "file" else local_rank
 
-    n_streams = n_streams_arg if n_streams_arg else (16 if small else 3)
+    n_streams = n_streams_arg if n_streams_arg else (16 if small else 5)
     n_streams = max(1, min(n_streams, steps))
     ctxs = [_ffi.Context(device) for _ in range(n_streams)]
     dev_name, cus, _ = ctxs[0].device_info()
@@ -443,7 +443,8 @@ def main():
     ap.add_argument("--targets", type=int, default=None, help="override targets per step per GPU")
     ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 3 otherwise")
+                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 5 otherwise "
+                         "(measured on cfg3: 3 -> 2.95e6, 4 -> 3.0e6, 5 -> 3.19e6, 6 -> 3.20e6 decompositions/s)")
     ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "-1")),
                     help="launch shaping (slam_opt_params.items_per_quad); 0 = library default (one item per quad, lowest "
                          "latency); default here: 3 for small batches with several in flight (+4.7 %% measured), else 0")

@@ -566,20 +566,15 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         else
             part[3] = dtheta_pair(A, Ur[0], Ui[0], Ur[2], Ui[2], fr[0], fi[0], fr[2], fi[2]) +
                       dtheta_pair(A, Ur[1], Ui[1], Ur[3], Ui[3], fr[1], fi[1], fr[3], fi[3]);
-        // stash this column's 6 partials of layer j in an fh slot this lane has already consumed:
-        // h_j's slot for j < K, f_K's slot for j = K  (rows 0..2 of the slot, as double2)
-        if (LEAN && j == K) {
-            // no consumed fh slot yet at the top layer: add lane pairs (q, q^1) and park the 6 x 2 pair
-            // sums in this layer's own trig-table entries, which are dead from here on
+        // sum the partials of lane pairs (q, q ^ 1) and park the 6 x 2 pair sums in this layer's own trig-table
+        // entries, which are dead from here on (every lane of the quad has loaded them above): parameter i = 6 j + m
+        // ends up as the double2 at xq + 2 i, so its owner lane reads it back with one ds_read_b128 at a fixed offset
+        // from a per-lane base -- no lane-dependent address arithmetic, no bank conflicts (the old gather read four
+        // b64 words per parameter from the stored-vector slots: ~20 integer instructions each and a 2-way conflict)
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                const double ps = part[m] + dpp_f64<0xB1>(part[m]);
-                if ((q & 1) == 0) xq[12 * K + 2 * m + (q >> 1)] = ps;
-            }
-        } else {
-            const int sl = (j < K) ? HS(j) : (2 * (K - 1));
-#pragma unroll
-            for (int m = 0; m < 3; ++m) fh[(sl * 4 + m) * kRow] = make_double2(part[2 * m], part[2 * m + 1]);
+        for (int m = 0; m < 6; ++m) {
+            const double ps = part[m] + dpp_f64<0xB1>(part[m]);
+            if ((q & 1) == 0) xq[12 * j + 2 * m + (q >> 1)] = ps;
         }
         if (j > 0) {
             // u <- u~ G_j
@@ -587,26 +582,14 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         }
     }
 
-    // ---- 5. sum the 4 columns' partials: the owner of parameter i = 6j + m (lane i & 3) reads the
-    //         stash of the 4 lanes of its quad
+    // ---- 5. the owner of parameter i (lane i & 3, slot i >> 2) adds the two pair sums
     lds_fence();
     {
-        const double* fhd = reinterpret_cast<const double*>(fh - q);  // lane 0 of this quad
+        const double2* ps2 = reinterpret_cast<const double2*>(xq) + q;
 #pragma unroll
         for (int a = 0; a < C::NA; ++a) {
-            const int i = 4 * a + q;
-            const int j = (i * 43) >> 8;          // i / 6 for i < 64
-            const int m = i - 6 * j;
-            const int sl = (j < K) ? HS(j) : (2 * (K - 1));
-            const double* base = fhd + ((sl * 4 + (m >> 1)) * kRow) * 2 + (m & 1);
-            double sum;
-            if (LEAN && j >= K) {
-                const double2 ps = *reinterpret_cast<const double2*>(xq + 12 * K + 2 * m);
-                sum = ps.x + ps.y;
-            } else {
-                sum = (base[0] + base[2]) + (base[4] + base[6]);  // the 4 lanes' stashes are 16 bytes apart
-            }
-            gd[a] = (i < C::N) ? sum : 0.0;
+            const double2 ps = ps2[4 * a];
+            gd[a] = (4 * a + q < C::N) ? ps.x + ps.y : 0.0;
         }
     }
     lds_fence();

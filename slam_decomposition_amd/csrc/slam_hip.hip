@@ -117,6 +117,7 @@ struct slam_ctx {
     int cost_kind = 0;  // SLAM_COST_*
     std::vector<double> gates_host;
     int compute_units = 0;
+    int reserve_waves = 0;  // wavefront slots the persistent optimizer grid leaves free for the span loop's bookkeeping kernels
     int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1][4] = {};
     // eval buffers
     DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary, ev_weyl;
@@ -304,7 +305,10 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
         blocks = (sl.n_items_max + (int64_t)kQuadsPerWave * prm->items_per_quad - 1) / ((int64_t)kQuadsPerWave * prm->items_per_quad);
         if (blocks < 1) blocks = 1;
     }
-    if (blocks > c->resident_waves[K][GC]) blocks = c->resident_waves[K][GC];
+    // leave a few wavefront slots free: with several batches in flight the bookkeeping kernels of the other streams
+    // (reduce / compaction / epilogue) otherwise wait for the tail of this stage before they can even start
+    const int64_t cap = c->resident_waves[K][GC] - c->reserve_waves > 0 ? c->resident_waves[K][GC] - c->reserve_waves : 1;
+    if (blocks > cap) blocks = cap;
     HIP_TRY(hipEventRecord(c->ev_a[K], c->stream));
     hipLaunchKernelGGL((minimize_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
@@ -672,6 +676,7 @@ int slam_ctx_create(int device, slam_ctx** out) {
     slam_ctx* c = new (std::nothrow) slam_ctx();
     if (!c) return fail(SLAM_ERR_NOMEM, "out of host memory");
     c->device = device;
+    if (const char* e = std::getenv("SLAM_RESERVE_WAVES")) c->reserve_waves = std::atoi(e) > 0 ? std::atoi(e) : 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int k = 0; k <= SLAM_MAX_SPAN_EVAL && e == hipSuccess; ++k) {
         e = hipEventCreate(&c->ev_a[k]);
