@@ -46,11 +46,23 @@ struct Cfg {
     static constexpr int NBLK = NA * (NA + 1) / 2;     // upper-triangle 4x4 blocks of H
     // doubles per quad in the exchange area.  Users: trig table [0, 2N) (the top layer's entries later
     // hold that layer's pair-summed gradient partials); fp32 mat-vec broadcast (4 NA floats) + transposed
-    // partial sums (16 (NA - 1) floats); fp32 rank-2 update broadcasts (8 NA floats).  Rounded up to
-    // == 8 (mod 16) so that the four quads of a b128 read group start 16 banks apart.
-    static constexpr int XNEED = (2 * N > 10 * NA - 8) ? 2 * N : 10 * NA - 8;
-    static constexpr int XSTRIDE = (XNEED - 8 + 15) / 16 * 16 + 8;
+    // partial sums (16 (NA - 1) floats); fp32 rank-2 update broadcasts (8 NA floats).
+    // The fp32 exchanges of the quasi-Newton algebra (h_matvec / h_update: 20 NA - 16 floats per quad, live only BETWEEN
+    // evaluations) overlay the whole wave's exchange area with their OWN quad stride, FSTRIDE floats == 4 (mod 32): their
+    // traffic is mostly ds_write_b32 of 4 consecutive dwords per quad, serviced in groups of 32 lanes = 8 quads on 32
+    // banks -- with the double area's stride (== 16 mod 32 dwords) the 8 quads fell on 2 bank groups, a 4-way conflict on
+    // every such store (31 per round at k = 2: most of the measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 33 %).
+    static constexpr int FNEED = 20 * NA - 16;
+    static constexpr int FSTRIDE = (FNEED - 4 + 31) / 32 * 32 + 4;
+    static constexpr int XNEED_D = 2 * N;
+    static constexpr int XNEED_F = (kQuadsPerWave * FSTRIDE + 2 * kQuadsPerWave - 1) / (2 * kQuadsPerWave);  // doubles per quad so that the float overlay fits
+    static constexpr int XNEED = XNEED_D > XNEED_F ? XNEED_D : XNEED_F;
+    // quad stride of the double area, == 4 (mod 16) doubles = 8 (mod 32) dwords: the four quads of a ds_write_b64 group
+    // (pair sums, two adjacent doubles per quad) and of a ds_read_b128 group (trig entries, one broadcast double2 per quad)
+    // land on different banks; the per-lane double2 gather of the gradient keeps a partial 2-way overlap between two quads
+    static constexpr int XSTRIDE = (XNEED - 4 + 15) / 16 * 16 + 4;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
+    static_assert(kQuadsPerWave * FSTRIDE * 4 <= LDS_XCHG * 8, "float overlay must fit the exchange area");
     static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;  // 2K column vectors x 4 rows x (64 lanes + pad) x (re,im)
     static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH;
     // LEAN layout (structured gate classes): only the K layer outputs h_j are stored; the layer inputs

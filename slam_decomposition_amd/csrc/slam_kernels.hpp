@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
     int q = lane & 3;
     const int quad = lane >> 2;
     double* xq = xchg + quad * C::XSTRIDE;
-    float* xq32 = reinterpret_cast<float*>(xq);
+    float* xq32 = reinterpret_cast<float*>(xchg) + quad * C::FSTRIDE;  // fp32 overlay with its own conflict-free stride
     double2* fh = fhbase + lane;
     double2* tbl = reinterpret_cast<double2*>(lds + lds_work_doubles<K, GC>());
     load_sincos_table(tbl, lane);

@@ -133,8 +133,13 @@ class TemplateOptimizer:
             raise ValueError("empty spanning range")
         if ks[0] <= 0:
             raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
+        if max(ks) > _ffi.MAX_SPAN_MINIMIZE:
+            raise NotImplementedError(
+                f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path "
+                f"(got {max(ks)})"
+            )
         if ks != list(range(ks[0], ks[-1] + 1)):
-            raise NotImplementedError("spanning range must be contiguous")
+            return self._run_batch_any_order(targets, ks)
         if ks[-1] > _ffi.MAX_SPAN_MINIMIZE:
             raise NotImplementedError(
                 f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path "
@@ -195,6 +200,41 @@ class TemplateOptimizer:
             best_cycles = np.concatenate([p[0][2] for p in parts])
             self._span_losses = np.concatenate([p[0][3] for p in parts])
             self.last_stats = [p[1] for p in parts]
+        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
+        return best_loss, xs, best_cycles
+
+    def _run_batch_any_order(self, targets: np.ndarray, ks):
+        """A spanning range that is not a run k0, k0 + 1, ... (e.g. ``basis.spanning_range = [1, 3]``): the sizes are
+        visited in the given order, one ``slam_decompose_list`` per size over the targets still unsolved -- the loop of
+        optimizer.py:233-303 with the host between the spans."""
+        n = len(targets)
+        prm = self._opt_params()
+        ctx = runtime.get_context(self.devices[0])
+        if self._device_sampler is not None:
+            self._device_sampler.fill(ctx)
+        else:
+            ctx.set_targets(targets)
+        ctx.set_gates(self.basis.gate_matrices)
+        ctx.set_cost(self._cost_kind)
+        ctx.reset_stats()
+        k_top = max(ks)
+        best_loss = np.full(n, np.inf)
+        best_x = np.zeros((n, 6 * (k_top + 1)))
+        best_cycles = np.full(n, -1, dtype=np.int32)
+        self._span_losses = np.full((n, _ffi.MAX_SPAN_EVAL), np.nan)
+        for k in ks:
+            if k <= 0:
+                raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
+            todo = np.nonzero(~(best_loss < self.success_threshold))[0]
+            if len(todo) == 0:
+                break
+            ctx.decompose_list(todo, k, k, [self.basis.gate_sequence(k)], prm, self.success_threshold, k_layout=k_top)
+            loss, x, cyc = ctx.fetch_results_range(k_top, 0, n)
+            better = np.zeros(n, bool)
+            better[todo] = (best_cycles[todo] < 0) | (loss[todo] < best_loss[todo])  # optimizer.py:281-284
+            best_loss[better], best_x[better], best_cycles[better] = loss[better], x[better], k
+            self._span_losses[todo, k - 1] = best_loss[todo]
+        self.last_stats = ctx.stats()
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
         return best_loss, xs, best_cycles
 

@@ -277,3 +277,24 @@ def test_span_log_lines_without_callback(caplog):
     assert len(cyc) == 6 and all(cyc[3 * i] >= cyc[3 * i + 1] >= cyc[3 * i + 2] for i in range(2))
     assert msgs.count("Break on cycle 3") == 2
     assert [td.loss_result for td in data] == [cyc[2], cyc[5]]
+
+
+def test_non_contiguous_spanning_range():
+    """basis.spanning_range = [1, 3] (the reference accepts any iterable, optimizer.py:233): sizes visited in order, the
+    template size 2 never tried."""
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.gates import RiSwapGate
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    from slam_decomposition_amd.sampler import HaarBatch
+
+    basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
+    basis.spanning_range = [1, 3]
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=6, seed=3)
+    sampler = HaarBatch(seed0=60, n_samples=5)
+    _, _, data = opt.approximate_from_distribution(sampler)
+    targets = list(sampler)
+    for t, td in enumerate(data):
+        assert td.cycles == 3 and td.success_label == 1
+        W = o.template_eval(td.Xk, [SQ] * 3)
+        assert abs(o.basic_cost(W, targets[t]) - td.loss_result) < 1e-12

@@ -14,7 +14,7 @@ table = gate_table(gname)
 ctx.set_gates(table)
 ctx.set_targets(make_targets(N, 20260000))
 seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
-prm = _ffi.OptParams(restarts=R, seed=20261003, flags=_ffi.FLAG_EARLY_EXIT, items_per_quad=int(os.environ.get("KB_IPQ", "0")))
+prm = _ffi.OptParams(restarts=R, seed=20261003, flags=int(os.environ.get("KB_FLAGS", str(_ffi.FLAG_EARLY_EXIT))), items_per_quad=int(os.environ.get("KB_IPQ", "0")))
 best = None
 for rep in range(reps + 1):
     ctx.reset_stats()
