@@ -197,7 +197,12 @@ def make_comm(rank: int, world: int, local_rank: int):
     if os.environ.get("SLAM_BENCH_COMM", "rccl") == "file":
         # rehearsal of the N > 1 path on a one-GPU box (RCCL refuses several ranks on one device)
         return parallel.FileComm(rank, world, os.environ.get("SLAM_COMM_DIR") or parallel.rendezvous_path() + ".d")
-    return parallel.RcclComm(local_rank, rank, world, parallel.rendezvous_path())
+    try:
+        return parallel.RcclComm(local_rank, rank, world, parallel.rendezvous_path())
+    except Exception as exc:  # RCCL missing or unusable on this node: keep the job alive, loudly (every rank fails alike)
+        print(f"[bench rank {rank}] RCCL communicator failed ({exc}); falling back to the file communicator -- the final "
+              f"all-reduce then goes through files and is far slower", file=sys.stderr, flush=True)
+        return parallel.FileComm(rank, world, os.environ.get("SLAM_COMM_DIR") or parallel.rendezvous_path() + ".d")
 
 
 # ------------------------------------------------------------------------------------------------
