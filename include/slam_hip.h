@@ -74,8 +74,9 @@ typedef struct slam_opt_params {
     uint32_t items_per_quad; /* launch shaping: at least this many work items per resident quad before more
                                 wavefronts are launched.  0/1 = spread a small batch over as many wavefronts as
                                 possible (lowest latency of one batch); 4..8 = keep quads refilled (highest
-                                throughput when several batches are in flight on different streams).  Results
-                                do not depend on it. */
+                                throughput when several batches are in flight on different streams).  With
+                                SLAM_FLAG_ORDERED (or without early exit) results do not depend on it; with the plain
+                                early-exit flag the winner among equally successful restarts depends on timing anyway. */
     double gtol_far;      /* with far_loss: also stop when |g|_inf < gtol_far and loss > far_loss, i.e. at a */
     double far_loss;      /* stationary point that is clearly not a zero of the loss.  gtol_far = 1e-5 is SciPy's
                              default gtol, which is what the reference runs with (optimizer.py:270-278);

@@ -110,3 +110,41 @@ def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path):
 
     with pytest.raises(TimeoutError):
         exchange_unique_id(1, 2, str(tmp_path / "never"), lambda: uid, timeout=0.2)
+
+
+FILE_WORKER = textwrap.dedent(
+    """
+    import os, sys
+    sys.path.insert(0, os.environ["SLAM_ROOT"])
+    import numpy as np
+    from slam_decomposition_amd.parallel import FileComm, merge_results, shard_range
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    comm = FileComm(rank, world, os.environ["SLAM_COMM_DIR"], timeout=60)
+    N = 11
+    first, count = shard_range(N, rank, world)
+    rng = np.random.default_rng(5)                       # the same stream on every rank: the "single-rank result"
+    loss_all, x_all, cyc_all = rng.random(N), rng.random((N, 6)), rng.integers(1, 4, N)
+    comm.barrier()
+    for _ in range(3):                                   # several rounds: sequence numbers, clean-up of old files
+        L, X, C = merge_results(comm, N, first, loss_all[first:first + count], x_all[first:first + count], cyc_all[first:first + count])
+        assert np.array_equal(L, loss_all) and np.array_equal(X, x_all) and np.array_equal(C, cyc_all)
+    t = np.array([float(rank)])
+    comm.allreduce_max(t)
+    assert t[0] == world - 1
+    print("ok", rank)
+    """
+)
+
+
+def test_file_communicator_three_ranks(tmp_path):
+    """parallel.FileComm (bench.py's rehearsal communicator for ranks that share one GPU, and its fallback when RCCL cannot
+    be initialised): three processes, merge_results equals the unsharded arrays on every rank."""
+    script = tmp_path / "fworker.py"
+    script.write_text(FILE_WORKER)
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, SLAM_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="3", SLAM_COMM_DIR=str(tmp_path / "fc"), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
