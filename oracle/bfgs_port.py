@@ -47,6 +47,7 @@ def minimize_port(
     if not np.isfinite(f):
         return f, x, 0, 3, nev
     H = np.eye(n, dtype=h_dtype)
+    hs1 = 0.0  # the effective inverse Hessian is H + hs1 I: the one-off scaling of the initial one is a scalar (as in the kernel)
     p = -(H @ g.astype(h_dtype)).astype(np.float64)  # the kernel's first direction is -H g in float32 too
     gnorm = np.abs(g).max()
 
@@ -69,6 +70,7 @@ def minimize_port(
         if not (gp < 0):
             # not a descent direction (H lost positive-definiteness numerically): reset
             H = np.eye(n, dtype=h_dtype)
+            hs1 = 0.0
             p = -g
             gp = g @ p
         s = alpha * p
@@ -79,28 +81,33 @@ def minimize_port(
             ft = np.inf
         if ft <= f + ARMIJO_C1 * alpha * gp:
             y = gt - g
-            sy = s @ y
+            # s = alpha p: the products with s come from p.g' and the direction's own p.g, p.p (the kernel's formulas)
+            pgt = p @ gt
+            sy = alpha * (pgt - gp)
+            ss = (alpha * alpha) * (p @ p)
+            sg = alpha * pgt
             # weak-Wolfe curvature condition violated (in particular: negative curvature along p, where the
             # update below is skipped and H never learns to take longer steps): lengthen the next trial step
             short = sy < (1.0 - WOLFE_C2) * alpha * (-gp)
             q = (H @ gt.astype(h_dtype)).astype(np.float64)
-            if sy > CURV_EPS * np.sqrt((s @ s) * (y @ y)):
+            if sy > CURV_EPS * np.sqrt(ss * (y @ y)):
                 rho = 1.0 / sy
                 fac = 1.0
                 if not scaled:
-                    # scale the initial inverse Hessian before its first update (Nocedal & Wright eq. 6.20)
+                    # scale the initial inverse Hessian (the identity) before its first update (Nocedal & Wright
+                    # eq. 6.20): H_eff = H + hs1 I with hs1 = fac - 1
                     fac = sy / (y @ y)
-                    H = H * h_dtype(fac)
+                    hs1 = fac - 1.0
                     scaled = True
-                q = q * fac
-                u = q + fac * p  # H y = H g' - H g,  p = -H g
+                q = q + hs1 * gt
+                u = q + fac * p  # H_eff y = H_eff g' - H_eff g,  p = -H_eff g before this round's scaling
                 c = rho * (1.0 + rho * (y @ u))
                 w = c * s - rho * u
                 v = -rho * u
                 H = H + np.outer(s.astype(h_dtype), w.astype(h_dtype)) + np.outer(v.astype(h_dtype), s.astype(h_dtype))
-                pn = -(q + s * (w @ gt) + v * (s @ gt))
+                pn = -(q + s * (w @ gt) + v * sg)
             else:
-                pn = -q
+                pn = -(q + hs1 * gt)
             nstall = nstall + 1 if (f - ft) <= STALL_DF else 0
             x, f, g = xt, ft, gt
             it += 1

@@ -127,6 +127,18 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
     }
 }
 
+// Kernel arguments that are only needed when an item starts or finishes (result pointers, seeds, the work queue) are
+// re-read from the kernarg segment where they are used instead of living in SGPRs across the evaluation: the optimizer
+// loop is short of scalar registers (the thresholds it tests every round were being spilled into VGPR lanes and read back
+// with v_readlane -- a vector-ALU slot each).  The pointer is laundered through an empty asm so that the loads stay at
+// their use sites (as for the gate matrices, slam_device.hpp:gate_matrix).
+template <int K>
+__device__ __forceinline__ const __attribute__((address_space(4))) MinimizeArgs<K>* cold_args() {
+    unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return (const __attribute__((address_space(4))) MinimizeArgs<K>*)a;
+}
+
 // ---------------------------------------------------------------------------------
 // batched quasi-Newton minimisation.  Persistent wavefronts: each of the 16 quads of a wave
 // owns one (target, seed) item at a time and pulls the next one from a global counter when
@@ -179,6 +191,10 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
     int slot = 0, tgt = 0;
     int nev = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
     double f = 0.0, alpha = 0.0, gp = 0.0, gnorm = 0.0, grow = 1.0;
+    // pp = p.p of the current direction; hs1 = (scale of the identity part of the inverse Hessian) - 1: the effective
+    // metric is H + hs1 I, so the one-off scaling of the initial inverse Hessian (Nocedal & Wright eq. 6.20) is a scalar
+    // update instead of a multiplication of every stored block
+    double pp = 0.0, hs1 = 0.0;
     const double* tcol = args.targets + q * 2;  // this lane's column of the quad's target
     double x[NA], g[NA], p[NA];
 #pragma unroll
@@ -215,7 +231,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                     cur_next = b;
                     cur_end = (b + kChunk < n_items) ? b + kChunk : n_items;
                     if (b >= n_items) { exhausted = true; break; }
-                    if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
+                    if (lane == 0) pre_base = atomicAdd(&cold_args<K>()->ctl->work_counter, kChunk);
                 }
                 // ---- scan up to 64 queue positions at once: lane l looks at position cur_next + l.  Positions whose
                 // target already has a successful restart are dropped here (one flag load for the whole window, their
@@ -250,11 +266,11 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                     // a sibling restart already succeeded: nothing to do for this item
                     // (outputs and explicit seeds keep the [slot][restart] layout whatever the processing order)
                     const unsigned o = psl * (unsigned)args.restarts + prs;
-                    args.item_loss[o] = INFINITY;
-                    args.item_iters[o] = 0;
-                    args.item_status[o] = ST_PREEMPTED;
-                    args.item_evals[o] = 0;
-                    args.item_acc[o] = 0;
+                    cold_args<K>()->item_loss[o] = INFINITY;
+                    cold_args<K>()->item_iters[o] = 0;
+                    cold_args<K>()->item_status[o] = ST_PREEMPTED;
+                    cold_args<K>()->item_evals[o] = 0;
+                    cold_args<K>()->item_acc[o] = 0;
                 }
                 int* wp = reinterpret_cast<int*>(xchg);  // wave-private, dead between rounds: [16] slots, [16] restarts
                 if (handed) {
@@ -275,20 +291,20 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                         slot = (int)sl;
                         const unsigned restart = rs;
                         // three independent loads (no load feeds another's address)
-                        tgt = args.orig ? args.orig[sl] : args.first_target + (int)sl;
-                        tcol = args.targets + (int64_t)sl * 32 + q * 2;
+                        tgt = cold_args<K>()->orig ? cold_args<K>()->orig[sl] : cold_args<K>()->first_target + (int)sl;
+                        tcol = cold_args<K>()->targets + (int64_t)sl * 32 + q * 2;
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
                             const int i = 4 * a + q;
                             double xv = 0.0;
                             if (i < C::N)
-                                xv = args.x0 ? args.x0[(int64_t)oidx * C::N + i]
-                                             : x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), restart, (uint32_t)K, (uint32_t)i);
+                                xv = cold_args<K>()->x0 ? cold_args<K>()->x0[(int64_t)oidx * C::N + i]
+                                             : x0_philox(cold_args<K>()->seed, (uint32_t)(tgt + (int)cold_args<K>()->target_base), restart, (uint32_t)K, (uint32_t)i);
                             x[a] = xv;
                             p[a] = 0.0;
                             g[a] = 0.0;
                         }
-                        alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0;
+                        alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0; pp = 0.0; hs1 = 0.0;
                         nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
                         scaled = false; fresh = true; live = true; taken = true;
                     }
@@ -337,47 +353,40 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: interleaving them only adds live registers
         h_matvec<NA>(H, gt, xq32, q, qv);
         __builtin_amdgcn_sched_barrier(0);
-        double sy = 0.0, yy = 0.0, ss = 0.0;
+        // s = am p, so every product with s follows from p.g' (one reduction) and the direction's own p.g, p.p, which
+        // the previous round left in gp and pp:  s.g' = am p.g',  s.y = am (p.g' - p.g),  s.s = am^2 p.p
+        double pgt = 0.0, yy = 0.0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const double sa = am * p[a];
             const double ya = gt[a] - g[a];
-            sy = fma(sa, ya, sy);
+            pgt = fma(p[a], gt[a], pgt);
             yy = fma(ya, ya, yy);
-            ss = fma(sa, sa, ss);
         }
-        sy = quad_sum(sy);
+        pgt = quad_sum(pgt);
         yy = quad_sum(yy);
-        ss = quad_sum(ss);
+        const double sg = am * pgt;
+        const double sy = am * (pgt - gp);
+        const double ss = (am * am) * pp;
         const bool curv = step && sy > 0.0 && (sy * sy > (kCurvEps * kCurvEps) * (ss * yy));
         const bool too_short = sy < (1.0 - kWolfeC2) * alpha * (-gp);  // weak-Wolfe curvature condition violated
         const bool first = curv && !scaled;
         scaled = scaled || curv;
+        // first update of an item: scale the initial inverse Hessian (= the identity then) by s.y / y.y -- as the scalar
+        // hs1 (round 1 multiplied all 30 / 42 stored blocks by a factor that is 1 in every other round)
         const double fac = first ? (sy * fast_rcp(yy)) : 1.0;
-        {
-            // fac = 1 except at a quad's first update; unconditional (42 packed multiplies at k = 3) so
-            // that H is not redefined on one side of a branch (measured again in round 2: under `if (__any(first))`
-            // the k = 2 kernel spills 32 B per lane and the k = 3 kernel 512 B instead of 288 B)
-            const float f32 = (float)fac;
-            const f32x2 f2 = f32x2{f32, f32};
-#pragma unroll
-            for (int b = 0; b < C::NBLK; ++b) {
-                H.h[b][0] *= f2;
-                H.h[b][1] *= f2;
-            }
-        }
-        // u = H y = H g' - H g = fac (q + p)   (p = -H g, q = H g' before the first-update scaling)
+        hs1 = first ? fac - 1.0 : hs1;
+        // u = H_eff y = H_eff g' - H_eff g = q + fac p   (p = -H_eff g with the metric before this round's scaling)
         double yu = 0.0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            qv[a] *= fac;
+            qv[a] = fma(hs1, gt[a], qv[a]);  // q = H_eff g' = H g' + hs1 g'
             const double ua = fma(fac, p[a], qv[a]);
             yu = fma(gt[a] - g[a], ua, yu);
         }
         yu = quad_sum(yu);
         const double rho = curv ? fast_rcp(sy) : 0.0;
         const double cf = rho * (1.0 + rho * yu);
-        double wg = 0.0, sg = 0.0;
+        double wg = 0.0;
         {
             float s32[NA], w32[NA], v32[NA];
 #pragma unroll
@@ -390,16 +399,17 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                 w32[a] = (float)wa;
                 v32[a] = (float)va;
                 wg = fma(wa, gt[a], wg);
-                sg = fma(sa, gt[a], sg);
             }
             __builtin_amdgcn_sched_barrier(0);
             h_update<NA>(H, s32, w32, v32, xq32, q);
             __builtin_amdgcn_sched_barrier(0);
         }
         wg = quad_sum(wg);
-        sg = quad_sum(sg);
 
         // ---- 4. per-quad state machine
+        // x <- x + s outside the branch: s = am p is zero unless the step was accepted, so no per-component select
+#pragma unroll
+        for (int a = 0; a < NA; ++a) x[a] += am * p[a];
         bool done = false;
         if (acc) {
             nstall = (step && (f - ft) <= kStallDf) ? nstall + 1 : 0;
@@ -412,17 +422,16 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                 const double sa = am * p[a];
                 const double ua = fma(fac, p[a], qv[a]);
                 const double va = -rho * ua;
-                x[a] += sa;
                 g[a] = gt[a];
                 p[a] = -(qv[a] + sa * wg + va * sg);
             }
-            if (args.trace_loss && step && iters <= args.trace_cap) {  // wave-uniform pointer test: nothing when off
-                const int64_t row = (int64_t)item * args.trace_cap + (iters - 1);
-                if (q == 0) args.trace_loss[row] = f;
+            if (cold_args<K>()->trace_loss && step && iters <= cold_args<K>()->trace_cap) {  // wave-uniform pointer test: nothing when off
+                const int64_t row = (int64_t)item * cold_args<K>()->trace_cap + (iters - 1);
+                if (q == 0) cold_args<K>()->trace_loss[row] = f;
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
                     const int i = 4 * a + q;
-                    if (i < C::N) args.trace_x[row * C::N + i] = x[a];
+                    if (i < C::N) cold_args<K>()->trace_x[row * C::N + i] = x[a];
                 }
             }
         } else if (active) {
@@ -432,7 +441,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                 done = true;
             } else {
                 const double denom = 2.0 * (ft - f - gp * alpha);
-                const double anew = (finite && denom > 0.0 && isfinite(denom)) ? (-gp * alpha * alpha / denom) : 0.5 * alpha;
+                const double anew = (finite && denom > 0.0 && isfinite(denom)) ? (-gp * alpha * alpha * fast_rcp(denom)) : 0.5 * alpha;
                 alpha = fmin(fmax(anew, 0.1 * alpha), 0.5 * alpha);
                 grow = 1.0;
                 ++nback;
@@ -446,7 +455,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             gnorm = quad_max(m);
         }
         gp = qdot<NA>(g, p);
-        const double pp = qdot<NA>(p, p);
+        pp = qdot<NA>(p, p);
         if (acc) {
             alpha = (pp > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(pp)) : grow;
             if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) {
@@ -461,10 +470,12 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         const bool reset = active && !done && !(gp < 0.0);
         if (__any(reset)) {
             h_set_identity_where<NA>(H, q, reset);
+            hs1 = reset ? 0.0 : hs1;
 #pragma unroll
             for (int a = 0; a < NA; ++a) p[a] = reset ? -g[a] : p[a];
             const double gg2 = qdot<NA>(g, g);
             gp = reset ? -gg2 : gp;
+            pp = reset ? gg2 : pp;
         }
         // ---- 5. early exit across the restarts of one target (optimizer.py:287-295)
         if (args.flags & 1u) {
@@ -478,24 +489,22 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         // ---- 6. finished items leave; their quads pull new work next round
         if (active && done) {
             if (q == 0) {
-                args.item_loss[item] = f;
-                args.item_iters[item] = iters;
-                args.item_status[item] = status;
-                args.item_evals[item] = nev & 0xFFFFF;
-                args.item_acc[item] = (int)((unsigned)nev >> 20);
+                cold_args<K>()->item_loss[item] = f;
+                cold_args<K>()->item_iters[item] = iters;
+                cold_args<K>()->item_status[item] = status;
+                cold_args<K>()->item_evals[item] = nev & 0xFFFFF;
+                cold_args<K>()->item_acc[item] = (int)((unsigned)nev >> 20);
             }
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const int i = 4 * a + q;
-                if (i < C::N) args.item_x[(int64_t)item * C::N + i] = x[a];
+                if (i < C::N) cold_args<K>()->item_x[(int64_t)item * C::N + i] = x[a];
             }
             live = false;
-            alpha = 0.0;
-#pragma unroll
-            for (int a = 0; a < NA; ++a) p[a] = 0.0;
+            alpha = 0.0;  // an idle quad keeps evaluating x + 0 p (its direction is reset when it takes the next item)
         }
     }
-    if (lane == 0 && rounds) atomicAdd(&args.ctl->rounds, (unsigned long long)rounds);
+    if (lane == 0 && rounds) atomicAdd(&cold_args<K>()->ctl->rounds, (unsigned long long)rounds);
 }
 
 // ---------------------------------------------------------------------------------
