@@ -298,3 +298,43 @@ def test_non_contiguous_spanning_range():
         assert td.cycles == 3 and td.success_label == 1
         W = o.template_eval(td.Xk, [SQ] * 3)
         assert abs(o.basic_cost(W, targets[t]) - td.loss_result) < 1e-12
+
+
+def test_callback_failure_raises_like_the_reference_and_vz_only_v2_runs():
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.basisv2 import CircuitTemplateV2
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.gates import ConversionGainGate, CXGate
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+
+    # configs[0]-like failure with the callback on: two CNOTs cannot reach a Haar target -> ValueError (optimizer.py:89-93)
+    basis = CircuitTemplate(base_gates=[CXGate()], maximum_span_guess=2)
+    opt = TemplateOptimizer(basis, BasicCost(), use_callback=True, training_restarts=2, seed=1)
+    with pytest.raises(ValueError, match="Failed to converge"):
+        opt.approximate_target_U(o.haar_unitary(3))
+    assert opt.training_loss == []  # without override_fail the break condition never fires (optimizer.py:287-292)
+    # utils/gates/family_extend.py:40-56: phase lambdas, rz-only layers, one cycle, SquareCost-free variant with BasicCost:
+    # the template reaches targets that are the gate itself up to rz layers
+    g1, g2 = 0.9, 0.4
+    fn = lambda p1, p2: ConversionGainGate(p1, p2, g1, g2, 1.0)
+    tmpl = CircuitTemplateV2(base_gates=[fn], maximum_span_guess=1, vz_only=True)
+    tmpl.spanning_range = range(1, 2)
+    target = ConversionGainGate(0.7, -1.3, g1, g2, 1.0).to_matrix()
+    opt2 = TemplateOptimizer(tmpl, BasicCost(), override_fail=True, training_restarts=6, seed=2)
+    td = opt2.approximate_target_U(target)
+    assert td.success_label == 1 and td.cycles == 1 and len(td.Xk) == 4 + 2 and td.loss_result < 1e-10
+    tmpl.build(1)
+    assert abs(o.basic_cost(tmpl.eval(td.Xk), target) - td.loss_result) < 1e-12
+
+
+def test_span_losses_entry_point(hip_ctx):
+    N = 12
+    hip_ctx.set_targets(o.haar_batch(N, seed0=8))
+    hip_ctx.set_gates(SQ[None])
+    best_loss, _, best_cycles = hip_ctx.decompose(1, 3, SEQS, _ffi.OptParams(restarts=5, seed=6, flags=ORDERED), 1e-10)
+    sl = hip_ctx.fetch_span_losses(0, N)
+    assert sl.shape == (N, _ffi.MAX_SPAN_EVAL) and np.all(np.isnan(sl[:, 3:]))
+    for t in range(N):
+        k = int(best_cycles[t])
+        assert np.all(np.isfinite(sl[t, :k])) and np.all(np.isnan(sl[t, k:3]))   # spans after the solving one never ran
+        assert sl[t, k - 1] == best_loss[t] and np.all(np.diff(sl[t, :k]) <= 0)  # running best: non-increasing
