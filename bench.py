@@ -198,7 +198,9 @@ def make_comm(rank: int, world: int, local_rank: int):
         # rehearsal of the N > 1 path on a one-GPU box (RCCL refuses several ranks on one device)
         return parallel.FileComm(rank, world, os.environ.get("SLAM_COMM_DIR") or parallel.rendezvous_path() + ".d")
     try:
-        return parallel.RcclComm(local_rank, rank, world, parallel.rendezvous_path())
+        from slam_decomposition_amd import _ffi
+
+        return parallel.RcclComm(local_rank % max(1, _ffi.device_count()), rank, world, parallel.rendezvous_path())
     except Exception as exc:  # RCCL missing or unusable on this node: keep the job alive, loudly (every rank fails alike)
         print(f"[bench rank {rank}] RCCL communicator failed ({exc}); falling back to the file communicator -- the final "
               f"all-reduce then goes through files and is far slower", file=sys.stderr, flush=True)
@@ -218,8 +220,10 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     small = n_per_step * restarts <= 65536
     total_steps = steps + warmup
     seed0 = TARGET_SEED0 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
+    # one GPU per rank: LOCAL_RANK; modulo the visible devices, so that a launcher which restricts every rank's
+    # visibility to its own GPU (device 0 everywhere) and the shared-GPU rehearsal (SLAM_BENCH_COMM=file) both work
     ndev = _ffi.device_count()
-    device = local_rank % max(1, ndev) if os.environ.get("SLAM_BENCH_COMM") == "file" else local_rank
+    device = local_rank % max(1, ndev)
 
     n_streams = n_streams_arg if n_streams_arg else (16 if small else 5)
     n_streams = max(1, min(n_streams, steps))
