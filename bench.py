@@ -189,6 +189,21 @@ def launch_ranks(n: int) -> int:
         return rc
 
 
+class _StdoutToStderr:
+    """RCCL prints its version banner on the C-level stdout when a communicator is created; rank 0's stdout must carry
+    the JSON line only, so fd 1 points at stderr while the communicator comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def make_comm(rank: int, world: int, local_rank: int):
     from slam_decomposition_amd import parallel
 
@@ -200,7 +215,10 @@ def make_comm(rank: int, world: int, local_rank: int):
     try:
         from slam_decomposition_amd import _ffi
 
-        return parallel.RcclComm(local_rank % max(1, _ffi.device_count()), rank, world, parallel.rendezvous_path())
+        with _StdoutToStderr():
+            comm = parallel.RcclComm(local_rank % max(1, _ffi.device_count()), rank, world, parallel.rendezvous_path())
+            comm.barrier()  # first collective (lazy channel set-up and its messages) before anything is timed or printed
+        return comm
     except Exception as exc:  # RCCL missing or unusable on this node: keep the job alive, loudly (every rank fails alike)
         print(f"[bench rank {rank}] RCCL communicator failed ({exc}); falling back to the file communicator -- the final "
               f"all-reduce then goes through files and is far slower", file=sys.stderr, flush=True)
