@@ -436,55 +436,83 @@ class TemplateOptimizer:
     # ------------------------------------------------------------------------------------------
     def approximate_target_U(self, target_U) -> DataDictEntry:
         """Atomic training function (optimizer.py:65-119)."""
-        return self._approximate_batch([np.asarray(target_U, dtype=np.complex128)], log_index=False)[0]
+        t = np.asarray(target_U, dtype=np.complex128)
+        if t.shape != (4, 4):
+            raise ValueError("targets must be 4x4 unitaries")
+        return self._approximate_batch(t[None], log_index=False)[0]
 
     def approximate_from_distribution(self, sampler: SampleFunction):
         """optimizer.py:180-186; all targets of the sampler are optimised as one GPU batch."""
-        targets = [np.asarray(t, dtype=np.complex128) for t in sampler]
         self._device_sampler = sampler if hasattr(sampler, "fill") else None  # sampler.DeviceHaarBatch
         try:
-            target_data = self._approximate_batch(targets, log_index=True) if targets else []
+            if self._device_sampler is not None:
+                stacked = np.asarray(sampler.as_array(), dtype=np.complex128)  # one array, no per-target Python objects
+            else:
+                targets = [np.asarray(t, dtype=np.complex128) for t in sampler]
+                for t in targets:
+                    if t.shape != (4, 4):
+                        raise ValueError("targets must be 4x4 unitaries")
+                stacked = np.stack(targets) if targets else np.zeros((0, 4, 4), dtype=np.complex128)
+            target_data = self._approximate_batch(stacked, log_index=True) if len(stacked) else []
         finally:
             self._device_sampler = None
         return self.training_loss, self.coordinate_list, target_data
 
-    def _approximate_batch(self, targets: List[np.ndarray], log_index: bool) -> List[DataDictEntry]:
-        for t in targets:
-            if t.shape != (4, 4):
-                raise ValueError("targets must be 4x4 unitaries")
-        stacked = np.stack(targets)
+    def _approximate_batch(self, stacked: np.ndarray, log_index: bool) -> List[DataDictEntry]:
+        n = len(stacked)
+        # The reference logs per target (optimizer.py:77-106,183,234,297-305).  Formatting ~10 lines for each of 1e5
+        # targets costs 50x the GPU time of the batch, so the log lines -- and the coordinates that only they show -- are
+        # produced only when INFO logging is enabled.
+        log_on = logging.getLogger().isEnabledFor(logging.INFO)
+        ctx0 = runtime.get_context(self.devices[0])
+        need_coords = log_on or (self.basis.use_polytopes and not self._v2)
         # target_invariant (basis_abc.py:80-84) for the whole batch, on the device
-        coords = [tuple(float(v) for v in c) for c in runtime.get_context(self.devices[0]).c1c2c3(stacked)]
+        coords_arr = ctx0.c1c2c3(stacked) if need_coords else None
         self.basis.assign_seed(None)  # optimizer.py:150-152
         spans_of = None
         if self._v2:
-            spanning_range = list(self.basis.get_spanning_range(targets[0]))
-            spans_of = [spanning_range] * len(targets)
+            spanning_range = list(self.basis.get_spanning_range(stacked[0]))
+            spans_of = [spanning_range] * n
             best_loss, best_xs, best_cycles = self._run_batch_v2(stacked, spanning_range)
         elif self.use_callback:
             if self.basis.use_polytopes:
-                spans_of = [list(range(int(k), int(k) + 1)) for k in self.basis.minimal_spans(np.array(coords))]
+                spans_of = [list(range(int(k), int(k) + 1)) for k in self.basis.minimal_spans(coords_arr)]
             else:
-                spans_of = [list(self.basis.get_spanning_range(targets[0]))] * len(targets)
+                spans_of = [list(self.basis.get_spanning_range(stacked[0]))] * n
             best_loss, best_xs, best_cycles = self._run_batch_callback(stacked, spans_of)
         elif self.basis.use_polytopes:
             # get_spanning_range per target (optimizer.py:233 with basis.py:95-100): only the template size
             # the target needs.  Targets are grouped by that size; each group is one batch.
-            spans = self.basis.minimal_spans(np.array(coords))
+            spans = self.basis.minimal_spans(coords_arr)
             spans_of = [[int(k)] for k in spans]
             best_loss, best_xs, best_cycles = self._run_batch_by_span(stacked, spans)
         else:
-            spanning_range = self.basis.get_spanning_range(targets[0])
-            spans_of = [list(spanning_range)] * len(targets)
+            spanning_range = self.basis.get_spanning_range(stacked[0])
+            spans_of = [list(spanning_range)] * n
             best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)
-        found = self._found_coordinates(best_xs, np.asarray(best_cycles))
+        best_loss = np.asarray(best_loss, dtype=np.float64)
+        best_cycles = np.asarray(best_cycles)
         self.basis.build(n_repetitions=int(best_cycles[-1]))  # the reference leaves the template at the last size
+        if not log_on and not self.use_callback:
+            # same bookkeeping as the per-target path below, without the log lines: every target up to (and including)
+            # the first one that fails without override_fail is recorded, then the reference's ValueError (optimizer.py:89-93)
+            ok = best_loss <= self.success_threshold
+            fail = (not self.override_fail) and (not bool(ok.all()))
+            stop = int(np.argmin(ok)) + 1 if fail else n
+            self.training_loss.extend(best_loss[:stop].tolist())  # optimizer.py:307-309 (no callback)
+            self.best_cycle_list.extend(int(c) for c in best_cycles[:stop])
+            if fail:
+                raise ValueError(_FAIL_MSG)
+            return [DataDictEntry(int(ok[i]), float(best_loss[i]), best_xs[i], int(best_cycles[i])) for i in range(n)]
+        found = self._found_coordinates(best_xs, best_cycles) if log_on else np.zeros((n, 3))
+        coords = coords_arr if coords_arr is not None else np.zeros((n, 3))
         out = []
-        for i in range(len(targets)):
+        for i in range(n):
+            tc = tuple(float(v) for v in coords[i])
             if log_index:
                 logging.info(f"Starting sample iter {i}")
-            logging.info(f"Begin search: {coords[i]}")
+            logging.info(f"Begin search: {tc}")
             self._log_span_loop(i, spans_of[i])
             fc = tuple(float(v) for v in found[i])
-            out.append(self._finish_target(coords[i], float(best_loss[i]), best_xs[i], int(best_cycles[i]), fc, index=i))
+            out.append(self._finish_target(tc, float(best_loss[i]), best_xs[i], int(best_cycles[i]), fc, index=i))
         return out
