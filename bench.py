@@ -179,13 +179,25 @@ def launch_ranks(n: int) -> int:
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         rc = 0
         try:
-            for p in procs:
-                code = p.wait()
-                rc = rc or code
+            live = list(procs)
+            while live:
+                for p in list(live):
+                    code = p.poll()
+                    if code is not None:
+                        live.remove(p)
+                        rc = rc or code
+                if rc:
+                    break  # a rank that died leaves the others waiting in a collective: do not wait for them
+                time.sleep(0.05)
         finally:
-            for p in procs:  # a rank that died leaves the others waiting in the rendezvous: end them by pid
+            for p in procs:  # end what is still running, by pid
                 if p.poll() is None:
                     p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
         return rc
 
 
