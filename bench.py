@@ -592,6 +592,8 @@ def main():
                 # trials at the forward-only count, pre-empted restarts not counted at all
                 "frac_accepted": m["flops_accepted"] / m["kernel_s"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
                 "frac_accepted_plus_rejected_forward": m["flops_strict"] / m["kernel_s"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "peak_note": "nominal: 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz; a pure v_fma_f64 loop sustains 58.8 TFLOP/s on this "
+                             "chip (it holds ~1.65 GHz under that load: tools/ubench_valu.hip, profiles/r2_ubench_valu.txt)",
                 "numerator_note": "dense flop accounting of SURVEY.md 8(d) for every lock-step evaluation; structured gates (CX = a swap) "
                                   "count at the dense 4x4 product's cost",
                 **({"per_span": m["per_span"]} if m["per_span"] else {}),
