@@ -284,6 +284,15 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
+// "these values are needed here": pins the s_waitcnt of the LDS reads that produced them to this point of the program
+__device__ __forceinline__ void u3_arrived(const U3t& a, const U3t& b) {
+    asm volatile("" ::"v"(a.c), "v"(a.s), "v"(a.cp), "v"(a.sp), "v"(a.cl), "v"(a.sl), "v"(b.c), "v"(b.s), "v"(b.cp), "v"(b.sp),
+                 "v"(b.cl), "v"(b.sl));
+}
+__device__ __forceinline__ void vec_arrived(const double (&r)[4], const double (&i)[4]) {
+    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(i[0]), "v"(i[1]), "v"(i[2]), "v"(i[3]));
+}
+
 // cold path, kept out of line so that its register appetite (ocml's Payne-Hanek reduction) does not
 // shape the register allocation of the optimizer loop
 __device__ __attribute__((noinline)) void sincos_slow(double x, double* s, double* c) { sincos(x, s, c); }
@@ -412,6 +421,75 @@ __device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&U
     }
 }
 
+// The entries of one gate matrix that a layer needs, fetched ONCE per use site group and early: for the XRI class the 8
+// real numbers are loaded into SGPRs at the top of the layer (forward) / once per backward layer for both of its uses
+// (f_j = G_j h_{j-1} and u <- u G_j), so the scalar-cache latency (~200 cycles, previously exposed three to five times
+// per layer right in front of the first use) runs under the layer's 1Q-gate arithmetic.  The other classes keep the
+// load-at-use form (32 / 64 SGPRs per matrix do not fit next to the loop's other scalars).
+template <int GC>
+struct GateRegs {
+    gate_ptr G;
+};
+template <>
+struct GateRegs<GC_XRI> {
+    double a_d0, a_o01, a_o10, a_d1;  // block on index pair (0, 3)
+    double b_d0, b_o01, b_o10, b_d1;  // block on index pair (1, 2)
+};
+template <int GC>
+__device__ __forceinline__ GateRegs<GC> load_gate(const double* gates, int j) {
+    gate_ptr G = gate_matrix(gates, j);
+    if constexpr (GC == GC_XRI) {
+        GateRegs<GC> r;
+        r.a_d0 = SLAM_GRE(0, 0); r.a_o01 = SLAM_GIM(0, 3); r.a_o10 = SLAM_GIM(3, 0); r.a_d1 = SLAM_GRE(3, 3);
+        r.b_d0 = SLAM_GRE(1, 1); r.b_o01 = SLAM_GIM(1, 2); r.b_o10 = SLAM_GIM(2, 1); r.b_d1 = SLAM_GRE(2, 2);
+        return r;
+    } else {
+        return GateRegs<GC>{G};
+    }
+}
+template <int GC>
+__device__ __forceinline__ void gate_col(const GateRegs<GC>& g, double (&Fr)[4], double (&Fi)[4]) {
+    if constexpr (GC == GC_XRI) {
+        {
+            const double ar = Fr[0], ai = Fi[0], br = Fr[3], bi = Fi[3];
+            Fr[0] = fma(g.a_d0, ar, -g.a_o01 * bi);
+            Fi[0] = fma(g.a_d0, ai, g.a_o01 * br);
+            Fr[3] = fma(g.a_d1, br, -g.a_o10 * ai);
+            Fi[3] = fma(g.a_d1, bi, g.a_o10 * ar);
+        }
+        {
+            const double ar = Fr[1], ai = Fi[1], br = Fr[2], bi = Fi[2];
+            Fr[1] = fma(g.b_d0, ar, -g.b_o01 * bi);
+            Fi[1] = fma(g.b_d0, ai, g.b_o01 * br);
+            Fr[2] = fma(g.b_d1, br, -g.b_o10 * ai);
+            Fi[2] = fma(g.b_d1, bi, g.b_o10 * ar);
+        }
+    } else {
+        gate_col<GC>(g.G, Fr, Fi);
+    }
+}
+template <int GC>
+__device__ __forceinline__ void gate_row(const GateRegs<GC>& g, double (&Ur)[4], double (&Ui)[4]) {
+    if constexpr (GC == GC_XRI) {
+        {
+            const double ar = Ur[0], ai = Ui[0], br = Ur[3], bi = Ui[3];
+            Ur[0] = fma(g.a_d0, ar, -g.a_o10 * bi);
+            Ui[0] = fma(g.a_d0, ai, g.a_o10 * br);
+            Ur[3] = fma(g.a_d1, br, -g.a_o01 * ai);
+            Ui[3] = fma(g.a_d1, bi, g.a_o01 * ar);
+        }
+        {
+            const double ar = Ur[1], ai = Ui[1], br = Ur[2], bi = Ui[2];
+            Ur[1] = fma(g.b_d0, ar, -g.b_o10 * bi);
+            Ui[1] = fma(g.b_d0, ai, g.b_o10 * br);
+            Ur[2] = fma(g.b_d1, br, -g.b_o01 * ai);
+            Ui[2] = fma(g.b_d1, bi, g.b_o01 * ar);
+        }
+    } else {
+        gate_row<GC>(g.G, Ur, Ui);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Fused forward chain + BasicCost + analytic gradient for the quad's item.
 //   xd    this lane's parameter slots: xd[a] = x[4a + q]
@@ -445,43 +523,88 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     // ---- 1. trig table: each lane handles its own parameter slots
     {
         double2* t2 = reinterpret_cast<double2*>(xq);
+        if constexpr (HUGE_ARGS) {
 #pragma unroll
-        for (int a = 0; a < C::NA; ++a) {
-            const int i = 4 * a + q;
-            const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
-            const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
-            double s, c;
-            if (HUGE_ARGS) sincos_any(arg, tbl, s, c);
-            else sincos_tbl(arg, tbl, s, c);
-            t2[i] = make_double2(c, s);
+            for (int a = 0; a < C::NA; ++a) {
+                const int i = 4 * a + q;
+                const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
+                const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
+                double s, c;
+                sincos_any(arg, tbl, s, c);
+                t2[i] = make_double2(c, s);
+            }
+        } else {
+            // all table entries are requested before the first polynomial: one exposed LDS latency instead of NA (the
+            // compiler cannot move a table read above the previous slot's store -- both live in the same LDS array)
+            double rr[C::NA];
+            int kk[C::NA];
+            double2 tt[C::NA];
+#pragma unroll
+            for (int a = 0; a < C::NA; ++a) {
+                const int i = 4 * a + q;
+                const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
+                const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
+                sincos_tbl_lookup(arg, tbl, rr[a], kk[a], tt[a]);
+            }
+#pragma unroll
+            for (int a = 0; a < C::NA; ++a) {
+                double s, c;
+                sincos_tbl_finish(rr[a], kk[a], tt[a], s, c);
+                t2[4 * a + q] = make_double2(c, s);
+            }
         }
     }
     lds_fence();
 
     // ---- 2. forward: F = column q of the running product
+    // LEAN: P = h_{j-1} while the backward pass is at layer j.  h_{K-1} never goes through LDS; the others are read ONCE,
+    // at the top of layer j -- a hundred operations before their first use (f_j = G_j h_{j-1}) -- and then stay in
+    // registers as the next layer's h
+    double Pr[4], Pi[4];
     double Fr[4], Fi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         Fr[r] = (r == q) ? 1.0 : 0.0;
         Fi[r] = 0.0;
     }
+    // the next layer's trig entries are requested half a layer ahead (before the qubit-1 gate is applied)
+    U3t Bn = load_u3(xq, 0), An = load_u3(xq, 3);
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
         if (j > 0 && !LEAN) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) fh[((2 * (j - 1)) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
         }
-        const U3t B = load_u3(xq, 6 * j);      // qubit 0 gate
-        const U3t A = load_u3(xq, 6 * j + 3);  // qubit 1 gate
+        const U3t B = Bn;  // qubit 0 gate
+        const U3t A = An;  // qubit 1 gate
+        GateRegs<GC> Gf;
+        if (j < K) {
+            // requested as soon as the trig entries have arrived (an LDS wait with scalar loads in flight would have to
+            // wait for those as well), consumed after the layer's 64 operations
+            if constexpr (GC == GC_XRI) u3_arrived(B, A);
+            Gf = load_gate<GC>(gates, j);
+            if constexpr (GC == GC_XRI) __builtin_amdgcn_sched_barrier(0);
+        }
         u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
         u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
+        if (j < K) {
+            Bn = load_u3(xq, 6 * (j + 1));
+            An = load_u3(xq, 6 * (j + 1) + 3);
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads to their first use)
+        }
         u3_col(A, Fr[0], Fi[0], Fr[2], Fi[2]);
         u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
         if (j < K) {
+            if (LEAN && j == K - 1) {
+                // the last stored vector is needed again a layer and a half later: it stays in registers
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fh[(HS(j) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
+                for (int r = 0; r < 4; ++r) { Pr[r] = Fr[r]; Pi[r] = Fi[r]; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fh[(HS(j) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);
+            }
             // F <- G_{j+1} F
-            gate_col<GC>(gate_matrix(gates, j), Fr, Fi);
+            gate_col<GC>(Gf, Fr, Fi);
         }
     }
     // column q of W = template unitary (CircuitTemplate.eval)
@@ -514,20 +637,41 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         Ur[r] = zr * tre[r] + zi * tim[r];
         Ui[r] = zi * tre[r] - zr * tim[r];
     }
+    constexpr bool kBwdTrigAhead = (K == 1);
     double Hr[4], Hi[4];  // h = output of the current layer (registers for j = K)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Hr[r] = Fr[r]; Hi[r] = Fi[r]; }
 #pragma unroll
     for (int j = K; j >= 0; --j) {
-        if (j < K) {
+        if (!LEAN && j < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double2 v = fh[(HS(j) * 4 + r) * kRow];
                 Hr[r] = v.x; Hi[r] = v.y;
             }
         }
-        const U3t B = load_u3(xq, 6 * j);
-        const U3t A = load_u3(xq, 6 * j + 3);
+        // layer K's trig entries are still in registers from the forward pass; layer j - 1's are requested below, before
+        // this layer's pair sums are stored
+        // (K = 1 only: at longer spans the 24 registers are not there)
+        if constexpr (!kBwdTrigAhead) {
+            Bn = load_u3(xq, 6 * j);
+            An = load_u3(xq, 6 * j + 3);
+        }
+        const U3t B = Bn;
+        const U3t A = An;
+        if (LEAN && j > 0 && j < K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double2 v = fh[(HS(j - 1) * 4 + r) * kRow];
+                Pr[r] = v.x; Pi[r] = v.y;
+            }
+        }
+        GateRegs<GC> Gb;
+        if (j > 0) {  // one request for both uses below, issued once this layer's trig entries have arrived
+            if constexpr (GC == GC_XRI) u3_arrived(B, A);
+            Gb = load_gate<GC>(gates, j - 1);
+            if constexpr (GC == GC_XRI) __builtin_amdgcn_sched_barrier(0);
+        }
         // phi: dU/dphi = i diag(0,1) U  ->  -Im( sum over rows with that qubit's bit set of u*h )
         const double m1 = im_mul(Ur[1], Ui[1], Hr[1], Hi[1]);
         const double m2 = im_mul(Ur[2], Ui[2], Hr[2], Hi[2]);
@@ -553,12 +697,17 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         // f = input of layer j
         double fr[4], fi[4];
         if (j > 0) {
+            if (LEAN) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((LEAN ? HS(j - 1) : 2 * (j - 1)) * 4 + r) * kRow];
-                fr[r] = v.x; fi[r] = v.y;
+                for (int r = 0; r < 4; ++r) { fr[r] = Pr[r]; fi[r] = Pi[r]; }
+                gate_col<GC>(Gb, fr, fi);  // f_j = G_j h_{j-1}
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 v = fh[(2 * (j - 1) * 4 + r) * kRow];
+                    fr[r] = v.x; fi[r] = v.y;
+                }
             }
-            if (LEAN) gate_col<GC>(gate_matrix(gates, j - 1), fr, fi);  // f_j = G_j h_{j-1}
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fr[r] = (r == q) ? 1.0 : 0.0; fi[r] = 0.0; }
@@ -583,6 +732,11 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         // ends up as the double2 at xq + 2 i, so its owner lane reads it back with one ds_read_b128 at a fixed offset
         // from a per-lane base -- no lane-dependent address arithmetic, no bank conflicts (the old gather read four
         // b64 words per parameter from the stored-vector slots: ~20 integer instructions each and a 2-way conflict)
+        if (kBwdTrigAhead && j > 0) {
+            Bn = load_u3(xq, 6 * (j - 1));
+            An = load_u3(xq, 6 * (j - 1) + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
             const double ps = part[m] + dpp_f64<0xB1>(part[m]);
@@ -590,7 +744,11 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         }
         if (j > 0) {
             // u <- u~ G_j
-            gate_row<GC>(gate_matrix(gates, j - 1), Ur, Ui);
+            gate_row<GC>(Gb, Ur, Ui);
+            if (LEAN) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { Hr[r] = Pr[r]; Hi[r] = Pi[r]; }
+            }
         }
     }
 
@@ -598,11 +756,11 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     lds_fence();
     {
         const double2* ps2 = reinterpret_cast<const double2*>(xq) + q;
+        double2 ps[C::NA];
 #pragma unroll
-        for (int a = 0; a < C::NA; ++a) {
-            const double2 ps = ps2[4 * a];
-            gd[a] = (4 * a + q < C::N) ? ps.x + ps.y : 0.0;
-        }
+        for (int a = 0; a < C::NA; ++a) ps[a] = ps2[4 * a];
+#pragma unroll
+        for (int a = 0; a < C::NA; ++a) gd[a] = (4 * a + q < C::N) ? ps[a].x + ps[a].y : 0.0;
     }
     lds_fence();
 }

@@ -64,11 +64,19 @@ constexpr int kSincosTableDoubles = 64;
 // table (sign from bit 5 of n), (cos, sin)(r) from degree-7/8 Taylor polynomials, combined by the angle
 // addition formulas.  26 instructions on the device against 41 for sincos_fast (no quadrant selects, short
 // polynomials); same accuracy (|abs err| < 3e-16) for |x| < 2e8.
+// The evaluation is split in two so that a caller with several arguments can request all table entries first and
+// run the polynomials while they are on their way from LDS (sincos_tbl_lookup for every argument, then
+// sincos_tbl_finish for every argument); sincos_tbl is the two in sequence.
 template <class Tbl>
-SLAM_HD void sincos_tbl(double x, const Tbl* tbl /* double2-like {x = cos, y = sin} [32] */, double& s, double& c) {
+SLAM_HD void sincos_tbl_lookup(double x, const Tbl* tbl /* double2-like {x = cos, y = sin} [32] */, double& r, int& k, Tbl& t) {
     const double n = rint(x * 10.185916357881301489);          // x * 32/pi
-    double r = fma(-n, 9.8174770424681034876e-02, x);           // pi/32 high part  (= pi/2 high / 16)
+    k = (int)n;
+    t = tbl[k & 31];
+    r = fma(-n, 9.8174770424681034876e-02, x);                  // pi/32 high part  (= pi/2 high / 16)
     r = fma(-n, 3.8270212473354786788e-18, r);                  // pi/32 low part   (= pi/2 low / 16)
+}
+template <class Tbl>
+SLAM_HD void sincos_tbl_finish(double r, int k, const Tbl& t, double& s, double& c) {
     const double z = r * r;
     double ps = fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03);
     ps = fma(z, ps, -1.66666666666666666667e-01);
@@ -76,8 +84,6 @@ SLAM_HD void sincos_tbl(double x, const Tbl* tbl /* double2-like {x = cos, y = s
     double pc = fma(z, 2.48015873015873015873e-05, -1.38888888888888888889e-03);
     pc = fma(z, pc, 4.16666666666666666667e-02);
     const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
-    const int k = (int)n;
-    const Tbl t = tbl[k & 31];
     const double c0 = fma(t.x, cr, -(t.y * sr));
     const double s0 = fma(t.y, cr, t.x * sr);
     // odd half-turns: (cos, sin)(a + pi) = -(cos, sin)(a)
@@ -89,6 +95,14 @@ SLAM_HD void sincos_tbl(double x, const Tbl* tbl /* double2-like {x = cos, y = s
     c = (k & 32) ? -c0 : c0;
     s = (k & 32) ? -s0 : s0;
 #endif
+}
+template <class Tbl>
+SLAM_HD void sincos_tbl(double x, const Tbl* tbl, double& s, double& c) {
+    double r;
+    int k;
+    Tbl t;
+    sincos_tbl_lookup(x, tbl, r, k, t);
+    sincos_tbl_finish(r, k, t, s, c);
 }
 
 }  // namespace slamdev
