@@ -504,6 +504,9 @@ __device__ __forceinline__ void gate_row(const GateRegs<GC>& g, double (&Ur)[4],
 // HUGE_ARGS: also handle |x| >= 2e9 (out-of-line ocml path).  The optimizer kernel keeps |x| far
 // below that (x0 in [0, 2 pi) or validated by the host, steps <= 2 rad) and instantiates false, so no
 // function call -- and none of the register save/restore traffic a call site drags in -- sits in its loop.
+#ifndef KEEPTOP
+#define KEEPTOP 3
+#endif
 template <int K, bool HUGE_ARGS, int GC>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double* tcol,
                                           const double* gates, double* xq, double2* fh, const double2* tbl,
@@ -546,6 +549,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
                 const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
                 sincos_tbl_lookup(arg, tbl, rr[a], kk[a], tt[a]);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < C::NA; ++a) {
                 double s, c;
@@ -638,6 +642,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         Ui[r] = zi * tre[r] - zr * tim[r];
     }
     constexpr bool kBwdTrigAhead = (K == 1);
+    constexpr bool kKeepTopTrig = (K <= KEEPTOP);  // layer K's trig entries stay in registers from the forward pass
     double Hr[4], Hi[4];  // h = output of the current layer (registers for j = K)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Hr[r] = Fr[r]; Hi[r] = Fi[r]; }
@@ -653,9 +658,11 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         // layer K's trig entries are still in registers from the forward pass; layer j - 1's are requested below, before
         // this layer's pair sums are stored
         // (K = 1 only: at longer spans the 24 registers are not there)
-        if constexpr (!kBwdTrigAhead) {
-            Bn = load_u3(xq, 6 * j);
-            An = load_u3(xq, 6 * j + 3);
+        if constexpr (!kKeepTopTrig) {
+            if (j == K) {
+                An = load_u3(xq, 6 * j + 3);
+                Bn = load_u3(xq, 6 * j);
+            }
         }
         const U3t B = Bn;
         const U3t A = An;
@@ -742,6 +749,13 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             const double ps = part[m] + dpp_f64<0xB1>(part[m]);
             if ((q & 1) == 0) xq[12 * j + 2 * m + (q >> 1)] = ps;
         }
+        if (!kBwdTrigAhead && j > 0) {
+            // K >= 2: requested here, behind the pair-sum stores (no registers to spare earlier): the gate's row action and
+            // the next layer's phi partials run under the LDS latency.  The qubit-1 gate is applied first: its entries first
+            An = load_u3(xq, 6 * (j - 1) + 3);
+            Bn = load_u3(xq, 6 * (j - 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (j > 0) {
             // u <- u~ G_j
             gate_row<GC>(Gb, Ur, Ui);
@@ -811,9 +825,18 @@ __device__ __forceinline__ void h_matvec(const HMat<NA>& H, const double (&vd)[N
     f32x2 acc[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) acc[a] = f32x2{0.0f, 0.0f};
+    // every column block's broadcast is requested before the first product (one exposed LDS latency instead of NA)
+    // (not at span 5: the 36 + 32 registers of the two batches are not there)
+    constexpr bool kBatch = NA <= 8;
+    f32x4 vall[NA];
+    if constexpr (kBatch) {
+#pragma unroll
+        for (int b = 0; b < NA; ++b) vall[b] = *reinterpret_cast<const f32x4*>(xq32 + 4 * b);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int b = 0; b < NA; ++b) {
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(xq32 + 4 * b);
+        const f32x4 vb = kBatch ? vall[b] : *reinterpret_cast<const f32x4*>(xq32 + 4 * b);
         const f32x2 vb0 = f32x2{vb.x, vb.y}, vb1 = f32x2{vb.z, vb.w};
         f32x2 t0 = f32x2{0.0f, 0.0f}, t1 = f32x2{0.0f, 0.0f};
 #pragma unroll
@@ -834,11 +857,17 @@ __device__ __forceinline__ void h_matvec(const HMat<NA>& H, const double (&vd)[N
         }
     }
     lds_fence();
+    f32x4 tall[NA];
+    if constexpr (kBatch) {
+#pragma unroll
+        for (int a = 1; a < NA; ++a) tall[a] = *reinterpret_cast<const f32x4*>(xt + (4 * a + q) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         float o = acc[a].x + acc[a].y;
         if (a >= 1) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(xt + (4 * a + q) * 4);
+            const f32x4 t = kBatch ? tall[a] : *reinterpret_cast<const f32x4*>(xt + (4 * a + q) * 4);
             o += (t.x + t.y) + (t.z + t.w);
         }
         out[a] = (double)o;
