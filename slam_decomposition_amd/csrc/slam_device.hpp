@@ -76,8 +76,12 @@ __host__ __device__ constexpr bool lean_layout() { return GC != 0; }  // every c
 template <int K, int GC>
 __host__ __device__ constexpr int lds_work_doubles() { return lean_layout<K, GC>() ? Cfg<K>::LDS_DOUBLES_LEAN : Cfg<K>::LDS_DOUBLES; }
 // ... plus the wave's copy of the 32-entry (cos, sin) table of sincos_tbl, after the working areas
+// ... plus the convergence thresholds of the launch (gtol, stop_loss, gtol_far, far_loss): tested every round, and as
+// kernel arguments they were re-read from the kernarg segment right in front of the test (a scalar-cache latency exposed
+// twice per round); an LDS read is requested ahead and counted exactly by lgkmcnt
+constexpr int kColdDoubles = 4;
 template <int K, int GC>
-__host__ __device__ constexpr int lds_doubles() { return lds_work_doubles<K, GC>() + kSincosTableDoubles; }
+__host__ __device__ constexpr int lds_doubles() { return lds_work_doubles<K, GC>() + kSincosTableDoubles + kColdDoubles; }
 
 __device__ const double kSinCosTable[kSincosTableDoubles] = SLAM_SINCOS_TABLE;
 
@@ -513,6 +517,14 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
                                           int q, int cost_kind, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
                                           double (&Wi)[4]) {
     using C = Cfg<K>;
+    // bit a set: this lane's slot a (parameter 4a + q) is a theta (parameter index divisible by 3)
+    int theta_bits = 0;
+#pragma unroll
+    for (int a = 0; a < C::NA; ++a) {
+        const int i = 4 * a + q;
+        theta_bits |= ((i - 3 * ((i * 43) >> 7)) == 0) << a;  // i % 3 for i < 128
+    }
+    asm volatile("" : "+v"(theta_bits));  // one register, not NA hoisted lane masks
     constexpr bool LEAN = lean_layout<K, GC>();
     auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
     // the target column is requested first and consumed after the forward pass
@@ -542,18 +554,20 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             double rr[C::NA];
             int kk[C::NA];
             double2 tt[C::NA];
+            const SincosLits L = sincos_lits_device();
 #pragma unroll
             for (int a = 0; a < C::NA; ++a) {
-                const int i = 4 * a + q;
-                const int i3 = i - 3 * ((i * 43) >> 7);  // i % 3 for i < 128
-                const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
-                sincos_tbl_lookup(arg, tbl, rr[a], kk[a], tt[a]);
+                // theta slots take the half angle: bit a of theta_bits is set when parameter 4a + q is a theta -> exponent
+                // -1 (sign-extended bit-field extract) for v_ldexp_f64, which gets zeros and denormals right.  (The
+                // select form cost a multiplication, two v_cndmask and a lane mask in a scalar register pair per slot.)
+                const double arg = __builtin_amdgcn_ldexp(xd[a], __builtin_amdgcn_sbfe(theta_bits, a, 1));
+                sincos_tbl_lookup(arg, tbl, L, rr[a], kk[a], tt[a]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < C::NA; ++a) {
                 double s, c;
-                sincos_tbl_finish(rr[a], kk[a], tt[a], s, c);
+                sincos_tbl_finish(rr[a], kk[a], tt[a], L, s, c);
                 t2[4 * a + q] = make_double2(c, s);
             }
         }

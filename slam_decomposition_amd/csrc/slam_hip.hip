@@ -283,7 +283,7 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.exit_loss = sl.exit_loss;
     a.seed = prm->seed;
     a.target_base = prm->target_base;
-    a.flags = prm->flags;
+    a.flags = prm->flags & (SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED);  // (the upper bits are internal: kFlagTrace)
     a.items_per_quad = prm->items_per_quad;
     a.cost_kind = c->cost_kind;
     a.solved = c->solved.as<int32_t>();
@@ -295,6 +295,7 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.item_acc = c->item_acc.as<int32_t>();
     a.trace_cap = c->trace_cap;
     a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
+    if (a.trace_loss) a.flags |= kFlagTrace;
     a.trace_x = c->trace_cap > 0 ? c->trace_x.as<double>() : nullptr;
     { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
     // persistent wavefronts: never more blocks than can be resident, every quad pulls items.  The grid is

@@ -30,6 +30,9 @@ struct StageCtl {
 };
 static_assert(sizeof(StageCtl) == 64, "StageCtl layout");
 
+// internal bit of MinimizeArgs::flags (beside SLAM_FLAG_*): the launch records per-iteration traces
+constexpr uint32_t kFlagTrace = 0x100u;
+
 template <int K>
 struct MinimizeArgs {
     const double* targets;    // [n_active][32]: target of stage slot s (gathered, or the resident array itself)
@@ -160,6 +163,11 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
     double2* fh = fhbase + lane;
     double2* tbl = reinterpret_cast<double2*>(lds + lds_work_doubles<K, GC>());
     load_sincos_table(tbl, lane);
+    double2* cold = tbl + kSincosTableDoubles / 2;  // (gtol, stop_loss), (gtol_far, far_loss)
+    if (lane == 0) {
+        cold[0] = make_double2(args.gtol, args.stop_loss);
+        cold[1] = make_double2(args.gtol_far, args.far_loss);
+    }
     lds_fence();
     // ---- launch shape from the device-side target count (the grid is sized for the host's upper bound)
     const unsigned n_act = (unsigned)args.ctl->n_active;
@@ -405,6 +413,9 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             __builtin_amdgcn_sched_barrier(0);
         }
         wg = quad_sum(wg);
+        // convergence thresholds: requested here, tested at the end of the state machine
+        const double2 th0 = cold[0], th1 = cold[1];
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- 4. per-quad state machine
         // x <- x + s outside the branch: s = am p is zero unless the step was accepted, so no per-component select
@@ -425,13 +436,19 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                 g[a] = gt[a];
                 p[a] = -(qv[a] + sa * wg + va * sg);
             }
-            if (cold_args<K>()->trace_loss && step && iters <= cold_args<K>()->trace_cap) {  // wave-uniform pointer test: nothing when off
-                const int64_t row = (int64_t)item * cold_args<K>()->trace_cap + (iters - 1);
-                if (q == 0) cold_args<K>()->trace_loss[row] = f;
+            if (args.flags & kFlagTrace) {  // wave-uniform flag test: nothing when off
+                const auto* ca = cold_args<K>();
+                const int t_cap = ca->trace_cap;
+                double* const t_loss = ca->trace_loss;
+                double* const t_x = ca->trace_x;
+                if (step && iters <= t_cap) {
+                const int64_t row = (int64_t)item * t_cap + (iters - 1);
+                if (q == 0) t_loss[row] = f;
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
                     const int i = 4 * a + q;
-                    if (i < C::N) cold_args<K>()->trace_x[row * C::N + i] = x[a];
+                    if (i < C::N) t_x[row * C::N + i] = x[a];
+                }
                 }
             }
         } else if (active) {
@@ -458,7 +475,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         pp = qdot<NA>(p, p);
         if (acc) {
             alpha = (pp > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(pp)) : grow;
-            if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) {
+            if (f < th0.y || gnorm < th0.x || (gnorm < th1.x && f > th1.y)) {
                 status = ST_CONVERGED; done = true;
             } else if (nstall >= 2) { status = ST_STALLED; done = true; }
             else if (iters >= args.maxiter) { status = ST_MAXITER; done = true; }

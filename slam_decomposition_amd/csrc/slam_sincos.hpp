@@ -67,22 +67,54 @@ constexpr int kSincosTableDoubles = 64;
 // The evaluation is split in two so that a caller with several arguments can request all table entries first and
 // run the polynomials while they are on their way from LDS (sincos_tbl_lookup for every argument, then
 // sincos_tbl_finish for every argument); sincos_tbl is the two in sequence.
+//
+// The nine fp64 literals travel in a struct: a 64-bit literal needs a scalar register pair on gfx950, and inside the
+// optimizer loop the compiler hoisted them out of the loop and then spilled them into VGPR lanes (a v_readlane -- a
+// vector-ALU slot -- per use).  sincos_lits_device() hands them out through an empty asm, so they are materialised
+// (two s_mov_b32 each) once per evaluation and die with it.
+struct SincosLits {
+    double inv;         // 32/pi
+    double hi, lo;      // pi/32 in two parts (= pi/2 high / 16, pi/2 low / 16)
+    double s2, s1, s0;  // sin(r) = r + r^3 (s0 + z (s1 + z s2)), z = r^2
+    double c2, c1, c0;  // cos(r) = 1 - z/2 + z^2 (c0 + z (c1 + z c2))
+};
+SLAM_HD SincosLits sincos_lits() {
+    return SincosLits{10.185916357881301489,    9.8174770424681034876e-02, 3.8270212473354786788e-18,
+                      -1.98412698412698412698e-04, 8.33333333333333333333e-03, -1.66666666666666666667e-01,
+                      2.48015873015873015873e-05, -1.38888888888888888889e-03, 4.16666666666666666667e-02};
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ double sincos_opaque(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(c));
+#endif
+    return c;
+}
+__device__ __forceinline__ SincosLits sincos_lits_device() {
+    SincosLits l = sincos_lits();
+    l.inv = sincos_opaque(l.inv); l.hi = sincos_opaque(l.hi); l.lo = sincos_opaque(l.lo);
+    l.s2 = sincos_opaque(l.s2); l.s1 = sincos_opaque(l.s1); l.s0 = sincos_opaque(l.s0);
+    l.c2 = sincos_opaque(l.c2); l.c1 = sincos_opaque(l.c1); l.c0 = sincos_opaque(l.c0);
+    return l;
+}
+#endif
 template <class Tbl>
-SLAM_HD void sincos_tbl_lookup(double x, const Tbl* tbl /* double2-like {x = cos, y = sin} [32] */, double& r, int& k, Tbl& t) {
-    const double n = rint(x * 10.185916357881301489);          // x * 32/pi
+SLAM_HD void sincos_tbl_lookup(double x, const Tbl* tbl /* double2-like {x = cos, y = sin} [32] */, const SincosLits& L, double& r,
+                               int& k, Tbl& t) {
+    const double n = rint(x * L.inv);
     k = (int)n;
     t = tbl[k & 31];
-    r = fma(-n, 9.8174770424681034876e-02, x);                  // pi/32 high part  (= pi/2 high / 16)
-    r = fma(-n, 3.8270212473354786788e-18, r);                  // pi/32 low part   (= pi/2 low / 16)
+    r = fma(-n, L.hi, x);
+    r = fma(-n, L.lo, r);
 }
 template <class Tbl>
-SLAM_HD void sincos_tbl_finish(double r, int k, const Tbl& t, double& s, double& c) {
+SLAM_HD void sincos_tbl_finish(double r, int k, const Tbl& t, const SincosLits& L, double& s, double& c) {
     const double z = r * r;
-    double ps = fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03);
-    ps = fma(z, ps, -1.66666666666666666667e-01);
+    double ps = fma(z, L.s2, L.s1);
+    ps = fma(z, ps, L.s0);
     const double sr = fma(r * z, ps, r);
-    double pc = fma(z, 2.48015873015873015873e-05, -1.38888888888888888889e-03);
-    pc = fma(z, pc, 4.16666666666666666667e-02);
+    double pc = fma(z, L.c2, L.c1);
+    pc = fma(z, pc, L.c0);
     const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
     const double c0 = fma(t.x, cr, -(t.y * sr));
     const double s0 = fma(t.y, cr, t.x * sr);
@@ -98,11 +130,12 @@ SLAM_HD void sincos_tbl_finish(double r, int k, const Tbl& t, double& s, double&
 }
 template <class Tbl>
 SLAM_HD void sincos_tbl(double x, const Tbl* tbl, double& s, double& c) {
+    const SincosLits L = sincos_lits();
     double r;
     int k;
     Tbl t;
-    sincos_tbl_lookup(x, tbl, r, k, t);
-    sincos_tbl_finish(r, k, t, s, c);
+    sincos_tbl_lookup(x, tbl, L, r, k, t);
+    sincos_tbl_finish(r, k, t, L, s, c);
 }
 
 }  // namespace slamdev
