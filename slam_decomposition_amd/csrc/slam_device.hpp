@@ -205,6 +205,18 @@ __device__ __forceinline__ void u3_col(const U3t& t, double& f0r, double& f0i, d
     f1i = t.cp * ti + t.sp * tr;
 }
 
+// column e of U3, e = 0 or 1 given as the real pair (f0, f1) = (1 - e, e): the column action on a real unit vector
+// (12 operations instead of 16; bit for bit what u3_col computes from (f0, 0, f1, 0))
+__device__ __forceinline__ void u3_unit(const U3t& t, double f0, double f1, double& y0r, double& y0i, double& y1r, double& y1i) {
+    const double g1r = t.cl * f1, g1i = t.sl * f1;
+    y0r = t.c * f0 - t.s * g1r;
+    y0i = -(t.s * g1i);
+    const double tr = t.s * f0 + t.c * g1r;
+    const double ti = t.c * g1i;
+    y1r = t.cp * tr - t.sp * ti;
+    y1i = t.cp * ti + t.sp * tr;
+}
+
 // row action: (u0, u1) <- (u0, u1) U3
 __device__ __forceinline__ void u3_row(const U3t& t, double& u0r, double& u0i, double& u1r, double& u1i) {
     const double g1r = t.cp * u1r - t.sp * u1i;
@@ -239,6 +251,14 @@ __device__ __forceinline__ void dtheta_dlam_last(const U3t& g, double n0r, doubl
                                                  double f1r, double f1i, double& dth, double& dlam) {
     const double gr = g.cl * f1r - g.sl * f1i, gi = g.cl * f1i + g.sl * f1r;  // e^{i lam} f1
     dth = 0.5 * ((tr * f0r - ti * f0i) - (n0r * gr - n0i * gi));
+    dlam = -(tr * gi + ti * gr);
+}
+
+// the same for a REAL input pair (f0, f1) -- layer 0, whose input is the unit vector e_q (8 operations instead of 13)
+__device__ __forceinline__ void dtheta_dlam_last_real(const U3t& g, double n0r, double n0i, double tr, double ti, double f0, double f1,
+                                                      double& dth, double& dlam) {
+    const double gr = g.cl * f1, gi = g.sl * f1;  // e^{i lam} f1
+    dth = 0.5 * (tr * f0 - (n0r * gr - n0i * gi));
     dlam = -(tr * gi + ti * gr);
 }
 
@@ -579,6 +599,12 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     // at the top of layer j -- a hundred operations before their first use (f_j = G_j h_{j-1}) -- and then stay in
     // registers as the next layer's h
     double Pr[4], Pi[4];
+    // this lane's unit vector e_q as real pairs per qubit: (1 - bit, bit)
+    // (from an opaque copy of q: four selects per evaluation instead of eight registers live across the optimizer loop)
+    int qo = q;
+    asm volatile("" : "+v"(qo));
+    const double e0[2] = {(qo & 1) ? 0.0 : 1.0, (qo & 1) ? 1.0 : 0.0};
+    const double e1[2] = {(qo & 2) ? 0.0 : 1.0, (qo & 2) ? 1.0 : 0.0};
     double Fr[4], Fi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -603,15 +629,30 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             Gf = load_gate<GC>(gates, j);
             if constexpr (GC == GC_XRI) __builtin_amdgcn_sched_barrier(0);
         }
-        u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
-        u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
+        double b0r, b0i, b1r, b1i;
+        if (j == 0) {
+            // layer 0 acts on the unit vector e_q:  K_0 e_q = (A e_{q >> 1}) (x) (B e_{q & 1}) -- 40 operations instead of 64
+            u3_unit(B, e0[0], e0[1], b0r, b0i, b1r, b1i);
+        } else {
+            u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
+            u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
+        }
         if (j < K) {
             Bn = load_u3(xq, 6 * (j + 1));
             An = load_u3(xq, 6 * (j + 1) + 3);
             __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads to their first use)
         }
-        u3_col(A, Fr[0], Fi[0], Fr[2], Fi[2]);
-        u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
+        if (j == 0) {
+            double a0r, a0i, a1r, a1i;
+            u3_unit(A, e1[0], e1[1], a0r, a0i, a1r, a1i);
+            Fr[0] = a0r * b0r - a0i * b0i; Fi[0] = a0r * b0i + a0i * b0r;
+            Fr[1] = a0r * b1r - a0i * b1i; Fi[1] = a0r * b1i + a0i * b1r;
+            Fr[2] = a1r * b0r - a1i * b0i; Fi[2] = a1r * b0i + a1i * b0r;
+            Fr[3] = a1r * b1r - a1i * b1i; Fi[3] = a1r * b1i + a1i * b1r;
+        } else {
+            u3_col(A, Fr[0], Fi[0], Fr[2], Fi[2]);
+            u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
+        }
         if (j < K) {
             if (LEAN && j == K - 1) {
                 // the last stored vector is needed again a layer and a half later: it stays in registers
@@ -656,6 +697,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         Ui[r] = zi * tre[r] - zr * tim[r];
     }
     constexpr bool kBwdTrigAhead = (K == 1);
+    constexpr bool kEarlyP = (K <= 4);
     constexpr bool kKeepTopTrig = (K <= KEEPTOP);  // layer K's trig entries stay in registers from the forward pass
     double Hr[4], Hi[4];  // h = output of the current layer (registers for j = K)
 #pragma unroll
@@ -680,7 +722,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         }
         const U3t B = Bn;
         const U3t A = An;
-        if (LEAN && j > 0 && j < K) {
+        if (LEAN && kEarlyP && j > 0 && j < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double2 v = fh[(HS(j - 1) * 4 + r) * kRow];
@@ -719,6 +761,13 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         double fr[4], fi[4];
         if (j > 0) {
             if (LEAN) {
+                if (!kEarlyP && j < K) {  // span 5: no registers for the early request
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double2 v = fh[(HS(j - 1) * 4 + r) * kRow];
+                        Pr[r] = v.x; Pi[r] = v.y;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { fr[r] = Pr[r]; fi[r] = Pi[r]; }
                 gate_col<GC>(Gb, fr, fi);  // f_j = G_j h_{j-1}
@@ -730,19 +779,29 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
                 }
             }
         } else {
+            fr[0] = e1[0] * e0[0]; fr[1] = e1[0] * e0[1]; fr[2] = e1[1] * e0[0]; fr[3] = e1[1] * e0[1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { fr[r] = (r == q) ? 1.0 : 0.0; fi[r] = 0.0; }
+            for (int r = 0; r < 4; ++r) fi[r] = 0.0;
         }
         // qubit 0 (B, applied last to u): theta and lambda from the rotation intermediates
         double th01, la01, th23, la23;
-        dtheta_dlam_last(B, Ur[0], Ui[0], tB01r, tB01i, fr[0], fi[0], fr[1], fi[1], th01, la01);
-        dtheta_dlam_last(B, Ur[2], Ui[2], tB23r, tB23i, fr[2], fi[2], fr[3], fi[3], th23, la23);
+        if (j > 0) {
+            dtheta_dlam_last(B, Ur[0], Ui[0], tB01r, tB01i, fr[0], fi[0], fr[1], fi[1], th01, la01);
+            dtheta_dlam_last(B, Ur[2], Ui[2], tB23r, tB23i, fr[2], fi[2], fr[3], fi[3], th23, la23);
+        } else {  // the input of layer 0 is real (e_q)
+            dtheta_dlam_last_real(B, Ur[0], Ui[0], tB01r, tB01i, fr[0], fr[1], th01, la01);
+            dtheta_dlam_last_real(B, Ur[2], Ui[2], tB23r, tB23i, fr[2], fr[3], th23, la23);
+        }
         part[0] = th01 + th23;
         part[2] = la01 + la23;
         // qubit 1 (A): lambda: dU/dlam = U i diag(0,1); theta: generic form
-        const double l2 = im_mul(Ur[2], Ui[2], fr[2], fi[2]);
-        const double l3 = im_mul(Ur[3], Ui[3], fr[3], fi[3]);
-        part[5] = -(l2 + l3);
+        if (j > 0) {
+            const double l2 = im_mul(Ur[2], Ui[2], fr[2], fi[2]);
+            const double l3 = im_mul(Ur[3], Ui[3], fr[3], fi[3]);
+            part[5] = -(l2 + l3);
+        } else {
+            part[5] = -(Ui[2] * fr[2] + Ui[3] * fr[3]);
+        }
         if constexpr (kThetaOut)
             part[3] = 0.5 * thA2;
         else
