@@ -80,14 +80,17 @@ __host__ __device__ constexpr int lds_work_doubles() { return lean_layout<K, GC>
 // kernel arguments they were re-read from the kernarg segment right in front of the test (a scalar-cache latency exposed
 // twice per round); an LDS read is requested ahead and counted exactly by lgkmcnt
 constexpr int kColdDoubles = 4;
+constexpr int kSincosLdsDoubles = 2 * kSincosTableDoubles;  // the LDS copy of the sincos table covers the whole circle
 template <int K, int GC>
-__host__ __device__ constexpr int lds_doubles() { return lds_work_doubles<K, GC>() + kSincosTableDoubles + kColdDoubles; }
+__host__ __device__ constexpr int lds_doubles() { return lds_work_doubles<K, GC>() + kSincosLdsDoubles + kColdDoubles; }
 
 __device__ const double kSinCosTable[kSincosTableDoubles] = SLAM_SINCOS_TABLE;
 
-// copy the table into the wave's LDS (lanes 0..31: one double2 each); the caller fences
+// the wave's LDS copy covers the whole circle: entry j = (cos, sin)(j pi / 32), j = 0..63 (second half = minus the first), so
+// the lookup needs no sign fix-up (three vector instructions per sincos).  One double2 per lane; the caller fences
 __device__ __forceinline__ void load_sincos_table(double2* tbl, int lane) {
-    if (lane < 32) tbl[lane] = reinterpret_cast<const double2*>(kSinCosTable)[lane];
+    const double2 t = reinterpret_cast<const double2*>(kSinCosTable)[lane & 31];
+    tbl[lane] = (lane & 32) ? make_double2(-t.x, -t.y) : t;
 }
 
 // Gate matrices G_1..G_K of the launch: K x 32 doubles, row-major (re, im), in device memory.
@@ -514,12 +517,25 @@ __device__ __forceinline__ void gate_row(const GateRegs<GC>& g, double (&Ur)[4],
     }
 }
 
+// bit a set: slot a of lane q (parameter 4a + q) is a theta (parameter index divisible by 3).  Computed once per kernel.
+template <int K>
+__device__ __forceinline__ int theta_slot_bits(int q) {
+    int bits = 0;
+#pragma unroll
+    for (int a = 0; a < Cfg<K>::NA; ++a) {
+        const int i = 4 * a + q;
+        bits |= ((i - 3 * ((i * 43) >> 7)) == 0) << a;  // i % 3 for i < 128
+    }
+    return bits;
+}
+
 // ---------------------------------------------------------------------------------
 // Fused forward chain + BasicCost + analytic gradient for the quad's item.
 //   xd    this lane's parameter slots: xd[a] = x[4a + q]
 //   tcol  global pointer to T[0][q] of the item's target (row-major (re, im): T[r][q] is 8 r doubles on);
 //         the column is re-read every evaluation (L1/L2 hits) instead of living in 16 registers
 //   gates gate matrices G_1..G_K in device memory (scalar loads -> SGPR operands)
+//   theta_bits  theta_slot_bits<K>(q)
 //   xq    LDS: this quad's exchange area (trig table, then gradient transpose)
 //   fh    LDS: this lane's slice of the stored column vectors (stride 64 double2 per row)
 //   cost_kind  0 = BasicCost, 1 = SquareCost (wave-uniform)
@@ -534,16 +550,9 @@ __device__ __forceinline__ void gate_row(const GateRegs<GC>& g, double (&Ur)[4],
 template <int K, bool HUGE_ARGS, int GC>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double* tcol,
                                           const double* gates, double* xq, double2* fh, const double2* tbl,
-                                          int q, int cost_kind, double& fout, double (&gd)[Cfg<K>::NA], double (&Wr)[4],
-                                          double (&Wi)[4]) {
+                                          int q, int theta_bits, int cost_kind, double& fout, double (&gd)[Cfg<K>::NA],
+                                          double (&Wr)[4], double (&Wi)[4]) {
     using C = Cfg<K>;
-    // bit a set: this lane's slot a (parameter 4a + q) is a theta (parameter index divisible by 3)
-    int theta_bits = 0;
-#pragma unroll
-    for (int a = 0; a < C::NA; ++a) {
-        const int i = 4 * a + q;
-        theta_bits |= ((i - 3 * ((i * 43) >> 7)) == 0) << a;  // i % 3 for i < 128
-    }
     asm volatile("" : "+v"(theta_bits));  // one register, not NA hoisted lane masks
     constexpr bool LEAN = lean_layout<K, GC>();
     auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
@@ -581,13 +590,13 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
                 // -1 (sign-extended bit-field extract) for v_ldexp_f64, which gets zeros and denormals right.  (The
                 // select form cost a multiplication, two v_cndmask and a lane mask in a scalar register pair per slot.)
                 const double arg = __builtin_amdgcn_ldexp(xd[a], __builtin_amdgcn_sbfe(theta_bits, a, 1));
-                sincos_tbl_lookup(arg, tbl, L, rr[a], kk[a], tt[a]);
+                sincos_tbl_lookup<true>(arg, tbl, L, rr[a], kk[a], tt[a]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < C::NA; ++a) {
                 double s, c;
-                sincos_tbl_finish(rr[a], kk[a], tt[a], L, s, c);
+                sincos_tbl_finish<true>(rr[a], kk[a], tt[a], L, s, c);
                 t2[4 * a + q] = make_double2(c, s);
             }
         }

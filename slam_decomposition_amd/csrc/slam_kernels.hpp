@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad<K, true, GC>(xd, tcol, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, tbl, q, args.cost_kind, f, gd, Wr, Wi);
+    eval_quad<K, true, GC>(xd, tcol, args.gates, xchg + quad * C::XSTRIDE, fhbase + lane, tbl, q, theta_slot_bits<K>(q), args.cost_kind, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -158,12 +158,13 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
     const int lane = threadIdx.x;
     int q = lane & 3;
     const int quad = lane >> 2;
+    const int theta_bits = theta_slot_bits<K>(q);
     double* xq = xchg + quad * C::XSTRIDE;
     float* xq32 = reinterpret_cast<float*>(xchg) + quad * C::FSTRIDE;  // fp32 overlay with its own conflict-free stride
     double2* fh = fhbase + lane;
     double2* tbl = reinterpret_cast<double2*>(lds + lds_work_doubles<K, GC>());
     load_sincos_table(tbl, lane);
-    double2* cold = tbl + kSincosTableDoubles / 2;  // (gtol, stop_loss), (gtol_far, far_loss)
+    double2* cold = tbl + kSincosLdsDoubles / 2;  // (gtol, stop_loss), (gtol_far, far_loss)
     if (lane == 0) {
         cold[0] = make_double2(args.gtol, args.stop_loss);
         cold[1] = make_double2(args.gtol_far, args.far_loss);
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, tbl, q, args.cost_kind, ft, gt, Wr, Wi);
+            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
         }
         const bool active = live;
         const bool finite = isfinite(ft);

@@ -98,16 +98,17 @@ __device__ __forceinline__ SincosLits sincos_lits_device() {
     return l;
 }
 #endif
-template <class Tbl>
-SLAM_HD void sincos_tbl_lookup(double x, const Tbl* tbl /* double2-like {x = cos, y = sin} [32] */, const SincosLits& L, double& r,
+// FULL: the table holds the whole circle (64 entries, the second half = minus the first): no sign fix-up in the finish
+template <bool FULL = false, class Tbl>
+SLAM_HD void sincos_tbl_lookup(double x, const Tbl* tbl /* double2-like {x = cos, y = sin} [32 or 64] */, const SincosLits& L, double& r,
                                int& k, Tbl& t) {
     const double n = rint(x * L.inv);
     k = (int)n;
-    t = tbl[k & 31];
+    t = tbl[k & (FULL ? 63 : 31)];
     r = fma(-n, L.hi, x);
     r = fma(-n, L.lo, r);
 }
-template <class Tbl>
+template <bool FULL = false, class Tbl>
 SLAM_HD void sincos_tbl_finish(double r, int k, const Tbl& t, const SincosLits& L, double& s, double& c) {
     const double z = r * r;
     double ps = fma(z, L.s2, L.s1);
@@ -118,6 +119,11 @@ SLAM_HD void sincos_tbl_finish(double r, int k, const Tbl& t, const SincosLits& 
     const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
     const double c0 = fma(t.x, cr, -(t.y * sr));
     const double s0 = fma(t.y, cr, t.x * sr);
+    if (FULL) {
+        c = c0;
+        s = s0;
+        return;
+    }
     // odd half-turns: (cos, sin)(a + pi) = -(cos, sin)(a)
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     const int sgn = k << 26 & (int)0x80000000;

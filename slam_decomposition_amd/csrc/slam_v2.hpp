@@ -52,7 +52,7 @@ struct CfgV2 {
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
     static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;          // f_1..f_K and h_0..h_{K-1}: [vector][row][lane + pad] double2
     static constexpr int LDS_BOUNDS = 2 * NA * 4;                // (lo, hi) per parameter, padded to 4 NA
-    static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH + LDS_BOUNDS + kSincosTableDoubles;
+    static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH + LDS_BOUNDS + kSincosLdsDoubles;
 };
 
 // ---- conversion-gain gate actions from the (cos, sin) table entries of the four raw angles -------------------------
