@@ -37,7 +37,9 @@ constexpr int kRow = kWave + 1;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int K>
+// PSQ: the quad's exchange area also holds the four lanes' gradient partials of every parameter (structured gate
+// classes; the dense class keeps the pair sums in the dead trig entries: its stored vectors leave no LDS for more)
+template <int K, bool PSQ = false>
 struct Cfg {
     static constexpr int L = K + 1;                    // 1Q layers
     static constexpr int N = 6 * L;                    // parameters (basis.py:152-169)
@@ -54,27 +56,34 @@ struct Cfg {
     // every such store (31 per round at k = 2: most of the measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 33 %).
     static constexpr int FNEED = 20 * NA - 16;
     static constexpr int FSTRIDE = (FNEED - 4 + 31) / 32 * 32 + 4;
-    static constexpr int XNEED_D = 2 * N;
+    static constexpr int XNEED_D = PSQ ? 6 * N : 2 * N;  // trig table [0, 2N); PSQ: partials [2N + 4 i, 2N + 4 i + 4) of parameter i
     static constexpr int XNEED_F = (kQuadsPerWave * FSTRIDE + 2 * kQuadsPerWave - 1) / (2 * kQuadsPerWave);  // doubles per quad so that the float overlay fits
     static constexpr int XNEED = XNEED_D > XNEED_F ? XNEED_D : XNEED_F;
     // quad stride of the double area, == 4 (mod 16) doubles = 8 (mod 32) dwords: the four quads of a ds_write_b64 group
     // (pair sums, two adjacent doubles per quad) and of a ds_read_b128 group (trig entries, one broadcast double2 per quad)
     // land on different banks; the per-lane double2 gather of the gradient keeps a partial 2-way overlap between two quads
-    static constexpr int XSTRIDE = (XNEED - 4 + 15) / 16 * 16 + 4;
+    // (== 4 (mod 8) is enough for that: 4 and 12 (mod 16) both put four consecutive quads on four different 32-byte segments)
+    static constexpr int XSTRIDE = (XNEED - 4 + 7) / 8 * 8 + 4;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
     static_assert(kQuadsPerWave * FSTRIDE * 4 <= LDS_XCHG * 8, "float overlay must fit the exchange area");
     static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;  // 2K column vectors x 4 rows x (64 lanes + pad) x (re,im)
     static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH;
     // LEAN layout (structured gate classes): only the K layer outputs h_j are stored; the layer inputs
     // f_j = G_j h_{j-1} are recomputed in the backward pass (0 / 8 / 16 products for CX / XRI / XGEN gates)
-    static constexpr int LDS_FH_LEAN = K * 4 * kRow * 2;
+    // (h_0 .. h_{K-2}: the last one, h_{K-1}, stays in registers)
+    static constexpr int LDS_FH_LEAN = (K - 1) * 4 * kRow * 2;
     static constexpr int LDS_DOUBLES_LEAN = LDS_XCHG + LDS_FH_LEAN;
 };
 
 template <int K, int GC>
 __host__ __device__ constexpr bool lean_layout() { return GC != 0; }  // every class but GC_DENSE
+// the quad partial-sum area (Cfg<K, true>): structured classes up to span 3 (beyond, its LDS would cost a wavefront per CU)
 template <int K, int GC>
-__host__ __device__ constexpr int lds_work_doubles() { return lean_layout<K, GC>() ? Cfg<K>::LDS_DOUBLES_LEAN : Cfg<K>::LDS_DOUBLES; }
+__host__ __device__ constexpr bool psq_layout() { return lean_layout<K, GC>() && K <= 3; }
+template <int K, int GC>
+__host__ __device__ constexpr int lds_work_doubles() {
+    return lean_layout<K, GC>() ? Cfg<K, psq_layout<K, GC>()>::LDS_DOUBLES_LEAN : Cfg<K, false>::LDS_DOUBLES;
+}
 // ... plus the wave's copy of the 32-entry (cos, sin) table of sincos_tbl, after the working areas
 // ... plus the convergence thresholds of the launch (gtol, stop_loss, gtol_far, far_loss): tested every round, and as
 // kernel arguments they were re-read from the kernarg segment right in front of the test (a scalar-cache latency exposed
@@ -552,9 +561,10 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
                                           const double* gates, double* xq, double2* fh, const double2* tbl,
                                           int q, int theta_bits, int cost_kind, double& fout, double (&gd)[Cfg<K>::NA],
                                           double (&Wr)[4], double (&Wi)[4]) {
-    using C = Cfg<K>;
-    asm volatile("" : "+v"(theta_bits));  // one register, not NA hoisted lane masks
     constexpr bool LEAN = lean_layout<K, GC>();
+    constexpr bool PSQ = psq_layout<K, GC>();
+    using C = Cfg<K, PSQ>;
+    asm volatile("" : "+v"(theta_bits));  // one register, not NA hoisted lane masks
     auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
     // the target column is requested first and consumed after the forward pass
     double tre[4], tim[4];
@@ -694,8 +704,12 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     const double basic = 1.0 - 0.25 * at;  // BasicCost, cost_function.py:140-145
     // SquareCost (cost_function.py:169-173): 1 - (|t|^2 + d) / (d (d + 1)), d = 4, is the monotone map
     // 0.8 (2 L - L^2) of BasicCost L, so its gradient is 1.6 (1 - L) times BasicCost's (wave-uniform select)
-    fout = (cost_kind == 1) ? 0.8 * basic * (2.0 - basic) : basic;
-    const double inv = (cost_kind == 1) ? 0.25 * rat * 1.6 * (1.0 - basic) : 0.25 * rat;
+    // written as L (c0 + c1 L) and its derivative factor d0 + d1 L with wave-uniform coefficients ((1, 0), (1, 0) for
+    // BasicCost -- exact --, (1.6, -0.8), (1.6, -1.6) for SquareCost): scalar selects instead of vector ones
+    const bool sq = (cost_kind == 1);
+    const double c0 = sq ? 1.6 : 1.0, c1 = sq ? -0.8 : 0.0, d1 = sq ? -1.6 : 0.0;
+    fout = basic * fma(c1, basic, c0);
+    const double inv = (0.25 * rat) * fma(d1, basic, c0);
     const double zr = -pr * inv, zi = pi * inv;
 
     // ---- 4. backward: u = row q of (z T^+)(suffix); accumulate this column's partials
@@ -826,10 +840,17 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             An = load_u3(xq, 6 * (j - 1) + 3);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PSQ) {
+            // every lane stores its partial: parameter i = 6 j + m gets the four doubles at xq + 2N + 4 i, which its owner
+            // reads back with two ds_read_b128 and adds up (no DPP moves, no additions on the producing side)
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const double ps = part[m] + dpp_f64<0xB1>(part[m]);
-            if ((q & 1) == 0) xq[12 * j + 2 * m + (q >> 1)] = ps;
+            for (int m = 0; m < 6; ++m) xq[2 * C::N + 4 * (6 * j + m) + q] = part[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                const double ps = part[m] + dpp_f64<0xB1>(part[m]);
+                if ((q & 1) == 0) xq[12 * j + 2 * m + (q >> 1)] = ps;
+            }
         }
         if (!kBwdTrigAhead && j > 0) {
             // K >= 2: requested here, behind the pair-sum stores (no registers to spare earlier): the gate's row action and
@@ -851,12 +872,24 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     // ---- 5. the owner of parameter i (lane i & 3, slot i >> 2) adds the two pair sums
     lds_fence();
     {
-        const double2* ps2 = reinterpret_cast<const double2*>(xq) + q;
-        double2 ps[C::NA];
+        if constexpr (PSQ) {
+            const double2* ps2 = reinterpret_cast<const double2*>(xq + 2 * C::N) + 2 * q;
+            double2 p0[C::NA], p1[C::NA];
 #pragma unroll
-        for (int a = 0; a < C::NA; ++a) ps[a] = ps2[4 * a];
+            for (int a = 0; a < C::NA; ++a) {
+                p0[a] = ps2[8 * a];
+                p1[a] = ps2[8 * a + 1];
+            }
 #pragma unroll
-        for (int a = 0; a < C::NA; ++a) gd[a] = (4 * a + q < C::N) ? ps[a].x + ps[a].y : 0.0;
+            for (int a = 0; a < C::NA; ++a) gd[a] = (4 * a + q < C::N) ? (p0[a].x + p0[a].y) + (p1[a].x + p1[a].y) : 0.0;
+        } else {
+            const double2* ps2 = reinterpret_cast<const double2*>(xq) + q;
+            double2 ps[C::NA];
+#pragma unroll
+            for (int a = 0; a < C::NA; ++a) ps[a] = ps2[4 * a];
+#pragma unroll
+            for (int a = 0; a < C::NA; ++a) gd[a] = (4 * a + q < C::N) ? ps[a].x + ps[a].y : 0.0;
+        }
     }
     lds_fence();
 }

@@ -88,7 +88,7 @@ struct EvalArgs {
 // ---------------------------------------------------------------------------------
 template <int K, int GC>
 __global__ void __launch_bounds__(kWave) eval_kernel(EvalArgs<K> args) {
-    using C = Cfg<K>;
+    using C = Cfg<K, psq_layout<K, GC>()>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* xchg = lds;
     double2* fhbase = reinterpret_cast<double2*>(lds + C::LDS_XCHG);
@@ -150,7 +150,7 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MinimizeArgs<
 // ---------------------------------------------------------------------------------
 template <int K, int GC>
 __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args) {
-    using C = Cfg<K>;
+    using C = Cfg<K, psq_layout<K, GC>()>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* xchg = lds;
@@ -221,7 +221,10 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         // q is re-materialised every iteration: otherwise the lane-dependent LDS addresses derived from it
         // (gradient gather, stash slots) are hoisted out of the loop, kept live across it, spilled to scratch
         // and reloaded -- one exposed memory latency each -- in every round
-        if constexpr (K == 2) asm volatile("" : "+v"(q));  // (measured: pays at k = 2 only)
+        if constexpr (K == 2) {
+            asm volatile("" : "+v"(q));  // (measured: pays at k = 2 only)
+            __builtin_assume((unsigned)q < 4u);  // keeps the slot-validity tests 4 a + q < N compile-time for a < NA - 1
+        }
         // ---- 1. idle quads pull work until every quad has an item or the queue is empty
         //         (single exit, single back edge: the loop-carried state is large).
         // Items are handed out from a wave-private chunk [cur_next, cur_end) of kChunk consecutive
