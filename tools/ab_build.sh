@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ab_build.sh <name> [git-rev]   -- build libslamhip variant into slam_decomposition_amd/lib/ab/<name>.so
+# usage: [AB_FLAGS="-DX=1"] tools/ab_build.sh <name> [git-rev]   -- build libslamhip variant into slam_decomposition_amd/lib/ab/<name>.so
 set -e
 NAME=$1; REV=$2
 mkdir -p slam_decomposition_amd/lib/ab
@@ -9,5 +9,5 @@ if [ -n "$REV" ]; then
 else
   SRC=.
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o slam_decomposition_amd/lib/ab/$NAME.so $SRC/slam_decomposition_amd/csrc/slam_hip.hip $SRC/slam_decomposition_amd/csrc/slam_comm.hip -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $AB_FLAGS -o slam_decomposition_amd/lib/ab/$NAME.so $SRC/slam_decomposition_amd/csrc/slam_hip.hip $SRC/slam_decomposition_amd/csrc/slam_comm.hip -ldl
 echo built $NAME
