@@ -297,6 +297,13 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                 lds_fence();
                 cur_next += consumed;
                 {
+                    // Start points.  Each Philox block yields the parameter pair (2m, 2m + 1) of one item; computed per lane
+                    // for its own slots, a lane runs NA blocks (half of them twice within the quad) whether or not its quad
+                    // takes an item.  With the wide exchange area (kSharedSeeds) the blocks of ALL taking quads are dealt
+                    // over the 64 lanes instead -- n_take N / 2 blocks, one pass for up to 10 / 7 / 5 quads at k = 1 / 2 / 3 --
+                    // and handed to their owners through LDS: the same numbers, a third to a sixth of the instructions.
+                    constexpr bool kSharedSeeds = psq_layout<K, GC>();
+                    const bool shared = kSharedSeeds && cold_args<K>()->x0 == nullptr;  // wave-uniform
                     if (get) {
                         const unsigned oidx = sl * (unsigned)args.restarts + rs;
                         item = oidx;
@@ -305,20 +312,61 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                         // three independent loads (no load feeds another's address)
                         tgt = cold_args<K>()->orig ? cold_args<K>()->orig[sl] : cold_args<K>()->first_target + (int)sl;
                         tcol = cold_args<K>()->targets + (int64_t)sl * 32 + q * 2;
+                        if (!shared) {
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) {
+                                const int i = 4 * a + q;
+                                double xv = 0.0;
+                                if (i < C::N) {
+                                    if constexpr (kSharedSeeds)  // (not shared: explicit start points)
+                                        xv = cold_args<K>()->x0[(int64_t)oidx * C::N + i];
+                                    else
+                                        xv = cold_args<K>()->x0 ? cold_args<K>()->x0[(int64_t)oidx * C::N + i]
+                                                     : x0_philox(cold_args<K>()->seed, (uint32_t)(tgt + (int)cold_args<K>()->target_base), restart, (uint32_t)K, (uint32_t)i);
+                                }
+                                x[a] = xv;
+                            }
+                        }
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
-                            const int i = 4 * a + q;
-                            double xv = 0.0;
-                            if (i < C::N)
-                                xv = cold_args<K>()->x0 ? cold_args<K>()->x0[(int64_t)oidx * C::N + i]
-                                             : x0_philox(cold_args<K>()->seed, (uint32_t)(tgt + (int)cold_args<K>()->target_base), restart, (uint32_t)K, (uint32_t)i);
-                            x[a] = xv;
                             p[a] = 0.0;
                             g[a] = 0.0;
                         }
                         alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0; pp = 0.0; hs1 = 0.0;
                         nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
                         scaled = false; fresh = true; live = true; taken = true;
+                    }
+                    if constexpr (kSharedSeeds) {
+                        if (shared) {
+                            constexpr int kPairs = C::N / 2;
+                            // wp[32 + r]: Philox target word of the r-th taking quad, wp[48 + r]: its quad index
+                            if (get && q == 0) {
+                                wp[32 + qrank] = tgt + (int)cold_args<K>()->target_base;
+                                wp[48 + qrank] = quad;
+                            }
+                            lds_fence();
+                            const uint64_t seed = cold_args<K>()->seed;
+                            const int jobs = n_take * kPairs;
+                            for (int j0 = 0; j0 < jobs; j0 += kWave) {
+                                const int jb = j0 + lane;
+                                if (jb < jobs) {
+                                    const int r = jb / kPairs, m = jb - r * kPairs;
+                                    uint32_t w[4];
+                                    philox4x32_10((uint32_t)m, (uint32_t)wp[16 + r], (uint32_t)wp[32 + r], (uint32_t)K, (uint32_t)seed,
+                                                  (uint32_t)(seed >> 32), w);
+                                    // staged behind the trig table and the first partial sums of the quad's exchange area
+                                    // (doubles [4N, 5N): clear of the 64 ints of wp at the head of quad 0's)
+                                    *reinterpret_cast<double2*>(xchg + wp[48 + r] * C::XSTRIDE + 4 * C::N + 2 * m) =
+                                        make_double2(x0_from_words(w[0], w[1]), x0_from_words(w[2], w[3]));
+                                }
+                            }
+                            lds_fence();
+                            if (get) {
+#pragma unroll
+                                for (int a = 0; a < NA; ++a) x[a] = (4 * a + q < C::N) ? xq[4 * C::N + 4 * a + q] : 0.0;
+                            }
+                            lds_fence();
+                        }
                     }
                 }
             }
