@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         {
             // the refill code is wave-wide (everyone waits while it runs), so at short spans -- where
             // items last only ~40 rounds -- it pays to let kRefillBatch quads go idle before running it
-            constexpr int kRefillBatch = (K == 1) ? 3 : (K == 2 ? 2 : 1);
+            // (3 / 2 / 1 before the seeds were shared out over the wave; measured again since: k = 1 10.96 -> 10.72 ms, k = 2 7.95 -> 7.87)
+            constexpr int kRefillBatch = (K == 1) ? 2 : 1;
             const int n_idle = __popcll(__ballot(!live && q == 0));
             const bool go = n_idle >= kRefillBatch || n_idle == __popcll(__ballot(q == 0));
             while (go && !exhausted && __any(!live)) {
