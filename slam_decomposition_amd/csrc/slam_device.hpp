@@ -56,7 +56,14 @@ struct Cfg {
     // every such store (31 per round at k = 2: most of the measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 33 %).
     static constexpr int FNEED = 20 * NA - 16;
     static constexpr int FSTRIDE = (FNEED - 4 + 31) / 32 * 32 + 4;
-    static constexpr int XNEED_D = PSQ ? 6 * N : 2 * N;  // trig table [0, 2N); PSQ: partials [2N + 4 i, 2N + 4 i + 4) of parameter i
+    // trig table [0, 2N).  PSQ: four planes of gradient partials, plane q' (the partials computed by lane q') at
+    // PS0 + q' PSP, parameter i at [i] -- plane stride == 1 (mod 4) doubles, quad stride an odd multiple of 32 bytes: the 16
+    // lanes of a ds_write_b64 group and the 32 lanes of a ds_read_b64 group then hit distinct banks (measured: the
+    // parameter-major layout [i][q'] read with ds_read_b128 put SQ_LDS_BANK_CONFLICT at 32 % of SQ_LDS_IDX_ACTIVE).
+    // The planes start over the TOP layer's trig entries, which are dead once the forward pass has loaded them (K <= 3).
+    static constexpr int PSP = (N + 3) / 4 * 4 + 1;
+    static constexpr int PS0 = 12 * K;
+    static constexpr int XNEED_D = PSQ ? PS0 + 3 * PSP + N : 2 * N;
     static constexpr int XNEED_F = (kQuadsPerWave * FSTRIDE + 2 * kQuadsPerWave - 1) / (2 * kQuadsPerWave);  // doubles per quad so that the float overlay fits
     static constexpr int XNEED = XNEED_D > XNEED_F ? XNEED_D : XNEED_F;
     // quad stride of the double area, == 4 (mod 16) doubles = 8 (mod 32) dwords: the four quads of a ds_write_b64 group
@@ -841,10 +848,10 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (PSQ) {
-            // every lane stores its partial: parameter i = 6 j + m gets the four doubles at xq + 2N + 4 i, which its owner
-            // reads back with two ds_read_b128 and adds up (no DPP moves, no additions on the producing side)
+            // every lane stores its partial into its own plane; the owner of parameter i reads the four planes' entry i and
+            // adds them up (no DPP moves, no additions on the producing side)
 #pragma unroll
-            for (int m = 0; m < 6; ++m) xq[2 * C::N + 4 * (6 * j + m) + q] = part[m];
+            for (int m = 0; m < 6; ++m) xq[C::PS0 + q * C::PSP + 6 * j + m] = part[m];
         } else {
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
@@ -873,15 +880,17 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     lds_fence();
     {
         if constexpr (PSQ) {
-            const double2* ps2 = reinterpret_cast<const double2*>(xq + 2 * C::N) + 2 * q;
-            double2 p0[C::NA], p1[C::NA];
+            const double* ps = xq + C::PS0 + q;
+            double p0[C::NA], p1[C::NA], p2[C::NA], p3[C::NA];
 #pragma unroll
             for (int a = 0; a < C::NA; ++a) {
-                p0[a] = ps2[8 * a];
-                p1[a] = ps2[8 * a + 1];
+                p0[a] = ps[4 * a];
+                p1[a] = ps[4 * a + C::PSP];
+                p2[a] = ps[4 * a + 2 * C::PSP];
+                p3[a] = ps[4 * a + 3 * C::PSP];
             }
 #pragma unroll
-            for (int a = 0; a < C::NA; ++a) gd[a] = (4 * a + q < C::N) ? (p0[a].x + p0[a].y) + (p1[a].x + p1[a].y) : 0.0;
+            for (int a = 0; a < C::NA; ++a) gd[a] = (4 * a + q < C::N) ? (p0[a] + p1[a]) + (p2[a] + p3[a]) : 0.0;
         } else {
             const double2* ps2 = reinterpret_cast<const double2*>(xq) + q;
             double2 ps[C::NA];
