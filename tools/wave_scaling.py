@@ -26,5 +26,5 @@ for k in (1, 2, 3):
                 best = st
         ev, wr, ms = best["evals"][k], best["wave_rounds"][k], best["kernel_ms"]
         waves = N // (16 * ipq)
-        print(f"{gname} k={k} {label:26s}: {ms:7.2f} ms, {ev/ms/1e6:6.3f} G evals/s = {100*ev*f_eval(k)/ms/1e9/78.6e3*1e3/1e3:5.1f} % of peak, "
+        print(f"{gname} k={k} {label:26s}: {ms:7.2f} ms, {ev/ms/1e6:6.3f} G evals/s = {100*ev*f_eval(k)/(ms*1e-3)/78.6e12:5.1f} % of peak, "
               f"occupancy {ev/16/wr:.3f}, {ms*1e3/(wr/waves):.2f} us per wave-round")
