@@ -729,6 +729,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     constexpr bool kBwdTrigAhead = (K == 1);
     constexpr bool kEarlyP = (K <= 4);
     constexpr bool kKeepTopTrig = (K <= KEEPTOP);  // layer K's trig entries stay in registers from the forward pass
+    static_assert(!PSQ || kKeepTopTrig, "the partial-sum planes start over the top layer's trig entries: nobody may read those in the backward pass");
     double Hr[4], Hi[4];  // h = output of the current layer (registers for j = K)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Hr[r] = Fr[r]; Hi[r] = Fi[r]; }

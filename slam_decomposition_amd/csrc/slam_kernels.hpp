@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                     if constexpr (kSharedSeeds) {
                         if (shared) {
                             constexpr int kPairs = C::N / 2;
+                            static_assert(5 * C::N <= C::XSTRIDE && 4 * C::N * 8 >= 64 * 4, "staging area [4N, 5N) inside the quad's exchange area and clear of wp");
                             // wp[32 + r]: Philox target word of the r-th taking quad, wp[48 + r]: its quad index
                             if (get && q == 0) {
                                 wp[32 + qrank] = tgt + (int)cold_args<K>()->target_base;
