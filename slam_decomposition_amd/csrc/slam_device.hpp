@@ -62,7 +62,15 @@ struct Cfg {
     // parameter-major layout [i][q'] read with ds_read_b128 put SQ_LDS_BANK_CONFLICT at 32 % of SQ_LDS_IDX_ACTIVE).
     // The planes start over the TOP layer's trig entries, which are dead once the forward pass has loaded them (K <= 3).
     static constexpr int PSP = (N + 3) / 4 * 4 + 1;
-    static constexpr int PS0 = 12 * K;
+    // PSQ: the trig table of quad number 4g + w starts (0, 4, 2, 6)[w] doubles into the quad's area (TOFF = the largest).  A
+    // ds_write_b128 is serviced in groups of 8 lanes = 2 quads on a 128-byte bank window, each quad storing 64 contiguous
+    // bytes, a ds_read_b128 in groups of 16 lanes = the quads {0,3,5,6}, {1,2,4,7}, ... on a 256-byte window, each quad one
+    // broadcast 16-byte slot.  With a uniform quad stride == 32 (mod 128) bytes the two store footprints overlap by half
+    // (2-way conflict on every trig store: 9 % of all LDS cycles at k = 1); these offsets put the stores 64 bytes apart and
+    // keep the four broadcast slots of a read group distinct (exhaustive search over offsets per quad mod 4 with the bank
+    // model of MI355X_MICROARCH.md; an offset for the odd quads alone moved the conflicts to the reads: measured 16 -> 26 %)
+    static constexpr int TOFF = PSQ ? 6 : 0;
+    static constexpr int PS0 = 12 * K + TOFF;
     static constexpr int XNEED_D = PSQ ? PS0 + 3 * PSP + N : 2 * N;
     static constexpr int XNEED_F = (kQuadsPerWave * FSTRIDE + 2 * kQuadsPerWave - 1) / (2 * kQuadsPerWave);  // doubles per quad so that the float overlay fits
     static constexpr int XNEED = XNEED_D > XNEED_F ? XNEED_D : XNEED_F;
@@ -70,7 +78,8 @@ struct Cfg {
     // (pair sums, two adjacent doubles per quad) and of a ds_read_b128 group (trig entries, one broadcast double2 per quad)
     // land on different banks; the per-lane double2 gather of the gradient keeps a partial 2-way overlap between two quads
     // (== 4 (mod 8) is enough for that: 4 and 12 (mod 16) both put four consecutive quads on four different 32-byte segments)
-    static constexpr int XSTRIDE = (XNEED - 4 + 7) / 8 * 8 + 4;
+    // PSQ: == 4 (mod 16), i.e. 32 (mod 128) bytes, which the trig-store offset above assumes
+    static constexpr int XSTRIDE = PSQ ? (XNEED - 4 + 15) / 16 * 16 + 4 : (XNEED - 4 + 7) / 8 * 8 + 4;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
     static_assert(kQuadsPerWave * FSTRIDE * 4 <= LDS_XCHG * 8, "float overlay must fit the exchange area");
     static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;  // 2K column vectors x 4 rows x (64 lanes + pad) x (re,im)
@@ -572,6 +581,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     constexpr bool PSQ = psq_layout<K, GC>();
     using C = Cfg<K, PSQ>;
     asm volatile("" : "+v"(theta_bits));  // one register, not NA hoisted lane masks
+    // this quad's trig table (Cfg::TOFF): offsets (0, 4, 2, 6) doubles for quad mod 4 = 0..3
+    double* const xt = xq + (PSQ ? (int)((threadIdx.x & 4) + ((threadIdx.x >> 2) & 2)) : 0);
     auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
     // the target column is requested first and consumed after the forward pass
     double tre[4], tim[4];
@@ -583,7 +594,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     }
     // ---- 1. trig table: each lane handles its own parameter slots
     {
-        double2* t2 = reinterpret_cast<double2*>(xq);
+        double2* t2 = reinterpret_cast<double2*>(xt);
         if constexpr (HUGE_ARGS) {
 #pragma unroll
             for (int a = 0; a < C::NA; ++a) {
@@ -638,7 +649,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         Fi[r] = 0.0;
     }
     // the next layer's trig entries are requested half a layer ahead (before the qubit-1 gate is applied)
-    U3t Bn = load_u3(xq, 0), An = load_u3(xq, 3);
+    U3t Bn = load_u3(xt, 0), An = load_u3(xt, 3);
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
         if (j > 0 && !LEAN) {
@@ -664,8 +675,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
         }
         if (j < K) {
-            Bn = load_u3(xq, 6 * (j + 1));
-            An = load_u3(xq, 6 * (j + 1) + 3);
+            Bn = load_u3(xt, 6 * (j + 1));
+            An = load_u3(xt, 6 * (j + 1) + 3);
             __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads to their first use)
         }
         if (j == 0) {
@@ -747,8 +758,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         // (K = 1 only: at longer spans the 24 registers are not there)
         if constexpr (!kKeepTopTrig) {
             if (j == K) {
-                An = load_u3(xq, 6 * j + 3);
-                Bn = load_u3(xq, 6 * j);
+                An = load_u3(xt, 6 * j + 3);
+                Bn = load_u3(xt, 6 * j);
             }
         }
         const U3t B = Bn;
@@ -844,8 +855,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         // from a per-lane base -- no lane-dependent address arithmetic, no bank conflicts (the old gather read four
         // b64 words per parameter from the stored-vector slots: ~20 integer instructions each and a 2-way conflict)
         if (kBwdTrigAhead && j > 0) {
-            Bn = load_u3(xq, 6 * (j - 1));
-            An = load_u3(xq, 6 * (j - 1) + 3);
+            Bn = load_u3(xt, 6 * (j - 1));
+            An = load_u3(xt, 6 * (j - 1) + 3);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (PSQ) {
@@ -863,8 +874,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         if (!kBwdTrigAhead && j > 0) {
             // K >= 2: requested here, behind the pair-sum stores (no registers to spare earlier): the gate's row action and
             // the next layer's phi partials run under the LDS latency.  The qubit-1 gate is applied first: its entries first
-            An = load_u3(xq, 6 * (j - 1) + 3);
-            Bn = load_u3(xq, 6 * (j - 1));
+            An = load_u3(xt, 6 * (j - 1) + 3);
+            Bn = load_u3(xt, 6 * (j - 1));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (j > 0) {
