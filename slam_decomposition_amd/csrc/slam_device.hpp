@@ -569,9 +569,6 @@ __device__ __forceinline__ int theta_slot_bits(int q) {
 // HUGE_ARGS: also handle |x| >= 2e9 (out-of-line ocml path).  The optimizer kernel keeps |x| far
 // below that (x0 in [0, 2 pi) or validated by the host, steps <= 2 rad) and instantiates false, so no
 // function call -- and none of the register save/restore traffic a call site drags in -- sits in its loop.
-#ifndef KEEPTOP
-#define KEEPTOP 3
-#endif
 template <int K, bool HUGE_ARGS, int GC>
 __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const double* tcol,
                                           const double* gates, double* xq, double2* fh, const double2* tbl,
@@ -739,7 +736,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     }
     constexpr bool kBwdTrigAhead = (K == 1);
     constexpr bool kEarlyP = (K <= 4);
-    constexpr bool kKeepTopTrig = (K <= KEEPTOP);  // layer K's trig entries stay in registers from the forward pass
+    constexpr bool kKeepTopTrig = (K <= 3);  // layer K's trig entries stay in registers from the forward pass
     static_assert(!PSQ || kKeepTopTrig, "the partial-sum planes start over the top layer's trig entries: nobody may read those in the backward pass");
     double Hr[4], Hi[4];  // h = output of the current layer (registers for j = K)
 #pragma unroll
