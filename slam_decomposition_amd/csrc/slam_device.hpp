@@ -8,9 +8,11 @@
 //     forward chain needs no cross-lane traffic; rows of (z T^+)(suffix) evolve
 //     independently under right multiplication, so the backward chain needs none either;
 //   * the only exchanges are quad reductions (DPP quad_perm shuffles) and small
-//     transposes through a wave-private LDS exchange area;
-//   * the 2Q gate matrices are kernel arguments: wave-uniform, so they sit in SGPRs and feed
+//     transposes through a wave-private LDS exchange area (trig table, gradient partials, fp32 broadcasts);
+//   * the 2Q gate matrices are wave-uniform device data: read with scalar loads, they sit in SGPRs and feed
 //     the fp64 FMAs as scalar operands (no VGPR, no LDS read);
+//   * memory latencies are kept off the critical path by hand: every LDS / scalar read is requested half a layer
+//     to a layer before its first use (sched_barriers keep the compiler from sinking it back);
 //   * the n x n inverse-Hessian approximation (the quasi-Newton metric, a preconditioner) is kept
 //     in fp32 VGPRs as packed symmetric 4x4 blocks -- lane q holds row q of every upper-triangle
 //     block -- and is applied / updated with packed fp32 FMAs.  Loss, gradient, parameters,
@@ -46,9 +48,9 @@ struct Cfg {
     static constexpr int NA = (N + 3) / 4;             // parameter slots per lane
     static constexpr int NP = NA * 4;                  // padded parameter count
     static constexpr int NBLK = NA * (NA + 1) / 2;     // upper-triangle 4x4 blocks of H
-    // doubles per quad in the exchange area.  Users: trig table [0, 2N) (the top layer's entries later
-    // hold that layer's pair-summed gradient partials); fp32 mat-vec broadcast (4 NA floats) + transposed
-    // partial sums (16 (NA - 1) floats); fp32 rank-2 update broadcasts (8 NA floats).
+    // doubles per quad in the exchange area.  Users: trig table (2N doubles); the gradient partials (PSQ: four planes,
+    // below; else pair sums parked in the layers' dead trig entries); fp32 mat-vec broadcast (4 NA floats) + transposed
+    // partial sums (16 (NA - 1) floats); fp32 rank-2 update broadcasts (8 NA floats); the start points dealt out at a refill.
     // The fp32 exchanges of the quasi-Newton algebra (h_matvec / h_update: 20 NA - 16 floats per quad, live only BETWEEN
     // evaluations) overlay the whole wave's exchange area with their OWN quad stride, FSTRIDE floats == 4 (mod 32): their
     // traffic is mostly ds_write_b32 of 4 consecutive dwords per quad, serviced in groups of 32 lanes = 8 quads on 32
