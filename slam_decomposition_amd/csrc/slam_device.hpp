@@ -153,9 +153,16 @@ __device__ __forceinline__ double quad_sum(double v) {
     v += dpp_f64<0x4E>(v);
     return v;
 }
-__device__ __forceinline__ double quad_max(double v) {
-    v = fmax(v, dpp_f64<0xB1>(v));
-    v = fmax(v, dpp_f64<0x4E>(v));
+// max(|a|, |b|) in ONE instruction: fmax() canonicalises its operands first (IEEE sNaN semantics), an extra v_max_f64
+// x, x, x each; the callers' values are finite by construction
+__device__ __forceinline__ double max_abs(double a, double b) {
+    double m;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ double quad_max(double v) {  // v >= 0
+    v = max_abs(v, dpp_f64<0xB1>(v));
+    v = max_abs(v, dpp_f64<0x4E>(v));
     return v;
 }
 

@@ -520,9 +520,9 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         }
         // quad reductions are executed by all lanes
         {
-            double m = 0.0;
+            double m = max_abs(g[0], g[NA > 1 ? 1 : 0]);
 #pragma unroll
-            for (int a = 0; a < NA; ++a) m = fmax(m, fabs(g[a]));
+            for (int a = 2; a < NA; ++a) m = max_abs(m, g[a]);
             gnorm = quad_max(m);
         }
         gp = qdot<NA>(g, p);

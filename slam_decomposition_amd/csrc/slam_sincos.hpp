@@ -102,8 +102,15 @@ __device__ __forceinline__ SincosLits sincos_lits_device() {
 template <bool FULL = false, class Tbl>
 SLAM_HD void sincos_tbl_lookup(double x, const Tbl* tbl /* double2-like {x = cos, y = sin} [32 or 64] */, const SincosLits& L, double& r,
                                int& k, Tbl& t) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    // round to nearest by adding 1.5 * 2^52: the integer lands in the low dword, no v_rndne / v_cvt (|x * 32/pi| < 2^31)
+    const double nm = fma(x, L.inv, 6755399441055744.0);
+    k = __double2loint(nm);
+    const double n = nm - 6755399441055744.0;
+#else
     const double n = rint(x * L.inv);
     k = (int)n;
+#endif
     t = tbl[k & (FULL ? 63 : 31)];
     r = fma(-n, L.hi, x);
     r = fma(-n, L.lo, r);
