@@ -70,7 +70,7 @@ typedef struct slam_opt_params {
     double gtol;          /* stop when |g|_inf < gtol (SciPy BFGS default 1e-5; we default 1e-9) */
     double stop_loss;     /* stop when loss < stop_loss */
     uint64_t seed;        /* Philox key for x0 ~ U[0,2pi)^n (basis.py:106-111) */
-    uint32_t flags;       /* SLAM_FLAG_* */
+    uint32_t flags;       /* SLAM_FLAG_* (bits above SLAM_FLAG_ORDERED are ignored) */
     uint32_t items_per_quad; /* launch shaping: at least this many work items per resident quad before more
                                 wavefronts are launched.  0/1 = spread a small batch over as many wavefronts as
                                 possible (lowest latency of one batch); 4..8 = keep quads refilled (highest

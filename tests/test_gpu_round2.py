@@ -374,3 +374,21 @@ def test_fast_and_logged_paths_of_the_python_api_agree(caplog):
         assert data is None and err.startswith("Failed to converge") and len(f_opt.training_loss) == 1 and f_opt.best_cycle_list == [2]
     o_opt, data, err = run(logging.WARNING, HaarBatch(seed0=70, n_samples=4), CXGate(), 2, override_fail=True)
     assert err is None and [d.success_label for d in data] == [0] * 4 and len(o_opt.training_loss) == 4
+
+
+def test_unknown_flag_bits_are_ignored_and_shared_seeds_equal_explicit_ones(hip_ctx):
+    """slam_opt_params.flags: bits above SLAM_FLAG_ORDERED are internal (masked at the boundary).  And the start points a
+    refill deals over the wave (Philox blocks spread over the 64 lanes, handed out through LDS) are the ones the oracle
+    generates item by item: a run from explicit x0 = the oracle's Philox seeds ends bit for bit where the in-kernel run does."""
+    N, R, k = 40, 8, 2
+    hip_ctx.set_targets(o.haar_batch(N, seed0=6200))
+    hip_ctx.set_gates(SQ[None])
+    base = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, seed=11, flags=ORDERED))
+    junk = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, seed=11, flags=ORDERED | 0x100 | 0x8000))
+    for key in ("best_loss", "best_x", "best_restart"):  # (restarts above the winner are pre-empted at a timing-dependent point)
+        assert np.array_equal(base[key], junk[key]), key
+    plain = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, seed=11, flags=0))
+    x0 = np.stack([np.stack([o.x0_philox(11, t, r, k) for r in range(R)]) for t in range(N)])
+    explicit = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, seed=999, flags=0), x0=x0)
+    assert np.array_equal(plain["item_loss"], explicit["item_loss"])
+    assert np.array_equal(plain["item_iters"], explicit["item_iters"])
