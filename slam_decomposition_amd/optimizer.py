@@ -200,7 +200,15 @@ class TemplateOptimizer:
             best_cycles = np.concatenate([p[0][2] for p in parts])
             self._span_losses = np.concatenate([p[0][3] for p in parts])
             self.last_stats = [p[1] for p in parts]
-        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
+        # per target the first 6 (cycles + 1) parameters: one contiguous block per template size, rows handed out as views
+        # (65 536 per-row slices + copies cost more than the span loop on the GPU)
+        xs = [None] * n
+        cyc = np.asarray(best_cycles)
+        for c in np.unique(cyc):
+            idx = np.nonzero(cyc == c)[0]
+            block = np.ascontiguousarray(best_x[idx, : 6 * (int(c) + 1)])
+            for i, row in zip(idx.tolist(), block):
+                xs[i] = row
         return best_loss, xs, best_cycles
 
     def _run_batch_any_order(self, targets: np.ndarray, ks):
@@ -503,7 +511,7 @@ class TemplateOptimizer:
             self.best_cycle_list.extend(int(c) for c in best_cycles[:stop])
             if fail:
                 raise ValueError(_FAIL_MSG)
-            return [DataDictEntry(int(ok[i]), float(best_loss[i]), best_xs[i], int(best_cycles[i])) for i in range(n)]
+            return [DataDictEntry(a, b, c, d) for a, b, c, d in zip(ok.astype(int).tolist(), best_loss.tolist(), best_xs, best_cycles.tolist())]
         found = self._found_coordinates(best_xs, best_cycles) if log_on else np.zeros((n, 3))
         coords = coords_arr if coords_arr is not None else np.zeros((n, 3))
         out = []
