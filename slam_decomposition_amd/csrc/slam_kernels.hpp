@@ -617,26 +617,52 @@ __device__ __forceinline__ void reduce_merge_slot(const ReduceArgs& a, int64_t s
         double best = INFINITY;
         int br = 0;
         bool hit = false;  // ordered mode: a restart below exit_loss has been seen (the lowest index wins)
+        // (unrolled: four restarts' loads in flight -- the trip count is a run-time value, and one thread walks several
+        // targets one after the other: the single-workgroup epilogue of a small batch is a chain of memory latencies)
+#pragma unroll 4
         for (int r = 0; r < a.restarts; ++r) {
             const double l = a.item_loss[s * a.restarts + r];
             const unsigned long long e = (unsigned long long)a.item_evals[s * a.restarts + r];
+            const bool pre = a.item_status[s * a.restarts + r] == ST_PREEMPTED;
+            const unsigned long long ac = (unsigned long long)a.item_acc[s * a.restarts + r];
             ev.all += e;
-            if (a.item_status[s * a.restarts + r] == ST_PREEMPTED) ev.preempted += e;
-            else ev.accepted += (unsigned long long)a.item_acc[s * a.restarts + r];
-            if (hit) continue;
-            if (a.ordered && l < a.exit_loss) { best = l; br = r; hit = true; continue; }
-            if (l < best) { best = l; br = r; }   // NaN / +inf (pre-empted) never win
+            ev.preempted += pre ? e : 0ull;
+            ev.accepted += pre ? 0ull : ac;
+            // branch-free (the loads of the next restarts must not wait for this one's verdict):
+            //   not hit yet: an ordered-mode restart below exit_loss takes the stage and closes it; else the lower loss takes
+            const bool below = a.ordered && l < a.exit_loss;
+            const bool take = !hit && (below || l < best);   // NaN / +inf (pre-empted) never win
+            best = take ? l : best;
+            br = take ? r : br;
+            hit = hit || below;
         }
         a.stage_loss[s] = best;
         a.stage_restart[s] = br;
         const double* src = a.item_x + (s * a.restarts + br) * a.n;
-        for (int i = 0; i < a.n; ++i) a.stage_x[s * a.n + i] = src[i];
+        // the winner's parameters are loaded six at a time (n = 6 (k + 1), plus the gate parameters of a V2 template: tail loop)
+        int i6 = 0;
+        for (; i6 + 6 <= a.n; i6 += 6) {
+            double v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v[j] = src[i6 + j];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a.stage_x[s * a.n + i6 + j] = v[j];
+        }
+        for (int i = i6; i < a.n; ++i) a.stage_x[s * a.n + i] = src[i];
         if (a.best_loss) {
             const int64_t t = a.active ? a.active[s] : s;
             if (a.best_cycles[t] < 0 || best < a.best_loss[t]) {
                 a.best_loss[t] = best;
                 a.best_cycles[t] = a.k;
-                for (int i = 0; i < a.n; ++i) a.best_x[t * a.nmax + i] = src[i];
+                int j6 = 0;
+                for (; j6 + 6 <= a.n; j6 += 6) {
+                    double v[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) v[j] = src[j6 + j];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) a.best_x[t * a.nmax + j6 + j] = v[j];
+                }
+                for (int i = j6; i < a.n; ++i) a.best_x[t * a.nmax + i] = src[i];
                 for (int i = a.n; i < a.nmax; ++i) a.best_x[t * a.nmax + i] = 0.0;  // defined rows: nothing beyond 6 (best_cycles + 1)
             }
             if (a.span_loss) a.span_loss[t * kSpanLossStride + (a.k - 1)] = a.best_loss[t];
