@@ -377,7 +377,9 @@ __device__ __forceinline__ void sincos_any(double x, const double2* tbl, double&
 //             ConversionGainGate with zero phases                                 8 real-scalar products
 //   GC_CX     qiskit CXGate: a permutation of amplitudes 1 <-> 3                 0
 // ---------------------------------------------------------------------------------
-enum : int { GC_DENSE = 0, GC_XGEN = 1, GC_XRI = 2, GC_CX = 3 };
+//   GC_XRI1   GC_XRI whose block on (0,3) is the identity: RiSwapGate(alpha) = sqrt-iSWAP, iSWAP  4 real-scalar products
+enum : int { GC_DENSE = 0, GC_XGEN = 1, GC_XRI = 2, GC_CX = 3, GC_XRI1 = 4 };
+constexpr int kGateClasses = 5;
 
 #define SLAM_GRE(r, s) G[((r) * 4 + (s)) * 2]
 #define SLAM_GIM(r, s) G[((r) * 4 + (s)) * 2 + 1]
@@ -427,6 +429,8 @@ __device__ __forceinline__ void gate_col(gate_ptr G, double (&Fr)[4], double (&F
         const double tr = Fr[1], ti = Fi[1];
         Fr[1] = Fr[3]; Fi[1] = Fi[3];
         Fr[3] = tr; Fi[3] = ti;
+    } else if constexpr (GC == GC_XRI1) {
+        block_col_ri<1, 2>(G, Fr, Fi);
     } else if constexpr (GC == GC_XRI) {
         block_col_ri<0, 3>(G, Fr, Fi);
         block_col_ri<1, 2>(G, Fr, Fi);
@@ -458,6 +462,8 @@ __device__ __forceinline__ void gate_row(gate_ptr G, double (&Ur)[4], double (&U
         const double tr = Ur[1], ti = Ui[1];
         Ur[1] = Ur[3]; Ui[1] = Ui[3];
         Ur[3] = tr; Ui[3] = ti;
+    } else if constexpr (GC == GC_XRI1) {
+        block_row_ri<1, 2>(G, Ur, Ui);
     } else if constexpr (GC == GC_XRI) {
         block_row_ri<0, 3>(G, Ur, Ui);
         block_row_ri<1, 2>(G, Ur, Ui);
@@ -496,10 +502,18 @@ struct GateRegs<GC_XRI> {
     double a_d0, a_o01, a_o10, a_d1;  // block on index pair (0, 3)
     double b_d0, b_o01, b_o10, b_d1;  // block on index pair (1, 2)
 };
+template <>
+struct GateRegs<GC_XRI1> {
+    double b_d0, b_o01, b_o10, b_d1;  // block on index pair (1, 2); the (0, 3) block is the identity
+};
 template <int GC>
 __device__ __forceinline__ GateRegs<GC> load_gate(const double* gates, int j) {
     gate_ptr G = gate_matrix(gates, j);
-    if constexpr (GC == GC_XRI) {
+    if constexpr (GC == GC_XRI1) {
+        GateRegs<GC> r;
+        r.b_d0 = SLAM_GRE(1, 1); r.b_o01 = SLAM_GIM(1, 2); r.b_o10 = SLAM_GIM(2, 1); r.b_d1 = SLAM_GRE(2, 2);
+        return r;
+    } else if constexpr (GC == GC_XRI) {
         GateRegs<GC> r;
         r.a_d0 = SLAM_GRE(0, 0); r.a_o01 = SLAM_GIM(0, 3); r.a_o10 = SLAM_GIM(3, 0); r.a_d1 = SLAM_GRE(3, 3);
         r.b_d0 = SLAM_GRE(1, 1); r.b_o01 = SLAM_GIM(1, 2); r.b_o10 = SLAM_GIM(2, 1); r.b_d1 = SLAM_GRE(2, 2);
@@ -510,7 +524,13 @@ __device__ __forceinline__ GateRegs<GC> load_gate(const double* gates, int j) {
 }
 template <int GC>
 __device__ __forceinline__ void gate_col(const GateRegs<GC>& g, double (&Fr)[4], double (&Fi)[4]) {
-    if constexpr (GC == GC_XRI) {
+    if constexpr (GC == GC_XRI1) {
+        const double ar = Fr[1], ai = Fi[1], br = Fr[2], bi = Fi[2];
+        Fr[1] = fma(g.b_d0, ar, -g.b_o01 * bi);
+        Fi[1] = fma(g.b_d0, ai, g.b_o01 * br);
+        Fr[2] = fma(g.b_d1, br, -g.b_o10 * ai);
+        Fi[2] = fma(g.b_d1, bi, g.b_o10 * ar);
+    } else if constexpr (GC == GC_XRI) {
         {
             const double ar = Fr[0], ai = Fi[0], br = Fr[3], bi = Fi[3];
             Fr[0] = fma(g.a_d0, ar, -g.a_o01 * bi);
@@ -531,7 +551,13 @@ __device__ __forceinline__ void gate_col(const GateRegs<GC>& g, double (&Fr)[4],
 }
 template <int GC>
 __device__ __forceinline__ void gate_row(const GateRegs<GC>& g, double (&Ur)[4], double (&Ui)[4]) {
-    if constexpr (GC == GC_XRI) {
+    if constexpr (GC == GC_XRI1) {
+        const double ar = Ur[1], ai = Ui[1], br = Ur[2], bi = Ui[2];
+        Ur[1] = fma(g.b_d0, ar, -g.b_o10 * bi);
+        Ui[1] = fma(g.b_d0, ai, g.b_o10 * br);
+        Ur[2] = fma(g.b_d1, br, -g.b_o01 * ai);
+        Ui[2] = fma(g.b_d1, bi, g.b_o01 * ar);
+    } else if constexpr (GC == GC_XRI) {
         {
             const double ar = Ur[0], ai = Ui[0], br = Ur[3], bi = Ui[3];
             Ur[0] = fma(g.a_d0, ar, -g.a_o10 * bi);
@@ -668,9 +694,9 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         if (j < K) {
             // requested as soon as the trig entries have arrived (an LDS wait with scalar loads in flight would have to
             // wait for those as well), consumed after the layer's 64 operations
-            if constexpr (GC == GC_XRI) u3_arrived(B, A);
+            if constexpr (GC == GC_XRI || GC == GC_XRI1) u3_arrived(B, A);
             Gf = load_gate<GC>(gates, j);
-            if constexpr (GC == GC_XRI) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GC == GC_XRI || GC == GC_XRI1) __builtin_amdgcn_sched_barrier(0);
         }
         double b0r, b0i, b1r, b1i;
         if (j == 0) {
@@ -779,9 +805,9 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         }
         GateRegs<GC> Gb;
         if (j > 0) {  // one request for both uses below, issued once this layer's trig entries have arrived
-            if constexpr (GC == GC_XRI) u3_arrived(B, A);
+            if constexpr (GC == GC_XRI || GC == GC_XRI1) u3_arrived(B, A);
             Gb = load_gate<GC>(gates, j - 1);
-            if constexpr (GC == GC_XRI) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GC == GC_XRI || GC == GC_XRI1) __builtin_amdgcn_sched_barrier(0);
         }
         // phi: dU/dphi = i diag(0,1) U  ->  -Im( sum over rows with that qubit's bit set of u*h )
         const double m1 = im_mul(Ur[1], Ui[1], Hr[1], Hi[1]);

@@ -118,11 +118,11 @@ struct slam_ctx {
     std::vector<double> gates_host;
     int compute_units = 0;
     int reserve_waves = 0;  // wavefront slots the persistent optimizer grid leaves free for the span loop's bookkeeping kernels
-    int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1][4] = {};
+    int64_t resident_waves[SLAM_MAX_SPAN_EVAL + 1][kGateClasses] = {};
     // eval buffers
     DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary, ev_weyl;
     slam_stats stats{};
-    bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][4][2] = {};
+    bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][kGateClasses][2] = {};
 
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
@@ -184,7 +184,7 @@ int stage_gates(slam_ctx* c, int k, const int32_t* gate_seq, const double** d_ou
 // general class any of its gates needs; entries below 1e-15 count as structural zeros.
 int classify_gates(slam_ctx* c, int k, const int32_t* gate_seq) {
     const double tol = 1e-15;
-    bool all_cx = true, all_x = true, all_xri = true;
+    bool all_cx = true, all_x = true, all_xri = true, all_xri1 = true;
     for (int j = 0; j < k; ++j) {
         const double* g = c->gates_host.data() + (size_t)gate_seq[j] * 32;
         auto re = [&](int r, int s) { return g[(r * 4 + s) * 2]; };
@@ -210,8 +210,12 @@ int classify_gates(slam_ctx* c, int k, const int32_t* gate_seq) {
                          std::fabs(im(2, 2)) <= tol && std::fabs(re(0, 3)) <= tol && std::fabs(re(3, 0)) <= tol &&
                          std::fabs(re(1, 2)) <= tol && std::fabs(re(2, 1)) <= tol;
         all_xri = all_xri && xri;
+        // ... and the identity on the (0,3) block: RiSwapGate(alpha) (sqrt-iSWAP, iSWAP) leaves |00> and |11> alone
+        all_xri1 = all_xri1 && xri && std::fabs(re(0, 0) - 1.0) <= tol && std::fabs(re(3, 3) - 1.0) <= tol && mag(0, 3) <= tol &&
+                   mag(3, 0) <= tol;
     }
     if (all_cx) return GC_CX;
+    if (all_xri1) return GC_XRI1;
     if (all_xri) return GC_XRI;
     if (all_x) return GC_XGEN;
     return GC_DENSE;
@@ -394,6 +398,7 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
 #define SLAM_MIN_CASE(KK)                                                   \
     case KK:                                                                \
         if (gc == GC_CX) rc = launch_minimize<KK, GC_CX>(c, sl);            \
+        else if (gc == GC_XRI1) rc = launch_minimize<KK, GC_XRI1>(c, sl);   \
         else if (gc == GC_XRI) rc = launch_minimize<KK, GC_XRI>(c, sl);     \
         else if (gc == GC_XGEN) rc = launch_minimize<KK, GC_XGEN>(c, sl);   \
         else rc = launch_minimize<KK, GC_DENSE>(c, sl);                     \
@@ -787,6 +792,7 @@ static int eval_body(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
 #define SLAM_EVAL_CASE(KK)                                                                                  \
     case KK:                                                                                                \
         if (gc == GC_CX) rc = launch_eval<KK, GC_CX>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);   \
+        else if (gc == GC_XRI1) rc = launch_eval<KK, GC_XRI1>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); \
         else if (gc == GC_XRI) rc = launch_eval<KK, GC_XRI>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); \
         else if (gc == GC_XGEN) rc = launch_eval<KK, GC_XGEN>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); \
         else rc = launch_eval<KK, GC_DENSE>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);          \
@@ -798,6 +804,7 @@ static int eval_body(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
         SLAM_EVAL_CASE(4)
         default:
             if (gc == GC_CX) rc = launch_eval<5, GC_CX>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
+            else if (gc == GC_XRI1) rc = launch_eval<5, GC_XRI1>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
             else if (gc == GC_XRI) rc = launch_eval<5, GC_XRI>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
             else if (gc == GC_XGEN) rc = launch_eval<5, GC_XGEN>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
             else rc = launch_eval<5, GC_DENSE>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
