@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev tool (CPU): compile ONE instantiation of the optimizer kernel and print its resource usage and instruction mix.
-# usage: tools/kcompile.sh <K> <GC> [extra hipcc flags]     (GC: 0 dense, 1 xgen, 2 xri, 3 cx)
+# usage: tools/kcompile.sh <K> <GC> [extra hipcc flags]     (GC: 0 dense, 1 xgen, 2 xri, 3 cx, 4 xri1 = RiSwap family)
 K=${1:-3}; GC=${2:-2}; shift 2
 mkdir -p build/kc
 cat > build/kc/one.hip <<SRC
