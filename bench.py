@@ -122,9 +122,10 @@ def _cpu_one(args):
 def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool):
     import multiprocessing as mp
 
-    cores = min(os.cpu_count() or 1, 32)
+    # every core the box gives this process (affinity mask when the platform has one): `value` is a whole-box number
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if n_sample <= 0:
-        n_sample = 4 * cores  # every core busy for several targets: `value` is a whole-box number
+        n_sample = 4 * cores  # every core busy for several targets
     with mp.get_context("spawn").Pool(cores) as pool:
         pool.map(abs, range(cores))  # workers up (interpreter + NumPy/SciPy import) before the clock starts
         t0 = time.perf_counter()
@@ -142,6 +143,7 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
         "value": ok / wall,
         "unit": "decompositions/s",
         "cores": cores,
+        "host_cpu_count": os.cpu_count(),
         "kind": "port",
         "sample": f"{n_sample} targets of the same workload{' (sweep basis %d only)' % SWEEP_CPU_BASIS if gname == 'cgsweep' else ''} "
         f"(SciPy BFGS + finite differences on the NumPy oracle, "
@@ -156,13 +158,37 @@ def traffic_per_launch(workload: str):
     """HBM bytes per optimizer-kernel launch (mean over the three spans) from the committed PMC passes
     (profiles/r2_traffic.json, else r1d_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
     None for workloads that were not profiled."""
-    for name in ("r2_traffic.json", "r1d_traffic.json"):
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1d_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload]
             return sum(t.values()) / len(t)
         except (OSError, KeyError, ValueError):
             continue
     return None
+
+
+def pmc_figures(workload: str):
+    """VALU-busy and achieved HBM GB/s of the optimizer launches, per span, from the committed rocprofv3 --pmc passes
+    (profiles/r3_pmc.json, else r2_pmc.json; tools/profile_r3.sh writes them).  Counters cannot be collected inside an
+    unprofiled run: these are the figures of the committed profile of the same command, named in `source`."""
+    for name in ("r3_pmc.json", "r2_pmc.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            per = d[workload]
+            return {"source": f"profiles/{name}", "valu_busy": {k: v["valu_busy"] for k, v in per.items()},
+                    "hbm_gbps": {k: v["hbm_gbps"] for k, v in per.items()}}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def gather_strings(comm, rank: int, world: int, text: str, width: int = 64):
+    """Every rank's short string on every rank, through the communicator's sum-all-reduce (bytes as doubles)."""
+    buf = np.zeros(world * width)
+    raw = text.encode()[:width]
+    buf[rank * width : rank * width + len(raw)] = list(raw)
+    comm.allreduce_sum(buf)
+    return [bytes(int(v) for v in buf[r * width : (r + 1) * width] if v > 0).decode(errors="replace") for r in range(world)]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -224,17 +250,23 @@ def make_comm(rank: int, world: int, local_rank: int):
     if os.environ.get("SLAM_BENCH_COMM", "rccl") == "file":
         # rehearsal of the N > 1 path on a one-GPU box (RCCL refuses several ranks on one device)
         return parallel.FileComm(rank, world, os.environ.get("SLAM_COMM_DIR") or parallel.rendezvous_path() + ".d")
-    try:
-        from slam_decomposition_amd import _ffi
+    from slam_decomposition_amd import _ffi
 
+    # No fallback: a rank whose RCCL communicator does not come up ends the job with a non-zero exit code (the launcher
+    # then stops the other ranks).  A per-rank fallback would leave the healthy ranks blocked in ncclCommInitRank, and a
+    # job-wide one would print a scaling number whose collective went through the file system.
+    try:
         with _StdoutToStderr():
             comm = parallel.RcclComm(local_rank % max(1, _ffi.device_count()), rank, world, parallel.rendezvous_path())
             comm.barrier()  # first collective (lazy channel set-up and its messages) before anything is timed or printed
-        return comm
-    except Exception as exc:  # RCCL missing or unusable on this node: keep the job alive, loudly (every rank fails alike)
-        print(f"[bench rank {rank}] RCCL communicator failed ({exc}); falling back to the file communicator -- the final "
-              f"all-reduce then goes through files and is far slower", file=sys.stderr, flush=True)
-        return parallel.FileComm(rank, world, os.environ.get("SLAM_COMM_DIR") or parallel.rendezvous_path() + ".d")
+    except Exception as exc:
+        print(f"[bench rank {rank}] RCCL communicator failed: {exc}  (SLAM_BENCH_COMM=file rehearses the N > 1 path without RCCL)",
+              file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    if (comm.rccl_rank, comm.rccl_world) != (rank, world):
+        print(f"[bench rank {rank}] RCCL reports rank {comm.rccl_rank} of {comm.rccl_world}, the launcher said {rank} of {world}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    return comm
 
 
 # ------------------------------------------------------------------------------------------------
@@ -247,6 +279,13 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         n_per_step = args.targets
     if main and args.restarts:
         restarts = args.restarts
+    strong = main and args.scaling == "strong" and world > 1
+    if strong:
+        # strong scaling: the batch of ONE GPU's step is split over the ranks (65 536 x 32 over N for the default workload)
+        if n_per_step % world:
+            raise SystemExit(f"--scaling strong: {n_per_step} targets per step do not divide over {world} ranks")
+        n_per_step //= world
+        desc += f" -- STRONG scaling: one such batch per step split over {world} GPUs ({n_per_step} targets per GPU)"
     small = n_per_step * restarts <= 65536
     total_steps = steps + warmup
     seed0 = TARGET_SEED0 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
@@ -367,17 +406,35 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
             t.start()
         for t in prime:
             t.join()
+    def sum_stats():
+        sts = [c.stats() for c in ctxs]
+        out = {"kernel_ms": sum(x["kernel_ms"] for x in sts), "kernel_launches": sum(x["kernel_launches"] for x in sts)}
+        for key in ("evals", "items", "evals_accepted", "evals_preempted", "kernel_ms_span", "wave_rounds"):
+            out[key] = [sum(x[key][k] for x in sts) for k in range(6)]
+        return out
+
     res = {}
     if warmup:
         run_steps(list(range(warmup)), res, 0)
-    sync()
-    for c in ctxs:
-        c.reset_stats()
-    res = {}
-    t0 = time.perf_counter()
-    run_steps(list(range(warmup, total_steps)), res, warmup)
-    sync()
-    elapsed = time.perf_counter() - t0
+    # The timed region -- exactly `steps` steps between barrier + drained streams on both sides, MAX over ranks -- is
+    # repeated `reps` times on the same resident batches (identical work every time); the line reports the MEDIAN
+    # repetition and the spread, so that box noise shows in a single run of the command.
+    reps = max(1, args.repeats)
+    rep_runs = []
+    for _ in range(reps):
+        sync()
+        for c in ctxs:
+            c.reset_stats()
+        res = {}
+        t0 = time.perf_counter()
+        run_steps(list(range(warmup, total_steps)), res, warmup)
+        sync()
+        tt = np.array([time.perf_counter() - t0])
+        comm.allreduce_max(tt)  # max over ranks of the time
+        rep_runs.append((float(tt[0]), res, sum_stats()))
+    order = sorted(range(reps), key=lambda i: rep_runs[i][0])
+    elapsed, res, st = rep_runs[order[(reps - 1) // 2]]
+    rep_ms = [1e3 * r[0] / steps for r in rep_runs]
 
     solved = 0
     cyc_hist = np.zeros(4, dtype=np.int64)
@@ -400,19 +457,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
             ok = bl < SUCCESS_LOSS
             per_basis[b] = {"solved_fraction": float(ok.mean()), "mean_cycles": float(bc[ok].mean()) if ok.any() else None}
 
-    def sum_stats():
-        sts = [c.stats() for c in ctxs]
-        out = {"kernel_ms": sum(x["kernel_ms"] for x in sts), "kernel_launches": sum(x["kernel_launches"] for x in sts)}
-        for key in ("evals", "items", "evals_accepted", "evals_preempted", "kernel_ms_span", "wave_rounds"):
-            out[key] = [sum(x[key][k] for x in sts) for k in range(6)]
-        return out
-
-    st = sum_stats()
-
-    # max over ranks of the time; solved targets counted on the all-reduced vector (same on every rank)
-    tt = np.array([elapsed])
-    comm.allreduce_max(tt)
-    elapsed = float(tt[0])
+    # solved targets counted on the all-reduced vector (same on every rank)
     if world > 1:
         solved_all = res["merged_solved"]
         cnt = np.array([float(solved)])
@@ -467,7 +512,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         "n_streams": n_streams, "ipq": ipq, "dev_name": dev_name, "cus": cus, "elapsed": elapsed, "solved_all": solved_all,
         "cyc_hist": cyc_hist, "worst": worst, "per_basis": per_basis, "st": st, "achieved": achieved, "kernel_s": kernel_s,
         "rejected": rejected, "flops_accepted": flops_accepted, "flops_strict": flops_strict, "per_span": per_span,
-        "resident_merge": resident_merge,
+        "resident_merge": resident_merge, "rep_ms": rep_ms, "strong": strong,
     }
 
 
@@ -494,11 +539,27 @@ def main():
     ap.add_argument("--fast-exit", action="store_true",
                     help="drop SLAM_FLAG_ORDERED: the first restart to FINISH below stop_loss wins (timing-dependent winner) instead of "
                          "the lowest-index successful restart (the reference's sequential semantics, bitwise reproducible; default)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="repetitions of the timed region (each exactly --steps steps between barriers); the line reports the median one and min / max")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU gets its own full-size batches; strong: one GPU's batch per step is split over the --gpus ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets of the CPU baseline sample (default 4 x host cores)")
     ap.add_argument("--per-span-steps", type=int, default=3, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 measurement")
     args = ap.parse_args()
+
+    stub = os.environ.get("SLAM_BENCH_TEST_STUB")
+    if stub:
+        # TEST HOOK (tests/test_bench_cpu.py): a stand-in for _ffi.Context so that the launcher / rank / communicator /
+        # JSON plumbing of the N > 1 path can be exercised on a box without a GPU.  Its numbers mean nothing; the line
+        # says so in "data".  Never set outside the tests.
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("slam_bench_test_stub", stub)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.install()
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):
@@ -529,9 +590,12 @@ def main():
             "roofline_frac": fl2 / s2["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
         }}
 
+    rank_devices = gather_strings(comm, rank, world, f"{m['dev_name'].strip()} cu={m['cus']} dev={local_rank}")
     if rank == 0:
         st = m["st"]
         n_launch = max(1, st["kernel_launches"])
+        pmc = pmc_figures(args.workload)
+        rep_ms = sorted(m["rep_ms"])
         out = {
             "metric": "Haar 2-qubit decompositions/sec (span<=3, loss<1e-8)",
             "value": m["solved_all"] / m["elapsed"],
@@ -540,11 +604,21 @@ def main():
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": 1e3 * m["elapsed"] / steps,
+            # the timed region (exactly `steps` steps between barriers) ran `repetitions` times on the same batches;
+            # value / ms_per_step / roofline are the MEDIAN repetition's, min / max show the box noise of this run
+            "repetitions": len(rep_ms),
+            "ms_per_step_min": rep_ms[0],
+            "ms_per_step_max": rep_ms[-1],
+            "ms_per_step_all": m["rep_ms"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if m["strong"] else "weak",
+            # what RCCL itself reports for the communicator the collective ran on (ncclCommCount); None: no RCCL in this run
+            "rccl_world": getattr(comm, "rccl_world", None),
+            "comm": type(comm).__name__,
+            "rank_devices": rank_devices,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not os.environ.get("SLAM_BENCH_TEST_STUB") else "STUB: test hook, no GPU work was done, numbers are meaningless",
             "config": {
                 "workload": m["desc"],
                 "basis": m["gname"],
@@ -576,6 +650,10 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": m["achieved"] / PEAK_FP64_VALU_TFLOPS,
                 "traffic": traffic_per_launch(args.workload),
+                # north_star's two evidence figures, per span, from the committed PMC passes of this workload
+                "valu_busy": pmc["valu_busy"] if pmc else None,
+                "hbm_gbps": pmc["hbm_gbps"] if pmc else None,
+                "pmc_source": pmc["source"] if pmc else None,
                 "kernel": "minimize_kernel<K> (k=1..3)",
                 "scope": "rank 0's GPU",
                 "time_basis": "hip_events" if m["n_streams"] == 1 else "wall_clock_of_timed_region",

@@ -293,6 +293,9 @@ int slam_reset_stats(slam_ctx* ctx);
  * without a host round trip. */
 int slam_best_loss_device_ptr(slam_ctx* ctx, void** ptr, int64_t* n);
 
+/* HIP device ordinal the context was created on (slam_comm_merge_add checks it against its communicator's). */
+int slam_ctx_device(slam_ctx* ctx, int* device);
+
 /*
  * Templates whose 2Q gates carry their own optimisable parameters -- CircuitTemplateV2 (src/slam/basisv2.py:27-299):
  * base_gates are gate classes / lambdas, every gate instance of the circuit gets its own "Q" parameters next to the "P"
@@ -349,10 +352,15 @@ int slam_v2_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const 
  *   slam_comm_merge_begin     start a job-wide best-loss vector of n_global entries on this rank's GPU, all +inf
  *   slam_comm_merge_add       min-merge the context's RESIDENT best_loss[first_local, first_local + count) -- the
  *                             buffer slam_best_loss_device_ptr exposes -- into [first_global, first_global + count)
- *                             of that vector, device to device (call once per context / window of the rank)
+ *                             of that vector, device to device (call once per context / window of the rank).  The
+ *                             context must live on the communicator's device (SLAM_ERR_INVALID otherwise); the read of
+ *                             its buffer is complete when the call returns, so the context may be used again at once
  *   slam_comm_merge_add_host  the same from a host array (results that were fetched already)
  *   slam_allreduce_min        ncclAllReduce(min) of the vector in place over xGMI; n_below (may be NULL) = number of
- *                             entries < threshold counted on the device, merged (may be NULL) = host copy [n_global]
+ *                             entries < threshold counted on the device, merged (may be NULL) = host copy of the
+ *                             n_global entries, merged_capacity = doubles it can hold (SLAM_ERR_INVALID if fewer)
+ *   slam_comm_rank            rank / world size as RCCL ITSELF reports them (ncclCommUserRank / ncclCommCount);
+ *                             SLAM_ERR_STATE if they differ from what slam_comm_init was given
  */
 #define SLAM_COMM_ID_BYTES 128
 #define SLAM_OP_SUM 0
@@ -368,7 +376,7 @@ int slam_comm_barrier(slam_comm* comm);
 int slam_comm_merge_begin(slam_comm* comm, int64_t n_global);
 int slam_comm_merge_add(slam_comm* comm, slam_ctx* ctx, int64_t first_local, int64_t count, int64_t first_global);
 int slam_comm_merge_add_host(slam_comm* comm, const double* loss, int64_t count, int64_t first_global);
-int slam_allreduce_min(slam_comm* comm, double threshold, int64_t* n_below, double* merged);
+int slam_allreduce_min(slam_comm* comm, double threshold, int64_t* n_below, double* merged, int64_t merged_capacity);
 
 /* Library version string. */
 const char* slam_version(void);

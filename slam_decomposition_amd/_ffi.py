@@ -63,6 +63,7 @@ EXPORTED_SYMBOLS = (
     "slam_get_stats",
     "slam_reset_stats",
     "slam_best_loss_device_ptr",
+    "slam_ctx_device",
     "slam_comm_get_unique_id",
     "slam_comm_init",
     "slam_comm_destroy",
@@ -180,6 +181,7 @@ def load_library() -> C.CDLL:
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.slam_reset_stats.argtypes = [P]
     lib.slam_best_loss_device_ptr.argtypes = [P, C.POINTER(P), C.POINTER(C.c_int64)]
+    lib.slam_ctx_device.argtypes = [P, C.POINTER(C.c_int)]
     if hasattr(lib, "slam_comm_init"):
         lib.slam_comm_get_unique_id.argtypes = [P]
         lib.slam_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, P, C.POINTER(P)]
@@ -190,7 +192,7 @@ def load_library() -> C.CDLL:
         lib.slam_comm_merge_begin.argtypes = [P, C.c_int64]
         lib.slam_comm_merge_add.argtypes = [P, P, C.c_int64, C.c_int64, C.c_int64]
         lib.slam_comm_merge_add_host.argtypes = [P, P, C.c_int64, C.c_int64]
-        lib.slam_allreduce_min.argtypes = [P, C.c_double, C.POINTER(C.c_int64), P]
+        lib.slam_allreduce_min.argtypes = [P, C.c_double, C.POINTER(C.c_int64), P, C.c_int64]
     for name in EXPORTED_SYMBOLS:
         if "SLAM_HIP_LIB" in os.environ and not hasattr(lib, name):
             continue  # an older A/B build: newer entry points are simply not used
@@ -628,8 +630,15 @@ class Comm:
     def barrier(self) -> None:
         _check(self._lib.slam_comm_barrier(self._h))
 
+    def rccl_rank_world(self):
+        """(rank, world size) as RCCL itself reports them for this communicator (``ncclCommUserRank`` / ``ncclCommCount``)."""
+        r, w = C.c_int(-1), C.c_int(-1)
+        _check(self._lib.slam_comm_rank(self._h, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
     def merge_begin(self, n_global: int) -> None:
         _check(self._lib.slam_comm_merge_begin(self._h, int(n_global)))
+        self._merge_n = int(n_global)
 
     def merge_add(self, ctx: "Context", first_local: int, count: int, first_global: int) -> None:
         """Min-merge the context's resident best_loss window into the job-wide vector, device to device."""
@@ -639,9 +648,13 @@ class Comm:
         loss = np.ascontiguousarray(loss, dtype=np.float64)
         _check(self._lib.slam_comm_merge_add_host(self._h, _ptr(loss), loss.size, int(first_global)))
 
-    def allreduce_min_merged(self, threshold: float, n_global: Optional[int] = None):
-        """The job's one collective.  Returns (number of entries < threshold, merged vector or None)."""
+    def allreduce_min_merged(self, threshold: float, want_merged: bool = False):
+        """The job's one collective.  Returns (number of entries < threshold, merged vector or None).  The host copy is
+        sized from the ``n_global`` given to ``merge_begin`` (the library checks the capacity again)."""
         nb = C.c_int64(0)
-        merged = np.empty(int(n_global), dtype=np.float64) if n_global else None
-        _check(self._lib.slam_allreduce_min(self._h, float(threshold), C.byref(nb), _ptr(merged)))
+        n = getattr(self, "_merge_n", 0)
+        if n <= 0:
+            raise RuntimeError("allreduce_min_merged: call merge_begin first")
+        merged = np.empty(n, dtype=np.float64) if want_merged else None
+        _check(self._lib.slam_allreduce_min(self._h, float(threshold), C.byref(nb), _ptr(merged), n if want_merged else 0))
         return int(nb.value), merged

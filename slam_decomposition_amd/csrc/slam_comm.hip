@@ -45,6 +45,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     char why[512] = {0};
 };
@@ -69,6 +71,8 @@ void load_rccl() {
     SLAM_SYM(CommInitRank, "ncclCommInitRank")
     SLAM_SYM(CommDestroy, "ncclCommDestroy")
     SLAM_SYM(AllReduce, "ncclAllReduce")
+    SLAM_SYM(CommCount, "ncclCommCount")
+    SLAM_SYM(CommUserRank, "ncclCommUserRank")
     SLAM_SYM(GetErrorString, "ncclGetErrorString")
 #undef SLAM_SYM
 }
@@ -199,8 +203,15 @@ int slam_comm_destroy(slam_comm* c) {
 
 int slam_comm_rank(slam_comm* c, int* rank, int* world) {
     if (!c) return cfail(SLAM_ERR_INVALID, "comm is NULL");
-    if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    // what RCCL itself reports for this communicator (ncclCommUserRank / ncclCommCount), not what the caller passed in:
+    // a job whose ranks did not all join the same communicator shows up here
+    int r = -1, w = -1;
+    RCCL_TRY(g_rccl.CommUserRank(c->comm, &r));
+    RCCL_TRY(g_rccl.CommCount(c->comm, &w));
+    if (r != c->rank || w != c->world)
+        return cfail(SLAM_ERR_STATE, "RCCL reports rank %d of %d, the communicator was created as rank %d of %d", r, w, c->rank, c->world);
+    if (rank) *rank = r;
+    if (world) *world = w;
     return SLAM_OK;
 }
 
@@ -251,12 +262,22 @@ int slam_comm_merge_add(slam_comm* c, slam_ctx* ctx, int64_t first_local, int64_
     if (c->merge_n <= 0) return cfail(SLAM_ERR_STATE, "call slam_comm_merge_begin first");
     void* p = nullptr;
     int64_t n = 0;
-    int rc = slam_best_loss_device_ptr(ctx, &p, &n);  // resident best_loss of the context (same device as the communicator)
+    int rc = slam_best_loss_device_ptr(ctx, &p, &n);  // resident best_loss of the context
     if (rc) return rc;
+    int ctx_device = -1;
+    rc = slam_ctx_device(ctx, &ctx_device);
+    if (rc) return rc;
+    if (ctx_device != c->device)
+        return cfail(SLAM_ERR_INVALID, "context lives on device %d, the communicator on device %d: a rank merges its own GPU's results", ctx_device, c->device);
     if (first_local < 0 || count < 0 || first_local + count > n) return cfail(SLAM_ERR_INVALID, "window outside the context's resident results");
     CHIP_TRY(hipSetDevice(c->device));
-    // every API call on the context ends with its stream drained, so its results are complete here
-    return merge_window(c, static_cast<const double*>(p) + first_local, count, first_global);
+    // every API call on the context ends with its stream drained, so its results are complete here ...
+    rc = merge_window(c, static_cast<const double*>(p) + first_local, count, first_global);
+    if (rc) return rc;
+    // ... and the read of the context's buffer is complete when this call returns: the context's next call (which resets
+    // the window to +inf on ITS stream) cannot race with it
+    CHIP_TRY(hipStreamSynchronize(c->stream));
+    return SLAM_OK;
 }
 
 int slam_comm_merge_add_host(slam_comm* c, const double* loss, int64_t count, int64_t first_global) {
@@ -274,9 +295,12 @@ int slam_comm_merge_add_host(slam_comm* c, const double* loss, int64_t count, in
     return SLAM_OK;
 }
 
-int slam_allreduce_min(slam_comm* c, double threshold, int64_t* n_below, double* merged) {
+int slam_allreduce_min(slam_comm* c, double threshold, int64_t* n_below, double* merged, int64_t merged_capacity) {
     if (!c) return cfail(SLAM_ERR_INVALID, "comm is NULL");
     if (c->merge_n <= 0) return cfail(SLAM_ERR_STATE, "call slam_comm_merge_begin first");
+    if (merged && merged_capacity < c->merge_n)
+        return cfail(SLAM_ERR_INVALID, "merged holds %lld doubles, the job vector has %lld (slam_comm_merge_begin)", (long long)merged_capacity,
+                     (long long)c->merge_n);
     CHIP_TRY(hipSetDevice(c->device));
     RCCL_TRY(g_rccl.AllReduce(c->d_merge, c->d_merge, (size_t)c->merge_n, ncclFloat64, ncclMin, c->comm, c->stream));
     unsigned long long cnt = 0;

@@ -1113,6 +1113,12 @@ int slam_reset_stats(slam_ctx* ctx) {
     return SLAM_OK;
 }
 
+int slam_ctx_device(slam_ctx* ctx, int* device) {
+    if (!ctx || !device) return fail(SLAM_ERR_INVALID, "NULL argument");
+    *device = ctx->device;
+    return SLAM_OK;
+}
+
 int slam_best_loss_device_ptr(slam_ctx* ctx, void** ptr, int64_t* n) {
     if (!ctx || !ptr || !n) return fail(SLAM_ERR_INVALID, "NULL argument");
     if (!ctx->best_loss.p || ctx->n_targets <= 0) return fail(SLAM_ERR_STATE, "no resident results");

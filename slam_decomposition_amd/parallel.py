@@ -20,6 +20,7 @@ from a file (``exchange_unique_id``); the file's name comes from ``SLAM_COMM_FIL
 from __future__ import annotations
 
 import os
+import struct
 import tempfile
 import time
 from typing import Callable, Optional, Tuple
@@ -76,49 +77,82 @@ def rendezvous_path(env=os.environ) -> str:
     return os.path.join(tempfile.gettempdir(), f"slam_comm_{os.getuid()}_{key}.id")
 
 
+_ID_MAGIC = b"SLAMID01"
+_JOB_START = time.time()  # wall clock at import: no id file of THIS job can be older
+
+
+def _generation_path(path: str, generation: int) -> str:
+    return path if generation == 0 else f"{path}.g{generation}"
+
+
 def exchange_unique_id(rank: int, world: int, path: str, make_id: Callable[[], bytes], timeout: float = 300.0,
-                       nbytes: int = 128) -> bytes:
-    """Rank 0 writes ``make_id()`` to ``path`` atomically (temp file + rename); the others wait for it."""
+                       nbytes: int = 128, generation: int = 0, not_before: Optional[float] = None) -> bytes:
+    """Rank 0 writes ``make_id()`` to the generation's file atomically (temp file + rename); the others wait for it.
+
+    Generation-safe: every communicator a process builds on one ``path`` has its own sequence number (``generation``,
+    counted per path by :class:`RcclComm` -- all ranks of a job build their communicators in the same order), which is in
+    the file's name and in its header (magic, generation, world size, rank 0's write time).  Rank 0 removes a
+    pre-existing file of that name before it creates the id; readers reject a file with the wrong header or one written
+    before ``not_before`` (default: 10 min before this process imported the module -- a leftover of a crashed job with a
+    repeated ``SLAM_COMM_FILE`` / torchrun key is older than any rank of this job)."""
     if world == 1:
         return make_id()
+    gpath = _generation_path(path, generation)
+    if not_before is None:
+        not_before = _JOB_START - 600.0
     if rank == 0:
+        try:
+            os.remove(gpath)  # a stale file of an earlier job: nobody may pick it up while the new id is being made
+        except OSError:
+            pass
         uid = make_id()
         if len(uid) != nbytes:
             raise ValueError(f"unique id must be {nbytes} bytes")
-        tmp = f"{path}.tmp{os.getpid()}"
+        tmp = f"{gpath}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
-            f.write(uid)
+            f.write(_ID_MAGIC + struct.pack("<qqd", int(generation), int(world), time.time()) + uid)
             f.flush()
             os.fsync(f.fileno())
-        os.replace(tmp, path)
+        os.replace(tmp, gpath)
         return uid
     t0 = time.monotonic()
+    hdr = len(_ID_MAGIC) + 24
     while True:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == nbytes:
-                return uid
+            with open(gpath, "rb") as f:
+                blob = f.read()
+            if len(blob) == hdr + nbytes and blob[: len(_ID_MAGIC)] == _ID_MAGIC:
+                gen, w, stamp = struct.unpack("<qqd", blob[len(_ID_MAGIC) : hdr])
+                if gen == generation and w == world and stamp >= not_before:
+                    return blob[hdr:]
         except FileNotFoundError:
             pass
         if time.monotonic() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s (is rank 0 running?)")
+            raise TimeoutError(f"rank {rank}: no communicator id (generation {generation}) at {gpath} after {timeout:.0f} s (is rank 0 running?)")
         time.sleep(0.02)
 
 
 class RcclComm:
     """RCCL communicator of this rank through libslamhip (``_ffi.Comm``): ``backend "nccl"`` without torch."""
 
+    _generations: dict = {}  # rendezvous path -> communicators this process has built on it
+
     def __init__(self, device: int, rank: int, world: int, path: Optional[str] = None, timeout: float = 300.0):
         from . import _ffi
 
         self.rank, self.world, self.device = int(rank), int(world), int(device)
         self.path = path or rendezvous_path()
-        uid = exchange_unique_id(self.rank, self.world, self.path, _ffi.Comm.unique_id, timeout)
+        # a second communicator on the same path gets its own file: a rank that is already through the first
+        # ncclCommInitRank can never read the first communicator's id again
+        gen = RcclComm._generations.get(self.path, 0)
+        RcclComm._generations[self.path] = gen + 1
+        uid = exchange_unique_id(self.rank, self.world, self.path, _ffi.Comm.unique_id, timeout, generation=gen)
         self.raw = _ffi.Comm(device, rank, world, uid)  # collective: returns once every rank has joined
+        # what RCCL itself says about the communicator; SLAM_ERR_STATE if it is not the job we asked for
+        self.rccl_rank, self.rccl_world = self.raw.rccl_rank_world()
         if self.rank == 0 and self.world > 1:
             try:
-                os.remove(self.path)  # every rank holds the id by now
+                os.remove(_generation_path(self.path, gen))  # every rank holds the id by now
             except OSError:
                 pass
 
@@ -130,14 +164,22 @@ class RcclComm:
         dev = int(env.get("LOCAL_RANK", "0")) if device is None else device
         return cls(dev, rank, world, rendezvous_path(env))
 
+    @staticmethod
+    def _flat(a: np.ndarray) -> np.ndarray:
+        # in place means in place: reshape(-1) of a non-contiguous array is a COPY, and reducing that would leave the
+        # caller's array untouched without a word
+        if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
+            raise ValueError("all-reduce buffers must be C-contiguous float64 arrays (reduced in place)")
+        return a.reshape(-1)
+
     def allreduce_min(self, a: np.ndarray) -> None:
-        self.raw.allreduce_min(a.reshape(-1))
+        self.raw.allreduce_min(self._flat(a))
 
     def allreduce_sum(self, a: np.ndarray) -> None:
-        self.raw.allreduce_sum(a.reshape(-1))
+        self.raw.allreduce_sum(self._flat(a))
 
     def allreduce_max(self, a: np.ndarray) -> None:
-        self.raw.allreduce_max(a.reshape(-1))
+        self.raw.allreduce_max(self._flat(a))
 
     def barrier(self) -> None:
         self.raw.barrier()

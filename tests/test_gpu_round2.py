@@ -141,7 +141,8 @@ def test_rccl_communicator_through_the_c_abi_single_rank(hip_ctx, tmp_path):
         comm.raw.merge_begin(N + 10)
         comm.raw.merge_add(hip_ctx, 0, 20, 5)
         comm.raw.merge_add(hip_ctx, 20, N - 20, 25)
-        n_below, merged = comm.raw.allreduce_min_merged(1e-8, N + 10)
+        n_below, merged = comm.raw.allreduce_min_merged(1e-8, want_merged=True)
+        assert len(merged) == N + 10 and comm.raw.rccl_rank_world() == (0, 1) and (comm.rccl_rank, comm.rccl_world) == (0, 1)
         assert np.array_equal(merged[5 : 5 + N], best_loss)
         assert np.all(np.isinf(merged[:5])) and np.all(np.isinf(merged[5 + N :]))
         assert n_below == int((best_loss < 1e-8).sum())
@@ -149,10 +150,18 @@ def test_rccl_communicator_through_the_c_abi_single_rank(hip_ctx, tmp_path):
         comm.raw.merge_begin(8)
         comm.raw.merge_add_host(np.array([1.0, 2.0, 3.0]), 2)
         comm.raw.merge_add_host(np.array([5.0, 0.5]), 3)
-        n_below, merged = comm.raw.allreduce_min_merged(1.5, 8)
+        n_below, merged = comm.raw.allreduce_min_merged(1.5, want_merged=True)
         assert np.array_equal(merged, [np.inf, np.inf, 1.0, 2.0, 0.5, np.inf, np.inf, np.inf]) and n_below == 2
         with pytest.raises(_ffi.SlamHipError):
             comm.raw.merge_add(hip_ctx, 0, N, 7)  # window beyond the merge vector
+        # the library checks the capacity of the host copy itself (a short buffer used to be a heap overflow)
+        lib = _ffi.load_library()
+        short = np.empty(3)
+        nb = _ffi.C.c_int64(0)
+        assert lib.slam_allreduce_min(comm.raw._h, 1.0, _ffi.C.byref(nb), short.ctypes.data_as(_ffi.C.c_void_p), 3) == -1  # SLAM_ERR_INVALID
+        # in place means in place: a non-contiguous view is refused instead of silently reducing a copy
+        with pytest.raises(ValueError):
+            comm.allreduce_min(np.zeros((4, 4))[:, 1])
         L, X, C = merge_results(comm, N, 0, best_loss, best_x, best_cycles)
         assert np.array_equal(L, best_loss) and np.array_equal(X, best_x) and np.array_equal(C, best_cycles)
     finally:

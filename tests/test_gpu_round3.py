@@ -1,0 +1,116 @@
+"""GPU, round 3: the first N > 1 run made self-verifying: bench.py's launcher path with one
+RCCL rank against the plain single-process line; two RCCL ranks on two GPUs (skipped on a one-GPU box) -- device-to-device
+merge = host merge, RCCL-reported world size, a context on another GPU refused."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from slam_decomposition_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SLAM_BENCH_TEST_STUB"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--per-span-steps", "0"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_launcher_with_one_rccl_rank_reproduces_the_plain_line():
+    """`bench.py --gpus 1` run as launcher + rank process + RCCL communicator (the N > 1 code path with a world of one) does
+    the same work as the plain single-process run -- identical evaluation counts and solved fraction (ordered early exit:
+    bitwise reproducible results) -- at the same speed (median of 3 repetitions within 3 %; 5 % here to
+    keep a shared box's noise from failing the suite) and reports what RCCL says about its communicator."""
+    args = ["--steps", "10", "--warmup", "3", "--targets", "16384"]
+    plain = _bench(args, {})
+    rccl = _bench(args, {"SLAM_BENCH_FORCE_LAUNCH": "1"})
+    assert plain["comm"] == "LocalComm" and plain["rccl_world"] is None
+    assert rccl["comm"] == "RcclComm" and rccl["rccl_world"] == 1 and rccl["n_gpus"] == 1
+    assert len(rccl["rank_devices"]) == 1 and "gfx950" in rccl["rank_devices"][0]
+    assert plain["roofline"]["evals_per_span"] == rccl["roofline"]["evals_per_span"]
+    assert plain["solved_fraction"] == rccl["solved_fraction"] == 1.0
+    assert plain["repetitions"] == 3 and plain["ms_per_step_min"] <= plain["ms_per_step"] <= plain["ms_per_step_max"]
+    ratio = rccl["value"] / plain["value"]
+    assert 0.95 < ratio < 1.05, (ratio, plain["ms_per_step_all"], rccl["ms_per_step_all"])
+    # north_star's two evidence figures ride on the line, from the committed PMC passes
+    assert set(plain["roofline"]["valu_busy"]) == {"1", "2", "3"} and plain["roofline"]["pmc_source"].startswith("profiles/")
+
+
+RANK_WORKER = textwrap.dedent(
+    """
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, sys.argv[1])
+    from oracle import slam_oracle as o
+    from slam_decomposition_amd import _ffi
+    from slam_decomposition_amd.parallel import RcclComm, shard_range
+
+    rank, world, path, N = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
+    comm = RcclComm(rank, rank, world, path)              # one GPU per rank
+    first, count = shard_range(N, rank, world)
+    ctx = _ffi.Context(rank)
+    ctx.set_targets(o.haar_batch(N, seed0=77)[first:first + count])
+    ctx.set_gates(o.riswap_matrix(0.5)[None])
+    prm = _ffi.OptParams(restarts=6, seed=9, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED, target_base=first)
+    loss, x, cyc = ctx.decompose(1, 3, [[0], [0, 0], [0, 0, 0]], prm, 1e-10)
+    # device to device: resident window -> this rank's slice -> ncclAllReduce(min)
+    comm.raw.merge_begin(N)
+    comm.raw.merge_add(ctx, 0, count, first)
+    n_below, merged = comm.raw.allreduce_min_merged(1e-8, want_merged=True)
+    # host path: the same vector through the small-array all-reduce
+    host = np.full(N, np.inf); host[first:first + count] = loss
+    comm.allreduce_min(host)
+    other_dev_refused = None
+    if world > 1:
+        other = _ffi.Context((rank + 1) % world)          # a context on ANOTHER GPU must be refused, not dereferenced
+        other.set_targets(o.haar_batch(4, seed0=1)); other.set_gates(o.riswap_matrix(0.5)[None])
+        other.decompose(1, 2, [[0], [0, 0]], _ffi.OptParams(restarts=2, seed=1), 1e-10)
+        try:
+            comm.raw.merge_add(other, 0, 4, 0); other_dev_refused = False
+        except _ffi.SlamHipError as e:
+            other_dev_refused = e.code == -1
+        other.close()
+    comm.barrier()
+    print(json.dumps({"rank": rank, "rccl": list(comm.raw.rccl_rank_world()), "n_below": n_below, "merged": merged.tolist(),
+                      "host": host.tolist(), "first": first, "count": count, "loss": loss.tolist(), "refused": other_dev_refused}))
+    ctx.close(); comm.close()
+    """
+)
+
+
+def test_two_rccl_ranks_on_two_gpus_merge_device_to_device(tmp_path):
+    """the resident merge (slam_comm_merge_add -> slam_allreduce_min, ncclMin over xGMI) with world > 1.  Two
+    FRESH rank processes, started before anything in them touches a GPU, one device each."""
+    if _ffi.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    N = 64
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", str(tmp_path / "id"), str(N)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    a, b = sorted(outs, key=lambda d: d["rank"])
+    assert a["rccl"] == [0, 2] and b["rccl"] == [1, 2]
+    assert a["merged"] == b["merged"] == a["host"] == b["host"]  # device-to-device merge = host merge, on both ranks, bit for bit
+    full = np.array(a["merged"])
+    assert np.array_equal(full[a["first"] : a["first"] + a["count"]], a["loss"]) and np.array_equal(full[b["first"] : b["first"] + b["count"]], b["loss"])
+    assert a["n_below"] == b["n_below"] == int((full < 1e-8).sum()) == N
+    assert a["refused"] is True and b["refused"] is True

@@ -108,6 +108,31 @@ def test_recorded_v2_square_cost_run_kat1():
     assert np.max(np.abs(np.array(c1c2c3(basis.eval(td.Xk))) - 0.5)) < 1e-3  # |coordinate error| ~ sqrt(loss)
 
 
+def test_recorded_riswap_sweep_through_the_c_abi(hip_ctx):
+    """decomp_trajectory.ipynb cell 12 (tests/golden/kat1_riswap_sweep.json): the KAT-1 circuit with its last RiSwapGate
+    at alpha = t, t = linspace(0, 0.5, 25) -- the only recorded data with RiSwapGate(alpha != 1/2).  The 25 parameter
+    vectors go through ``slam_v2_eval_loss_grad`` (template unitary with the gate parameter on the device) and
+    ``slam_c1c2c3``; with cell 10's x-axis mirror the triples equal the recorded ones to all 8 digits."""
+    here = os.path.dirname(__file__)
+    kat = json.load(open(os.path.join(here, "golden", "kat1.json")))
+    sweep = json.load(open(os.path.join(here, "golden", "kat1_riswap_sweep.json")))
+    basis = CircuitTemplateV2(n_qubits=2, base_gates=[RiSwapGate], edge_params=[[(0, 1)]])
+    basis.build(3)
+    ts = np.linspace(0, 0.5, 25)
+    X = np.stack([np.concatenate([kat["params"], [0.5, 0.5, t]]) for t in ts])
+    hip_ctx.set_targets(np.eye(4, dtype=np.complex128)[None])
+    hip_ctx.v2_set_gates(basis._gate_maps)
+    _, _, W = hip_ctx.v2_eval(basis.gate_sequence(3), basis.to_device_vector(X, 3), want_grad=False, want_unitary=True)
+    coords = np.array(hip_ctx.c1c2c3(W))
+    m = coords[:, 0] > 0.5
+    coords[m, 0] = -1 * coords[m, 0] + 1  # "eliminating x-axis symmetry" (cell 10)
+    assert np.array_equal(np.round(coords, 8), np.array(sweep["c1c2c3"]))
+    # ... and the unitaries themselves against the oracle's gate objects
+    for t, w in zip(ts, W):
+        ref = v.template_eval(np.concatenate([kat["params"], [0.5, 0.5, t]]), [lambda a: RiSwapGate(a).to_matrix()] * 3, 1, 3)
+        assert np.max(np.abs(w - ref)) < 1e-13
+
+
 def _scipy_best(fn, qn, k, target, bounds, x0s, square=False):
     best = np.inf
     gm = gate_map(fn)[1:]

@@ -176,3 +176,24 @@ def test_kat1_through_the_v2_restatement():
     f, g = v.loss_and_grad(x, [gmap] * 3, 1, 3, SWAP, square=True)
     assert abs(f - KAT1["square_cost_vs_swap"]) < 1e-15
     assert np.max(np.abs(g - v.fd_grad(x, fns, 1, 3, SWAP, square=True))) < 1e-9
+
+
+def test_kat1_riswap_sweep_pins_the_gate_parameter_path():
+    """decomp_trajectory.ipynb cell 12 (tests/golden/kat1_riswap_sweep.json, tools/make_kat_sweep.py): 25 recorded
+    ``c1c2c3`` triples of the KAT-1 circuit with the LAST RiSwapGate at alpha = t, t = linspace(0, 0.5, 25), mirrored on the
+    x axis as cell 10 does.  The only recorded data with RiSwapGate(alpha != 1/2): it pins the gate-parameter forward
+    path of the V2 restatement (custom_gates.py:582-595 through basisv2.py:262-287) digit for digit."""
+    from oracle import v2_oracle as v
+
+    sweep = json.load(open(os.path.join(HERE, "golden", "kat1_riswap_sweep.json")))
+    fns = [lambda a: o.riswap_matrix(a)] * 3
+    ts = np.linspace(0, 0.5, 25)
+    assert len(sweep["c1c2c3"]) == len(ts)
+    for t, want in zip(ts, sweep["c1c2c3"]):
+        x = np.concatenate([KAT1["params"], [0.5, 0.5, t]])
+        c = list(o.c1c2c3(v.template_eval(x, fns, 1, 3)))
+        if c[0] > 0.5:
+            c[0] = -1 * c[0] + 1  # "eliminating x-axis symmetry" (cell 10)
+        assert [round(float(v_), 8) for v_ in c] == want, (t, c, want)  # exact to the 8 recorded digits
+    # the sweep's ends are the two triples KAT-1 already holds
+    assert sweep["c1c2c3"][0] == KAT1["c1c2c3_first8"] and sweep["c1c2c3"][-1] == KAT1["c1c2c3_full"]

@@ -112,6 +112,49 @@ def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path):
         exchange_unique_id(1, 2, str(tmp_path / "never"), lambda: uid, timeout=0.2)
 
 
+def test_file_rendezvous_rejects_stale_and_foreign_ids(tmp_path):
+    """a 128-byte file left at the rendezvous path by a crashed job (fixed SLAM_COMM_FILE, repeated torchrun
+    key) or by an EARLIER communicator of the same job must never be taken for this communicator's id -- the ranks
+    would sit in ncclCommInitRank with different ids for ever."""
+    import os
+    import struct
+    import threading
+    import time
+
+    import pytest
+
+    from slam_decomposition_amd import parallel
+    from slam_decomposition_amd.parallel import exchange_unique_id
+
+    path = str(tmp_path / "id")
+    old, new = bytes([7]) * 128, bytes(range(128))
+    # (a) a bare 128-byte leftover (round 2's format) and a well-formed file from long ago: both ignored
+    open(path, "wb").write(old)
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(1, 2, path, lambda: b"", timeout=0.2)
+    open(path, "wb").write(parallel._ID_MAGIC + struct.pack("<qqd", 0, 2, time.time() - 86400.0) + old)
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(1, 2, path, lambda: b"", timeout=0.2)
+    # (b) a reader that started before rank 0 gets the NEW id: rank 0 removes the leftover before it makes its own
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault(1, exchange_unique_id(1, 2, path, lambda: b"", timeout=20)))
+    t.start()
+    time.sleep(0.1)
+    assert exchange_unique_id(0, 2, path, lambda: new) == new
+    t.join()
+    assert got[1] == new
+    # (c) the second communicator on the same path has its own file: generation 0's id is never read for generation 1,
+    # neither is a file written for another world size
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(1, 2, path, lambda: b"", timeout=0.2, generation=1)
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(1, 3, path, lambda: b"", timeout=0.2)
+    newer = bytes([9]) * 128
+    assert exchange_unique_id(0, 2, path, lambda: newer, generation=1) == newer
+    assert exchange_unique_id(1, 2, path, lambda: b"", timeout=5, generation=1) == newer
+    assert exchange_unique_id(1, 2, path, lambda: b"", timeout=5) == new and os.path.exists(path + ".g1")
+
+
 FILE_WORKER = textwrap.dedent(
     """
     import os, sys

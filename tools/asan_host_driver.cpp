@@ -65,6 +65,7 @@ int main() {
     EXPECT(slam_get_stats(nullptr, &st) == SLAM_ERR_INVALID);
     EXPECT(slam_reset_stats(nullptr) == SLAM_ERR_INVALID);
     EXPECT(slam_best_loss_device_ptr(nullptr, &p, &i64) == SLAM_ERR_INVALID);
+    { int dev = 0; EXPECT(slam_ctx_device(nullptr, &dev) == SLAM_ERR_INVALID); }
     // communicator: bad arguments; without RCCL or without a device creation fails with a message
     slam_comm* comm = nullptr;
     char id[SLAM_COMM_ID_BYTES] = {0};
@@ -79,7 +80,7 @@ int main() {
     EXPECT(slam_comm_merge_begin(nullptr, 1) == SLAM_ERR_INVALID);
     EXPECT(slam_comm_merge_add(nullptr, nullptr, 0, 0, 0) == SLAM_ERR_INVALID);
     EXPECT(slam_comm_merge_add_host(nullptr, d, 1, 0) == SLAM_ERR_INVALID);
-    EXPECT(slam_allreduce_min(nullptr, 1e-8, &i64, d) == SLAM_ERR_INVALID);
+    EXPECT(slam_allreduce_min(nullptr, 1e-8, &i64, d, 1) == SLAM_ERR_INVALID);
     // the message is thread-local: concurrent failing calls do not trample each other
     std::vector<std::thread> th;
     for (int t = 0; t < 8; ++t)
