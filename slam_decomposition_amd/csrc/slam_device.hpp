@@ -28,6 +28,14 @@
 
 #include "slam_sincos.hpp"
 
+// build-time experiment switches (tools/ab_build.sh)
+#ifndef SLAM_L0OUT
+#define SLAM_L0OUT 1
+#endif
+#ifndef SLAM_K1_LOWREG
+#define SLAM_K1_LOWREG 0
+#endif
+
 namespace slamdev {
 
 constexpr int kQuadsPerWave = 16;
@@ -148,10 +156,37 @@ __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 // quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2), [0,0,0,0] = 0x00 (broadcast lane 0)
+#ifndef SLAM_SWZ
+#define SLAM_SWZ 0
+#endif
+// The same quad permutation executed by the LDS unit (ds_swizzle_b32, quad-perm mode: bit 15 + the four lane selects):
+// no vector-ALU slot -- a fp64 shuffle is two v_mov_b32_dpp, 8 issue cycles of a kernel that is bound by exactly those --
+// at the price of an LDS round trip per stage, which the SIMD's other wavefront covers.
+template <int CTRL>
+__device__ __forceinline__ double swz_f64(double v) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x8000 | CTRL);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x8000 | CTRL);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_shuffle(double v) {
+#if SLAM_SWZ
+    return swz_f64<CTRL>(v);
+#else
+    return dpp_f64<CTRL>(v);
+#endif
+}
 __device__ __forceinline__ double quad_sum(double v) {
-    v += dpp_f64<0xB1>(v);
-    v += dpp_f64<0x4E>(v);
+    v += quad_shuffle<0xB1>(v);
+    v += quad_shuffle<0x4E>(v);
     return v;
+}
+// two sums at once: both values' shuffles of a stage are in flight together (one LDS round trip per stage, not two)
+__device__ __forceinline__ void quad_sum2(double& a, double& b) {
+    const double a1 = quad_shuffle<0xB1>(a), b1 = quad_shuffle<0xB1>(b);
+    a += a1; b += b1;
+    const double a2 = quad_shuffle<0x4E>(a), b2 = quad_shuffle<0x4E>(b);
+    a += a2; b += b2;
 }
 // max(|a|, |b|) in ONE instruction: fmax() canonicalises its operands first (IEEE sNaN semantics), an extra v_max_f64
 // x, x, x each; the callers' values are finite by construction
@@ -161,8 +196,8 @@ __device__ __forceinline__ double max_abs(double a, double b) {
     return m;
 }
 __device__ __forceinline__ double quad_max(double v) {  // v >= 0
-    v = max_abs(v, dpp_f64<0xB1>(v));
-    v = max_abs(v, dpp_f64<0x4E>(v));
+    v = max_abs(v, quad_shuffle<0xB1>(v));
+    v = max_abs(v, quad_shuffle<0x4E>(v));
     return v;
 }
 
@@ -252,6 +287,35 @@ __device__ __forceinline__ void u3_unit(const U3t& t, double f0, double f1, doub
     const double ti = t.c * g1i;
     y1r = t.cp * tr - t.sp * ti;
     y1i = t.cp * ti + t.sp * tr;
+}
+
+// u3_unit that also returns t = (s f0 + c e^{i lam} f1), the second component before the phi phase.  With it the column of
+// 2 dU3/dtheta (= U3 with (c, s) -> (-s, c)) applied to the same unit vector is (-t, e^{i phi} y0): no second rotation.
+__device__ __forceinline__ void u3_unit_t(const U3t& t, double f0, double f1, double& y0r, double& y0i, double& y1r, double& y1i,
+                                          double& tr, double& ti) {
+    const double g1r = t.cl * f1, g1i = t.sl * f1;
+    y0r = t.c * f0 - t.s * g1r;
+    y0i = -(t.s * g1i);
+    tr = t.s * f0 + t.c * g1r;
+    ti = t.c * g1i;
+    y1r = t.cp * tr - t.sp * ti;
+    y1i = t.cp * ti + t.sp * tr;
+}
+// Layer 0 seen from its OUTPUT side.  Its input is the unit vector e_q, so K_0 e_q = a (x) b with a = A e_{q1}, b = B e_{q0}, and
+// the derivative with respect to a parameter of one gate X (column x = X e, w = the backward vector contracted with the OTHER
+// gate's column) is Re(w . dx):
+//   d/dphi x = (0, i x1)                 ->  -Im(w1 x1)
+//   d/dlam x = i f1 x   (f1 = the bit)   ->  -f1 Im(w0 x0 + w1 x1)
+//   d/dtheta x = 1/2 (-t, e^{i phi} x0)  ->  1/2 ( Re(w1 e^{i phi} x0) - Re(w0 t) )
+// 42 operations per gate including the column itself, against ~60 for the row action with its intermediates.
+__device__ __forceinline__ void l0_gate_partials(const U3t& g, double f0, double f1, double w0r, double w0i, double w1r, double w1i,
+                                                 double x0r, double x0i, double x1r, double x1i, double tr, double ti, double& dth, double& dph,
+                                                 double& dla) {
+    const double d1r = g.cp * x0r - g.sp * x0i, d1i = g.cp * x0i + g.sp * x0r;  // e^{i phi} x0
+    dth = 0.5 * ((w1r * d1r - w1i * d1i) - (w0r * tr - w0i * ti));
+    const double im1 = w1r * x1i + w1i * x1r;
+    dph = -im1;
+    dla = -f1 * (im1 + (w0r * x0i + w0i * x0r));
 }
 
 // row action: (u0, u1) <- (u0, u1) U3
@@ -613,16 +677,21 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     constexpr bool PSQ = psq_layout<K, GC>();
     using C = Cfg<K, PSQ>;
     asm volatile("" : "+v"(theta_bits));  // one register, not NA hoisted lane masks
+    // K = 1 at three wavefronts per SIMD (168 registers): the latency-hiding prefetches that cost registers are dropped --
+    // the third wavefront covers what they covered
+    constexpr bool kLowReg = (K == 1) && (SLAM_K1_LOWREG != 0);
     // this quad's trig table (Cfg::TOFF): offsets (0, 4, 2, 6) doubles for quad mod 4 = 0..3
     double* const xt = xq + (PSQ ? (int)((threadIdx.x & 4) + ((threadIdx.x >> 2) & 2)) : 0);
     auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
-    // the target column is requested first and consumed after the forward pass
+    // the target column is requested first and consumed after the forward pass (kLowReg: requested after it)
     double tre[4], tim[4];
+    if constexpr (!kLowReg) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
-        tre[r] = t.x;
-        tim[r] = t.y;
+        for (int r = 0; r < 4; ++r) {
+            const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
+            tre[r] = t.x;
+            tim[r] = t.y;
+        }
     }
     // ---- 1. trig table: each lane handles its own parameter slots
     {
@@ -740,14 +809,21 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     for (int r = 0; r < 4; ++r) { Wr[r] = Fr[r]; Wi[r] = Fi[r]; }
 
     // ---- 3. t = Tr(T^+ W), loss, z = -conj(t) / (4|t|)
+    if constexpr (kLowReg) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
+            tre[r] = t.x;
+            tim[r] = t.y;
+        }
+    }
     double pr = 0.0, pi = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         pr = fma(tre[r], Fr[r], fma(tim[r], Fi[r], pr));
         pi = fma(tre[r], Fi[r], fma(-tim[r], Fr[r], pi));
     }
-    pr = quad_sum(pr);
-    pi = quad_sum(pi);
+    quad_sum2(pr, pi);
     const double at2 = pr * pr + pi * pi;
     const double rat = (at2 > 1e-300) ? fast_rsqrt(at2) : 0.0;  // 1 / |t|
     const double at = at2 * rat;
@@ -756,6 +832,9 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     // 0.8 (2 L - L^2) of BasicCost L, so its gradient is 1.6 (1 - L) times BasicCost's (wave-uniform select)
     // written as L (c0 + c1 L) and its derivative factor d0 + d1 L with wave-uniform coefficients ((1, 0), (1, 0) for
     // BasicCost -- exact --, (1.6, -0.8), (1.6, -1.6) for SquareCost): scalar selects instead of vector ones
+    // (opaque: hoisted out of the optimizer loop the three coefficients were spilled into VGPR lanes and came back through six
+    // v_readlane -- vector-ALU slots -- per evaluation; re-selected here they are three s_cselect_b64)
+    asm volatile("" : "+s"(cost_kind));
     const bool sq = (cost_kind == 1);
     const double c0 = sq ? 1.6 : 1.0, c1 = sq ? -0.8 : 0.0, d1 = sq ? -1.6 : 0.0;
     fout = basic * fma(c1, basic, c0);
@@ -769,7 +848,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         Ur[r] = zr * tre[r] + zi * tim[r];
         Ui[r] = zi * tre[r] - zr * tim[r];
     }
-    constexpr bool kBwdTrigAhead = (K == 1);
+    constexpr bool kL0Out = SLAM_L0OUT != 0;  // layer 0's partials from its output side (l0_gate_partials)
+    constexpr bool kBwdTrigAhead = (K == 1) && !kLowReg;
     constexpr bool kEarlyP = (K <= 4);
     constexpr bool kKeepTopTrig = (K <= 3);  // layer K's trig entries stay in registers from the forward pass
     static_assert(!PSQ || kKeepTopTrig, "the partial-sum planes start over the top layer's trig entries: nobody may read those in the backward pass");
@@ -777,7 +857,7 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Hr[r] = Fr[r]; Hi[r] = Fi[r]; }
 #pragma unroll
-    for (int j = K; j >= 0; --j) {
+    for (int j = K; j >= (kL0Out ? 1 : 0); --j) {
         if (!LEAN && j < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -916,6 +996,33 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
             if (LEAN) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { Hr[r] = Pr[r]; Hi[r] = Pi[r]; }
+            }
+        }
+    }
+
+    if constexpr (kL0Out) {
+        // layer 0 from its output side: Ur/Ui is the backward vector behind G_1, Bn/An hold layer 0's trig entries
+        const U3t B = Bn;
+        const U3t A = An;
+        double b0r, b0i, b1r, b1i, tbr, tbi, a0r, a0i, a1r, a1i, tar, tai;
+        u3_unit_t(B, e0[0], e0[1], b0r, b0i, b1r, b1i, tbr, tbi);
+        u3_unit_t(A, e1[0], e1[1], a0r, a0i, a1r, a1i, tar, tai);
+        // wB[r0] = u[r0] a0 + u[2 + r0] a1,   wA[r1] = u[2 r1] b0 + u[2 r1 + 1] b1
+        const double wB0r = (Ur[0] * a0r - Ui[0] * a0i) + (Ur[2] * a1r - Ui[2] * a1i), wB0i = (Ur[0] * a0i + Ui[0] * a0r) + (Ur[2] * a1i + Ui[2] * a1r);
+        const double wB1r = (Ur[1] * a0r - Ui[1] * a0i) + (Ur[3] * a1r - Ui[3] * a1i), wB1i = (Ur[1] * a0i + Ui[1] * a0r) + (Ur[3] * a1i + Ui[3] * a1r);
+        const double wA0r = (Ur[0] * b0r - Ui[0] * b0i) + (Ur[1] * b1r - Ui[1] * b1i), wA0i = (Ur[0] * b0i + Ui[0] * b0r) + (Ur[1] * b1i + Ui[1] * b1r);
+        const double wA1r = (Ur[2] * b0r - Ui[2] * b0i) + (Ur[3] * b1r - Ui[3] * b1i), wA1i = (Ur[2] * b0i + Ui[2] * b0r) + (Ur[3] * b1i + Ui[3] * b1r);
+        double part[6];
+        l0_gate_partials(B, e0[0], e0[1], wB0r, wB0i, wB1r, wB1i, b0r, b0i, b1r, b1i, tbr, tbi, part[0], part[1], part[2]);
+        l0_gate_partials(A, e1[0], e1[1], wA0r, wA0i, wA1r, wA1i, a0r, a0i, a1r, a1i, tar, tai, part[3], part[4], part[5]);
+        if constexpr (PSQ) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) xq[C::PS0 + q * C::PSP + m] = part[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                const double ps = part[m] + dpp_f64<0xB1>(part[m]);
+                if ((q & 1) == 0) xq[2 * m + (q >> 1)] = ps;
             }
         }
     }

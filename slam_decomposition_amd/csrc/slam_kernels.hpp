@@ -148,8 +148,11 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MinimizeArgs<
 // it finishes, so lanes stay busy although items need very different iteration counts.
 // All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
+#ifndef SLAM_K1_WAVES
+#define SLAM_K1_WAVES 2
+#endif
 template <int K, int GC>
-__global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args) {
+__global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 : 1))) minimize_kernel(MinimizeArgs<K> args) {
     using C = Cfg<K, psq_layout<K, GC>()>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -424,8 +427,7 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             pgt = fma(p[a], gt[a], pgt);
             yy = fma(ya, ya, yy);
         }
-        pgt = quad_sum(pgt);
-        yy = quad_sum(yy);
+        quad_sum2(pgt, yy);
         const double sg = am * pgt;
         const double sy = am * (pgt - gp);
         const double ss = (am * am) * pp;

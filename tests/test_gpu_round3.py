@@ -40,7 +40,12 @@ def test_launcher_with_one_rccl_rank_reproduces_the_plain_line():
     assert plain["comm"] == "LocalComm" and plain["rccl_world"] is None
     assert rccl["comm"] == "RcclComm" and rccl["rccl_world"] == 1 and rccl["n_gpus"] == 1
     assert len(rccl["rank_devices"]) == 1 and "gfx950" in rccl["rank_devices"][0]
-    assert plain["roofline"]["evals_per_span"] == rccl["roofline"]["evals_per_span"]
+    # k = 1: no sqrt(iSWAP)-class Haar target, nothing is pre-empted -> the evaluation count is a property of the work;
+    # at k = 2, 3 the evaluations of restarts a sibling pre-empts depend on timing (the RESULTS do not: ordered early exit)
+    ea, eb = plain["roofline"]["evals_per_span"], rccl["roofline"]["evals_per_span"]
+    assert ea["1"] == eb["1"] and abs(ea["2"] / eb["2"] - 1) < 0.05
+    assert plain["roofline"]["items_per_span"] == rccl["roofline"]["items_per_span"]
+    assert plain["best_cycles_hist_rank0"] == rccl["best_cycles_hist_rank0"] and plain["worst_loss_rank0"] == rccl["worst_loss_rank0"]
     assert plain["solved_fraction"] == rccl["solved_fraction"] == 1.0
     assert plain["repetitions"] == 3 and plain["ms_per_step_min"] <= plain["ms_per_step"] <= plain["ms_per_step_max"]
     ratio = rccl["value"] / plain["value"]
