@@ -294,8 +294,16 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     ndev = _ffi.device_count()
     device = local_rank % max(1, ndev)
 
-    n_streams = n_streams_arg if n_streams_arg else (16 if small else 5)
-    n_streams = max(1, min(n_streams, steps))
+    # Small batches are not given a host thread + stream each any more (16 in flight in round 2): `group` consecutive
+    # steps -- windows of the same resident array, same basis and seed -- go to the library as ONE call, i.e. one
+    # device-side work queue per span over all their (target, restart) items, and come back as per-step slices.  With
+    # the ordered early exit every step's results are bit for bit those of its own call (tests/test_gpu_round2.py).
+    group = 1
+    if small and not (gname == "cgsweep") and not (main and args.span_rules):
+        group = args.group if (main and args.group) else 10
+    group = max(1, min(group, steps))
+    n_streams = n_streams_arg if n_streams_arg else (4 if small else 5)
+    n_streams = max(1, min(n_streams, (steps + group - 1) // group))
     ctxs = [_ffi.Context(device) for _ in range(n_streams)]
     dev_name, cus, _ = ctxs[0].device_info()
     table = gate_table(gname)
@@ -313,7 +321,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         else:
             c.sample_haar(seed0 if not sweep else TARGET_SEED0, n_resident)
     gate_seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
-    ipq = args.items_per_quad if (main and args.items_per_quad >= 0) else (3 if (small and n_streams > 1) else 0)
+    ipq = args.items_per_quad if (main and args.items_per_quad >= 0) else (3 if (small and group == 1 and n_streams > 1) else 0)
     flags = _ffi.FLAG_EARLY_EXIT | (0 if args.fast_exit else _ffi.FLAG_ORDERED)
     prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=flags, items_per_quad=ipq)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
@@ -369,9 +377,18 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     def run_steps(step_ids, results, first_step):
         # steps are dealt round-robin to n_streams host threads, each with its own context / HIP stream,
         # so the tail of one batch (a stage lasts as long as its slowest work item) overlaps the next batch
+        groups = [step_ids[i : i + group] for i in range(0, len(step_ids), group)]
+
         def worker(w):
-            for s in step_ids[w::n_streams]:
-                results[s] = one_step(s, ctxs[w])
+            for g in groups[w::n_streams]:
+                if len(g) == 1 or g != list(range(g[0], g[0] + len(g))):
+                    for s in g:
+                        results[s] = one_step(s, ctxs[w])
+                    continue
+                # one library call for the whole group of consecutive steps, results handed back per step
+                bl, _, bc = ctxs[w].decompose_range(g[0] * n_per_step, len(g) * n_per_step, 1, 3, gate_seqs, prm, threshold)
+                for i, s in enumerate(g):
+                    results[s] = (bl[i * n_per_step : (i + 1) * n_per_step], bc[i * n_per_step : (i + 1) * n_per_step])
 
         if n_streams == 1:
             worker(0)
@@ -389,8 +406,9 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
                 # device to device: each context's resident best_loss windows -> this rank's slice of the job vector
                 comm.raw.merge_begin(world * n_loc)
                 for w in range(n_streams):
-                    for s in step_ids[w::n_streams]:
-                        comm.raw.merge_add(ctxs[w], s * n_per_step, n_per_step, rank * n_loc + (s - first_step) * n_per_step)
+                    for g in groups[w::n_streams]:
+                        for s in g:
+                            comm.raw.merge_add(ctxs[w], s * n_per_step, n_per_step, rank * n_loc + (s - first_step) * n_per_step)
                 results["merged_solved"], _ = comm.raw.allreduce_min_merged(SUCCESS_LOSS)
             else:
                 merged = np.full(world * n_loc, np.inf)
@@ -512,7 +530,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         "n_streams": n_streams, "ipq": ipq, "dev_name": dev_name, "cus": cus, "elapsed": elapsed, "solved_all": solved_all,
         "cyc_hist": cyc_hist, "worst": worst, "per_basis": per_basis, "st": st, "achieved": achieved, "kernel_s": kernel_s,
         "rejected": rejected, "flops_accepted": flops_accepted, "flops_strict": flops_strict, "per_span": per_span,
-        "resident_merge": resident_merge, "rep_ms": rep_ms, "strong": strong,
+        "resident_merge": resident_merge, "rep_ms": rep_ms, "strong": strong, "group": group,
     }
 
 
@@ -529,6 +547,9 @@ def main():
     ap.add_argument("--streams", type=int, default=None,
                     help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 5 otherwise "
                          "(measured on cfg3: 3 -> 2.95e6, 4 -> 3.0e6, 5 -> 3.19e6, 6 -> 3.20e6 decompositions/s)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="small batches: consecutive steps handed to the library as one call = one device-side work queue per span "
+                         "(default 10 for cfg2-sized batches, 1 otherwise)")
     ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "-1")),
                     help="launch shaping (slam_opt_params.items_per_quad); 0 = library default (one item per quad, lowest "
                          "latency); default here: 3 for small batches with several in flight (+4.7 %% measured), else 0")
@@ -585,7 +606,8 @@ def main():
         fl2 = sum(s2["st"]["evals"][k] * f_eval(k) for k in (1, 2, 3))
         secondary = {"cfg2": {
             "workload": s2["desc"], "value": s2["solved_all"] / s2["elapsed"], "unit": "decompositions/s", "steps": 320, "warmup": 32,
-            "ms_per_step": 1e3 * s2["elapsed"] / 320, "batches_in_flight_per_gpu": s2["n_streams"], "items_per_quad": s2["ipq"],
+            "ms_per_step": 1e3 * s2["elapsed"] / 320, "batches_in_flight_per_gpu": s2["n_streams"], "steps_per_library_call": s2["group"],
+            "items_per_quad": s2["ipq"],
             "solved_fraction": s2["solved_all"] / (world * 320 * s2["n_per_step"]),
             "roofline_frac": fl2 / s2["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
         }}
@@ -635,6 +657,7 @@ def main():
                                      ("slam_allreduce_min: ncclAllReduce(min) of the resident best-loss windows, device to device (RCCL via C ABI)"
                                       if m["resident_merge"] else f"min-all-reduce of the best-loss vector ({type(comm).__name__})")),
                 "batches_in_flight_per_gpu": m["n_streams"],
+                "steps_per_library_call": m["group"],
                 "items_per_quad": m["ipq"],
                 "device": m["dev_name"],
                 "compute_units": m["cus"],

@@ -308,7 +308,9 @@ int slam_ctx_device(slam_ctx* ctx, int* device);
  * (sel[r] = -1: the constant offset[r]).  n_params is 1, 2 or 4 and the same for every gate of a template.
  *
  * Parameter vectors are in index order: P0 .. P{6(k+1)-1} as for fixed-gate templates, then the parameters of gate 1,
- * of gate 2, ...: n = 6 (k + 1) + n_params k.  Spans 1..SLAM_V2_MAX_SPAN.
+ * of gate 2, ...: n = 6 (k + 1) + n_params k.  Spans 1..3 for every n_params; span 4 for n_params <= 2 and span 5
+ * (the reference's default maximum_span_guess, basisv2.py:35) for n_params = 1 -- as long as the packed inverse Hessian of
+ * the n parameters fits one wavefront's registers (n <= 41); beyond that SLAM_ERR_UNSUPPORTED.
  *
  *   slam_v2_set_gates        the table of parametrised base gates (host side only; replaces nothing resident)
  *   slam_v2_eval_loss_grad   loss, gradient with respect to ALL n parameters (analytic, incl. the gate parameters) and
@@ -318,12 +320,15 @@ int slam_ctx_device(slam_ctx* ctx, int* device);
  *                            (BFGS metric, steps projected onto the box [bound_lo, bound_hi]; NULL bounds = none, which
  *                            is plain BFGS as in optimizer.py:255).  Start points: x0, or U[init_lo, init_hi) per
  *                            parameter from the Philox stream of params->seed (parameter_guess, basisv2.py:150-172:
- *                            the bound of a bounded parameter, else (-4 pi, 4 pi)).  Every restart runs to its end; the
- *                            stage result is the lowest-index restart below exit_loss, else the lowest loss -- the
- *                            restart the reference's sequential loop ends with (optimizer.py:281-295).
+ *                            the bound of a bounded parameter, else (-4 pi, 4 pi)).  The stage result is the
+ *                            lowest-index restart below exit_loss, else the lowest loss -- the restart the reference's
+ *                            sequential loop ends with (optimizer.py:281-295).  With SLAM_FLAG_EARLY_EXIT in
+ *                            params->flags a restart is not started once a LOWER-index restart of its target has
+ *                            ended below exit_loss (the loop's break); without it every restart runs to its end.
+ *                            Persistent wavefronts over a restart-major queue, as slam_minimize_stage.
  *                            Outputs as in slam_minimize_stage with rows of n parameters.
  */
-#define SLAM_V2_MAX_SPAN 3
+#define SLAM_V2_MAX_SPAN 5 /* spans 4 and 5 for gates with few parameters: see slam_v2_minimize_stage */
 typedef struct slam_v2_gate {
     int32_t n_params;
     int32_t sel[4];

@@ -23,7 +23,7 @@ ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED 
 FLAG_EARLY_EXIT = 1
 FLAG_ORDERED = 2  # with EARLY_EXIT: the lowest-index successful restart wins (reference semantics, reproducible)
 MAX_MAXITER = 4000
-V2_MAX_SPAN = 3
+V2_MAX_SPAN = 5
 OP_SUM, OP_MAX, OP_MIN = 0, 2, 3
 COMM_ID_BYTES = 128
 COST_BASIC, COST_SQUARE = 0, 1

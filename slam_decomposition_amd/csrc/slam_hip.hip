@@ -101,6 +101,7 @@ struct slam_ctx {
     DevBuf stage_loss, stage_x, stage_restart;
     // decompose results
     DevBuf best_loss, best_x, best_cycles, span_loss;
+    DevBuf v2_hmem;              // inverse Hessians of the long parametrised-gate templates (slam_v2.hpp: v2_h_in_memory)
     DevBuf v2_maps, v2_bounds;   // slam_v2_*: staged gate maps [SLAM_MAX_SPAN_EVAL], (init_lo, init_hi, bound_lo, bound_hi)[n]
     std::vector<V2GateMap> v2_gates_host;
     int v2_qn = 0;
@@ -127,7 +128,7 @@ struct slam_ctx {
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &item_acc, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
+                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -436,8 +437,9 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
         r.best_cycles = c->best_cycles.as<int32_t>();
         r.span_loss = c->span_loss.as<double>();
     }
-    if (loop && n_upper <= kEpilogueMaxTargets) {
-        // small batch: reduction, bookkeeping, compaction and the next stage's inputs in one launch
+    if (loop) {
+        // reduction, bookkeeping, compaction and the next stage's inputs in ONE launch: a single workgroup for small
+        // batches (ordered compaction without atomics), a grid of 256-thread workgroups beyond
         EpilogueArgs e{};
         e.r = r;
         e.has_next = loop->has_next ? 1 : 0;
@@ -448,18 +450,15 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
         e.stage_targets = c->stage_targets.as<double>();
         e.solved = c->solved.as<int32_t>();
         if (n_upper <= 2048) hipLaunchKernelGGL(stage_epilogue_kernel<256>, dim3(1), dim3(256), 0, c->stream, e);
-        else hipLaunchKernelGGL(stage_epilogue_kernel<1024>, dim3(1), dim3(1024), 0, c->stream, e);
+        else if (n_upper <= kEpilogueMaxTargets) hipLaunchKernelGGL(stage_epilogue_kernel<1024>, dim3(1), dim3(1024), 0, c->stream, e);
+        else hipLaunchKernelGGL(stage_epilogue_grid_kernel, dim3((unsigned)((n_upper + 255) / 256)), dim3(256), 0, c->stream, e);
         HIP_TRY(hipGetLastError());
         return SLAM_OK;
     }
+    // single-stage call: per-target reduction only
     const int rb = 256;
     hipLaunchKernelGGL(reduce_merge_kernel, dim3((unsigned)((n_upper + rb - 1) / rb)), dim3(rb), 0, c->stream, r);
     HIP_TRY(hipGetLastError());
-    if (loop && loop->has_next) {
-        hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, c->stream, d_active, ctl,
-                           c->best_loss.as<double>(), loop->threshold, loop->active_out, stage_ctl(c, k + 1));
-        HIP_TRY(hipGetLastError());
-    }
     return SLAM_OK;
 }
 
@@ -613,11 +612,9 @@ int decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     DevBuf* cur = &c->active;
     DevBuf* nxt = &c->active2;
     const int32_t* gs = gate_seqs;
-    const bool small = N <= kEpilogueMaxTargets;
     for (int k = k_min; k <= k_max; ++k) {
-        // the first stage's inputs come from init_results_kernel, a small batch's later ones from the
-        // previous stage's epilogue
-        SpanLoopStep step{success_threshold, k == k_min || small, k < k_max, success_threshold, nxt->as<int32_t>()};
+        // the first stage's inputs come from init_results_kernel, the later ones from the previous stage's epilogue
+        SpanLoopStep step{success_threshold, true, k < k_max, success_threshold, nxt->as<int32_t>()};
         rc = enqueue_stage(c, k, gs, d_active, N, nullptr, prm, &step);
         if (rc) return rc;
         gs += k;
@@ -1174,6 +1171,7 @@ int v2_launch_eval(slam_ctx* c, const V2GateMap* d_maps, const double* d_x, cons
 }
 
 struct V2Stage {
+    double exit_loss;
     const V2GateMap* d_maps;
     const int32_t* d_active;
     int32_t n_active;
@@ -1186,6 +1184,9 @@ template <int K, int QN>
 int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
     const size_t lds = v2_lds_bytes<K, QN>();
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN>), kWave, lds));
+    if (per_cu < 1) per_cu = 1;
     constexpr int n = CfgV2<K, QN>::N;
     MinimizeV2Args<K, QN> a{};
     a.targets = c->targets.as<double>();
@@ -1202,10 +1203,13 @@ int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
     a.stop_loss = sgt.prm->stop_loss;
     a.gtol_far = sgt.prm->gtol_far;
     a.far_loss = sgt.prm->far_loss;
+    a.exit_loss = sgt.exit_loss;
+    a.flags = sgt.prm->flags & (SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED);
     a.seed = sgt.prm->seed;
     a.target_base = sgt.prm->target_base;
     a.cost_kind = c->cost_kind;
     a.maps = sgt.d_maps;
+    a.solved = c->solved.as<int32_t>();
     a.item_loss = c->item_loss.as<double>();
     a.item_x = c->item_x.as<double>();
     a.item_iters = c->item_iters.as<int32_t>();
@@ -1213,12 +1217,24 @@ int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
     a.item_evals = c->item_evals.as<int32_t>();
     a.item_acc = c->item_acc.as<int32_t>();
     a.ctl = stage_ctl(c, K);
+    // persistent wavefronts: never more than can be resident; every quad pulls items from the stage's queue
     const int64_t M = (int64_t)sgt.n_active * sgt.prm->restarts;
-    hipLaunchKernelGGL((minimize_v2_kernel<K, QN>), dim3((unsigned)((M + kQuadsPerWave - 1) / kQuadsPerWave)), dim3(kWave), lds, c->stream, a);
+    int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
+    const int64_t cap = (int64_t)per_cu * c->compute_units;
+    if (blocks > cap) blocks = cap;
+    if constexpr (v2_h_in_memory<K, QN>()) {
+        HIP_TRY(c->v2_hmem.reserve((size_t)blocks * v2_h_floats_per_wave<K, QN>() * sizeof(float)));
+        a.hmem = c->v2_hmem.as<float>();
+    }
+    HIP_TRY(hipEventRecord(c->ev_a[K], c->stream));
+    hipLaunchKernelGGL((minimize_v2_kernel<K, QN>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_b[K], c->stream));
     return SLAM_OK;
 }
 
+// spans 1..3 with 1, 2 or 4 parameters per gate; spans 4 and 5 (the reference's default maximum_span_guess = 5,
+// basisv2.py:35) where the packed inverse Hessian still fits one wavefront's 512 registers: n <= 41 parameters
 #define SLAM_V2_DISPATCH(FN, ...)                                                                             \
     do {                                                                                                      \
         const int key = k * 10 + c->v2_qn;                                                                    \
@@ -1232,8 +1248,11 @@ int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
             case 31: rc = FN<3, 1>(__VA_ARGS__); break;                                                       \
             case 32: rc = FN<3, 2>(__VA_ARGS__); break;                                                       \
             case 34: rc = FN<3, 4>(__VA_ARGS__); break;                                                       \
-            default: rc = fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates: spans 1..%d with 1, 2 or 4 parameters per gate (got span %d, %d)", \
-                               SLAM_V2_MAX_SPAN, k, c->v2_qn);                                                \
+            case 41: rc = FN<4, 1>(__VA_ARGS__); break;                                                       \
+            case 42: rc = FN<4, 2>(__VA_ARGS__); break;                                                       \
+            case 51: rc = FN<5, 1>(__VA_ARGS__); break;                                                       \
+            default: rc = fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates: spans 1..3 with 1, 2 or 4 parameters per gate, span 4 with 1 or 2, span 5 with 1 (got span %d, %d)", \
+                               k, c->v2_qn);                                                                  \
         }                                                                                                     \
     } while (0)
 
@@ -1333,7 +1352,9 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), c->stream));
     hipLaunchKernelGGL(set_n_active_kernel, dim3(1), dim3(1), 0, c->stream, stage_ctl(c, k), (int32_t)n_active);
     HIP_TRY(hipGetLastError());
-    V2Stage sgt{d_maps, d_active, (int32_t)n_active, d_x0, c->v2_bounds.as<double>(), prm};
+    HIP_TRY(c->solved.reserve((size_t)n_active * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(c->solved.p, 0, (size_t)n_active * sizeof(int32_t), c->stream));
+    V2Stage sgt{exit_loss, d_maps, d_active, (int32_t)n_active, d_x0, c->v2_bounds.as<double>(), prm};
     SLAM_V2_DISPATCH(v2_launch_minimize, c, sgt);
     if (rc) return rc;
     ReduceArgs r{};
@@ -1343,7 +1364,7 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     r.item_acc = c->item_acc.as<int32_t>();
     r.item_status = c->item_status.as<int32_t>();
     r.exit_loss = exit_loss;
-    r.ordered = 1;  // every restart ran to its end: the winner is the one the reference's sequential loop breaks at
+    r.ordered = 1;  // the winner is the restart the reference's sequential loop breaks at (restarts below it always run to their end)
     r.ctl = stage_ctl(c, k);
     r.restarts = prm->restarts;
     r.n = n;
@@ -1359,8 +1380,9 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     if (item_iters) HIP_TRY(hipMemcpyAsync(item_iters, c->item_iters.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (item_status) HIP_TRY(hipMemcpyAsync(item_status, c->item_status.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (item_evals) HIP_TRY(hipMemcpyAsync(item_evals, c->item_evals.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_ctl, c->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return SLAM_OK;
+    return collect_stats(c, k, k, c->h_ctl, prm->restarts);
 }
 
 }  // namespace

@@ -782,15 +782,6 @@ __device__ __forceinline__ int32_t compact_block(const int32_t* active_in, int64
     return offs[NT];
 }
 
-__global__ void __launch_bounds__(1024) compact_active_kernel(const int32_t* active_in, const StageCtl* ctl,
-                                                             const double* best_loss, double threshold,
-                                                             int32_t* active_out, StageCtl* next) {
-    __shared__ int32_t counts[1024];
-    __shared__ int32_t offs[1025];
-    const int32_t total = compact_block<1024>(active_in, ctl->n_active, best_loss, threshold, active_out, counts, offs);
-    if (threadIdx.x == 0) next->n_active = total;
-}
-
 // Small batches (at most kEpilogueMaxTargets targets): everything between two optimizer launches in ONE
 // single-workgroup kernel -- reduction over restarts, span-loop bookkeeping, compaction of the unsolved
 // targets and the next stage's inputs (gathered targets, cleared early-exit flags).  With several batches in
@@ -828,6 +819,52 @@ __global__ void __launch_bounds__(NT) stage_epilogue_kernel(EpilogueArgs a) {
         reinterpret_cast<double2*>(a.stage_targets)[i] =
             reinterpret_cast<const double2*>(a.targets)[(int64_t)a.active_out[i >> 4] * 16 + (i & 15)];
     for (int64_t i = tid; i < total; i += NT) a.solved[i] = 0;
+}
+
+// Big batches: the same single launch per stage, as a GRID of 256-thread workgroups -- reduction over restarts + span-loop
+// bookkeeping per target, then the compaction of the targets that still need a longer template by one atomicAdd per
+// workgroup on the next stage's target count (ordered inside a workgroup, workgroups in arrival order: the active list's
+// order only decides which wavefront works on what, never a result), then the next stage's inputs for the kept targets.
+// Round 2 ran three kernels here (reduce_merge, a single-workgroup compact_active, stage_prepare): with several batches in
+// flight each of them waited its turn behind other batches' persistent wavefronts.
+__global__ void __launch_bounds__(256) stage_epilogue_grid_kernel(EpilogueArgs a) {
+    __shared__ int32_t wave_counts[4];
+    __shared__ int32_t s_base;
+    const int tid = threadIdx.x;
+    const int64_t n_in = a.r.ctl->n_active;
+    const int64_t s = (int64_t)blockIdx.x * 256 + tid;
+    EvalCounts ev;
+    bool keep = false;
+    int32_t t = -1;
+    if (s < n_in) {
+        reduce_merge_slot(a.r, s, ev);
+        t = a.r.active ? a.r.active[s] : (int32_t)s;
+        keep = a.has_next && !(a.r.best_loss[t] < a.threshold);  // optimizer.py:301: break when best < threshold
+    }
+    publish_eval_counts(a.r.ctl, ev, tid);
+    if (!a.has_next) return;
+    const unsigned long long m = __ballot(keep);
+    const int lane = tid & 63, w = tid >> 6;
+    if (lane == 0) wave_counts[w] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        const int32_t tot = wave_counts[0] + wave_counts[1] + wave_counts[2] + wave_counts[3];
+        s_base = tot ? atomicAdd(&a.next->n_active, tot) : 0;
+    }
+    __syncthreads();
+    if (keep) {
+        int32_t o = s_base + __popcll(m & ((1ull << lane) - 1ull));
+        for (int i = 0; i < w; ++i) o += wave_counts[i];
+        a.active_out[o] = t;
+        a.solved[o] = 0;
+        const double2* src = reinterpret_cast<const double2*>(a.targets) + (int64_t)t * 16;
+        double2* dst = reinterpret_cast<double2*>(a.stage_targets) + (int64_t)o * 16;
+        double2 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = src[e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[e] = v[e];
+    }
 }
 
 }  // namespace slamdev

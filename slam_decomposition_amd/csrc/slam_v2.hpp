@@ -14,11 +14,19 @@
 // Parameter vector of a span-k template, index order: P0 .. P{6(k+1)-1} (as in slam_device.hpp), then the QN
 // parameters of gate 1, of gate 2, ...  n = 6 (k + 1) + QN k.
 //
-// Kernels: the same work decomposition as the fixed-gate path (a quad of lanes per (target, seed) item, lane c owns
-// column c of the running product and row c of the backward vector, fp32 packed inverse Hessian in registers), in a
-// plain form -- static item assignment, both layer inputs and outputs stored, per-item gate entries read from LDS --
-// plus the gradient with respect to the gate angles and a projected quasi-Newton step for the box bounds.  This path is
-// a first correct one, measured but not tuned like minimize_kernel<K>.
+// Kernels (round 3: off the first-correct path): the work decomposition of the fixed-gate path -- a quad of lanes per
+// (target, seed) item, lane c owns column c of the running product and row c of the backward vector, fp32 packed inverse
+// Hessian in registers -- with
+//   * the LEAN layout: only the layer outputs h_j go through LDS, the layer inputs f_j = G_j h_{j-1} are recomputed;
+//   * table-driven sincos with all lookups requested ahead (no out-of-line call in the loop, no scratch);
+//   * gradient partials pair-summed by one DPP stage and added by their owner lane (was: a full quad reduction each);
+//   * persistent wavefronts: a quad that finishes pulls the next (target, restart) item from the stage's RESTART-MAJOR
+//     queue; a restart whose target already has a successful lower-index restart is dropped when pulled (the reference's
+//     sequential break, optimizer.py:287-295);
+//   * ONE symmetric mat-vec per iteration: H g is carried from the previous iteration, so H y = H g' - H g needs H g' only
+//     (the projected direction is no longer -H g, which is why the first version formed both);
+//   * the one-off scaling of the initial inverse Hessian as the scalar hs1 (metric H + hs1 I), as in minimize_kernel.
+// plus the gradient with respect to the gate angles and the projected quasi-Newton step for the box bounds.
 #pragma once
 #include "slam_device.hpp"
 #include "slam_kernels.hpp"
@@ -39,18 +47,19 @@ struct CfgV2 {
     static constexpr int NQ = QN * K;
     static constexpr int N = NP + NQ;
     static constexpr int NA = (N + 3) / 4;
-    // per-quad LDS area (doubles): trig of the P parameters [2 NP], gate trig [8 K], trial Q values [NQ -> padded],
-    // summed 1Q partials [NP], summed raw-angle partials [4 K]; the fp32 mat-vec / update exchanges of slam_device.hpp
-    // (10 NA - 8 doubles) reuse the front of it between evaluations
+    static constexpr int NAP = (NP + 3) / 4;  // slots that can hold a 1Q parameter
+    // per-quad LDS area (doubles): trig of the P parameters [2 NP], gate trig [8 K], trial Q values [NQ -> even],
+    // pair sums of the 1Q partials [2 NP], pair sums of the raw-angle partials [8 K]; the fp32 mat-vec / update exchanges of
+    // slam_device.hpp (10 NA - 8 doubles) reuse the front of it between evaluations
     static constexpr int OFF_GTRIG = 2 * NP;
     static constexpr int OFF_QVAL = OFF_GTRIG + 8 * K;
     static constexpr int OFF_GP = OFF_QVAL + ((NQ + 1) / 2) * 2;
-    static constexpr int OFF_DQ = OFF_GP + NP;
-    static constexpr int XNEED0 = OFF_DQ + 4 * K;
+    static constexpr int OFF_DQ = OFF_GP + 2 * NP;
+    static constexpr int XNEED0 = OFF_DQ + 8 * K;
     static constexpr int XNEED = XNEED0 > 10 * NA - 8 ? XNEED0 : 10 * NA - 8;
     static constexpr int XSTRIDE = (XNEED - 8 + 15) / 16 * 16 + 8;
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
-    static constexpr int LDS_FH = 2 * K * 4 * kRow * 2;          // f_1..f_K and h_0..h_{K-1}: [vector][row][lane + pad] double2
+    static constexpr int LDS_FH = K * 4 * kRow * 2;              // h_0..h_{K-1}: [vector][row][lane + pad] double2
     static constexpr int LDS_BOUNDS = 2 * NA * 4;                // (lo, hi) per parameter, padded to 4 NA
     static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH + LDS_BOUNDS + kSincosLdsDoubles;
 };
@@ -97,14 +106,27 @@ __device__ __forceinline__ double cg_block_dot(double d, double er, double ei, d
     return (ulr * vlr - uli * vli) + (uhr * vhr - uhi * vhi);
 }
 
+// bit a set: slot a of lane q (parameter 4a + q) is a theta of a U gate (index < NP and divisible by 3)
+template <int K, int QN>
+__device__ __forceinline__ int theta_slot_bits_v2(int q) {
+    int bits = 0;
+#pragma unroll
+    for (int a = 0; a < CfgV2<K, QN>::NAP; ++a) {
+        const int i = 4 * a + q;
+        bits |= ((i < CfgV2<K, QN>::NP) && ((i - 3 * ((i * 43) >> 7)) == 0)) << a;  // i % 3 for i < 128
+    }
+    return bits;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // loss + gradient with respect to all n parameters for the quad's item
-//   xd     this lane's parameter slots (component 4a + q)
+//   xd     this lane's parameter slots (component 4a + q); |x| < 2e8 (table-driven sincos), checked by the host for explicit
+//          seeds and guaranteed by the optimizer for its own points (HUGE_ARGS = true: the evaluation entry point, any x)
 //   maps   gate maps of G_1..G_K (wave-uniform, global memory)
 // ---------------------------------------------------------------------------------------------------------------
-template <int K, int QN>
+template <int K, int QN, bool HUGE_ARGS>
 __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA], const double* tcol, const V2GateMap* maps, double* xq,
-                                             double2* fh, const double2* tbl, int q, int cost_kind, double& fout,
+                                             double2* fh, const double2* tbl, int q, int theta_bits, int cost_kind, double& fout,
                                              double (&gd)[CfgV2<K, QN>::NA], double (&Wr)[4], double (&Wi)[4]) {
     using C = CfgV2<K, QN>;
     double tre[4], tim[4];
@@ -117,43 +139,94 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
     // ---- 1. trig of the 1Q parameters (owner lanes); the Q values go to LDS for the gates' raw angles
     {
         double2* t2 = reinterpret_cast<double2*>(xq);
+        if constexpr (HUGE_ARGS) {
 #pragma unroll
-        for (int a = 0; a < C::NA; ++a) {
-            const int i = 4 * a + q;
-            if (i < C::NP) {
+            for (int a = 0; a < C::NAP; ++a) {
+                const int i = 4 * a + q;
                 const int i3 = i - 3 * ((i * 43) >> 7);
                 const double arg = (i3 == 0) ? 0.5 * xd[a] : xd[a];
                 double s, c;
                 sincos_any(arg, tbl, s, c);
-                t2[i] = make_double2(c, s);
-            } else if (i < C::N) {
-                xq[C::OFF_QVAL + (i - C::NP)] = xd[a];
+                if (i < C::NP) t2[i] = make_double2(c, s);
             }
+        } else {
+            // table lookups requested four slots ahead of their polynomials (all of them at once would keep 7 registers
+            // per slot alive: too many next to the long templates' vectors)
+            constexpr int kChunk = 4;
+            const SincosLits L = sincos_lits_device();
+#pragma unroll
+            for (int a0 = 0; a0 < C::NAP; a0 += kChunk) {
+                double rr[kChunk];
+                int kk[kChunk];
+                double2 tt[kChunk];
+#pragma unroll
+                for (int c = 0; c < kChunk; ++c) {
+                    const int a = a0 + c;
+                    if (a < C::NAP) {
+                        const double arg = __builtin_amdgcn_ldexp(xd[a], __builtin_amdgcn_sbfe(theta_bits, a, 1));
+                        sincos_tbl_lookup<true>(arg, tbl, L, rr[c], kk[c], tt[c]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < kChunk; ++c) {
+                    const int a = a0 + c;
+                    if (a < C::NAP) {
+                        double sn, cs;
+                        sincos_tbl_finish<true>(rr[c], kk[c], tt[c], L, sn, cs);
+                        if (4 * a + q < C::NP) t2[4 * a + q] = make_double2(cs, sn);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int a = C::NP / 4; a < C::NA; ++a) {
+            const int i = 4 * a + q;
+            if (i >= C::NP && i < C::N) xq[C::OFF_QVAL + (i - C::NP)] = xd[a];
         }
     }
     lds_fence();
     // lane r of the quad evaluates raw angle r of every gate:  raw = scale q[sel] + offset
+    {
+        double raw[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const int sel = maps[j].sel[q];
-        const double qv = xq[C::OFF_QVAL + QN * j + (sel < 0 ? 0 : sel)];
-        const double raw = (sel < 0) ? maps[j].offset[q] : fma(maps[j].scale[q], qv, maps[j].offset[q]);
-        double s, c;
-        sincos_any(raw, tbl, s, c);
-        reinterpret_cast<double2*>(xq + C::OFF_GTRIG)[4 * j + q] = make_double2(c, s);
+        for (int j = 0; j < K; ++j) {
+            const int sel = maps[j].sel[q];
+            const double qv = xq[C::OFF_QVAL + QN * j + (sel < 0 ? 0 : sel)];
+            raw[j] = (sel < 0) ? maps[j].offset[q] : fma(maps[j].scale[q], qv, maps[j].offset[q]);
+        }
+        if constexpr (HUGE_ARGS) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                double s, c;
+                sincos_any(raw[j], tbl, s, c);
+                reinterpret_cast<double2*>(xq + C::OFF_GTRIG)[4 * j + q] = make_double2(c, s);
+            }
+        } else {
+            double rr[K];
+            int kk[K];
+            double2 tt[K];
+            const SincosLits L = sincos_lits_device();
+#pragma unroll
+            for (int j = 0; j < K; ++j) sincos_tbl_lookup<true>(raw[j], tbl, L, rr[j], kk[j], tt[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                double s, c;
+                sincos_tbl_finish<true>(rr[j], kk[j], tt[j], L, s, c);
+                reinterpret_cast<double2*>(xq + C::OFF_GTRIG)[4 * j + q] = make_double2(c, s);
+            }
+        }
     }
     lds_fence();
 
-    // ---- 2. forward
+    // ---- 2. forward; only the layer outputs h_j (j < K) are stored
     double Fr[4], Fi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Fr[r] = (r == q) ? 1.0 : 0.0; Fi[r] = 0.0; }
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
-        if (j > 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) fh[((2 * (j - 1)) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);  // f_j
-        }
         const U3t B = load_u3(xq, 6 * j);
         const U3t A = load_u3(xq, 6 * j + 3);
         u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
@@ -162,9 +235,11 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
         if (j < K) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fh[((2 * j + 1) * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);  // h_j
+            for (int r = 0; r < 4; ++r) fh[(j * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);  // h_j
             cg_col(load_cg(xq + C::OFF_GTRIG + 8 * j), Fr, Fi);
         }
+        // long templates: keep the scheduler from pulling every layer's table reads to the front (12 registers per layer)
+        if constexpr (K >= 3) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Wr[r] = Fr[r]; Wi[r] = Fi[r]; }
@@ -176,8 +251,7 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         pr = fma(tre[r], Fr[r], fma(tim[r], Fi[r], pr));
         pi = fma(tre[r], Fi[r], fma(-tim[r], Fr[r], pi));
     }
-    pr = quad_sum(pr);
-    pi = quad_sum(pi);
+    quad_sum2(pr, pi);
     const double at2 = pr * pr + pi * pi;
     const double rat = (at2 > 1e-300) ? fast_rsqrt(at2) : 0.0;
     const double at = at2 * rat;
@@ -193,18 +267,16 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         Ur[r] = zr * tre[r] + zi * tim[r];
         Ui[r] = zi * tre[r] - zr * tim[r];
     }
-    double Hr[4], Hi[4];
+    double Hr[4], Hi[4];  // h_j: the current layer's output
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Hr[r] = Fr[r]; Hi[r] = Fi[r]; }
+    // pair sums (lanes q, q ^ 1) of a partial; the even lane of the pair parks it at [2 i + (q >> 1)] for the owner to add
+    auto park = [&](int off, int i, double v) {
+        const double ps = v + dpp_f64<0xB1>(v);
+        if ((q & 1) == 0) xq[off + 2 * i + (q >> 1)] = ps;
+    };
 #pragma unroll
     for (int j = K; j >= 0; --j) {
-        if (j < K) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((2 * j + 1) * 4 + r) * kRow];
-                Hr[r] = v.x; Hi[r] = v.y;
-            }
-        }
         const U3t B = load_u3(xq, 6 * j);
         const U3t A = load_u3(xq, 6 * j + 3);
         double part[6];
@@ -218,13 +290,18 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         double tB01r, tB01i, tB23r, tB23i;
         u3_row_t(B, Ur[0], Ui[0], Ur[1], Ui[1], tB01r, tB01i);
         u3_row_t(B, Ur[2], Ui[2], Ur[3], Ui[3], tB23r, tB23i);
-        double fr[4], fi[4];
+        // h_{j-1} (the gate's input; also the next iteration's layer output) and f_j = G_j h_{j-1}
+        double Pr[4], Pi[4], fr[4], fi[4];
+        CGt g;
         if (j > 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((2 * (j - 1)) * 4 + r) * kRow];
+                const double2 v = fh[((j - 1) * 4 + r) * kRow];
+                Pr[r] = v.x; Pi[r] = v.y;
                 fr[r] = v.x; fi[r] = v.y;
             }
+            g = load_cg(xq + C::OFF_GTRIG + 8 * (j - 1));
+            cg_col(g, fr, fi);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fr[r] = (r == q) ? 1.0 : 0.0; fi[r] = 0.0; }
@@ -240,33 +317,23 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         part[3] = dtheta_pair(A, Ur[0], Ui[0], Ur[2], Ui[2], fr[0], fi[0], fr[2], fi[2]) +
                   dtheta_pair(A, Ur[1], Ui[1], Ur[3], Ui[3], fr[1], fi[1], fr[3], fi[3]);
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            const double sum = quad_sum(part[m]);
-            if (q == 0) xq[C::OFF_GP + 6 * j + m] = sum;
-        }
+        for (int m = 0; m < 6; ++m) park(C::OFF_GP, 6 * j + m, part[m]);
         if (j > 0) {
             // gate j: d loss / d raw angle = Re( u~ (dG / d angle) h_{j-1} ), summed over the four columns
-            double hr[4], hi[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double2 v = fh[((2 * (j - 1) + 1) * 4 + r) * kRow];
-                hr[r] = v.x; hi[r] = v.y;
-            }
-            const CGt g = load_cg(xq + C::OFF_GTRIG + 8 * (j - 1));
             double d[4];
             // a:     d = -sin a,  e = -i e^{i phi_c} cos a = cos a (sin phi_c, -cos phi_c)
-            d[0] = cg_block_dot(-g.sa, g.ca * g.spc, -g.ca * g.cpc, Ur[1], Ui[1], Ur[2], Ui[2], hr[1], hi[1], hr[2], hi[2]);
+            d[0] = cg_block_dot(-g.sa, g.ca * g.spc, -g.ca * g.cpc, Ur[1], Ui[1], Ur[2], Ui[2], Pr[1], Pi[1], Pr[2], Pi[2]);
             // phi_c: d = 0,       e = i w,  w = sin a (sin phi_c, -cos phi_c)  ->  i w = sin a (cos phi_c, sin phi_c)
-            d[1] = cg_block_dot(0.0, g.sa * g.cpc, g.sa * g.spc, Ur[1], Ui[1], Ur[2], Ui[2], hr[1], hi[1], hr[2], hi[2]);
-            d[2] = cg_block_dot(-g.sb, g.cb * g.spg, -g.cb * g.cpg, Ur[0], Ui[0], Ur[3], Ui[3], hr[0], hi[0], hr[3], hi[3]);
-            d[3] = cg_block_dot(0.0, g.sb * g.cpg, g.sb * g.spg, Ur[0], Ui[0], Ur[3], Ui[3], hr[0], hi[0], hr[3], hi[3]);
+            d[1] = cg_block_dot(0.0, g.sa * g.cpc, g.sa * g.spc, Ur[1], Ui[1], Ur[2], Ui[2], Pr[1], Pi[1], Pr[2], Pi[2]);
+            d[2] = cg_block_dot(-g.sb, g.cb * g.spg, -g.cb * g.cpg, Ur[0], Ui[0], Ur[3], Ui[3], Pr[0], Pi[0], Pr[3], Pi[3]);
+            d[3] = cg_block_dot(0.0, g.sb * g.cpg, g.sb * g.spg, Ur[0], Ui[0], Ur[3], Ui[3], Pr[0], Pi[0], Pr[3], Pi[3]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double sum = quad_sum(d[r]);
-                if (q == 0) xq[C::OFF_DQ + 4 * (j - 1) + r] = sum;
-            }
+            for (int r = 0; r < 4; ++r) park(C::OFF_DQ, 4 * (j - 1) + r, d[r]);
             cg_row(g, Ur, Ui);  // u <- u~ G_j
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Hr[r] = Pr[r]; Hi[r] = Pi[r]; }
         }
+        if constexpr (K >= 3) __builtin_amdgcn_sched_barrier(0);
     }
     // ---- 5. gradient in the owners' slots
     lds_fence();
@@ -275,12 +342,15 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         const int i = 4 * a + q;
         double v = 0.0;
         if (i < C::NP) {
-            v = xq[C::OFF_GP + i];
+            const double2 ps = *reinterpret_cast<const double2*>(xq + C::OFF_GP + 2 * i);
+            v = ps.x + ps.y;
         } else if (i < C::N) {
             const int j = (i - C::NP) / QN, m = (i - C::NP) - QN * j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (maps[j].sel[r] == m) v = fma(maps[j].scale[r], xq[C::OFF_DQ + 4 * j + r], v);
+            for (int r = 0; r < 4; ++r) {
+                const double2 ps = *reinterpret_cast<const double2*>(xq + C::OFF_DQ + 2 * (4 * j + r));
+                if (maps[j].sel[r] == m) v = fma(maps[j].scale[r], ps.x + ps.y, v);
+            }
         }
         gd[a] = v;
     }
@@ -320,7 +390,7 @@ __global__ void __launch_bounds__(kWave, 1) eval_v2_kernel(EvalV2Args<K, QN> arg
         xd[a] = (i < C::N) ? args.x[it * C::N + i] : 0.0;
     }
     double f, Wr[4], Wi[4];
-    eval_quad_v2<K, QN>(xd, tcol, args.maps, lds + quad * C::XSTRIDE, fh, tbl, q, args.cost_kind, f, gd, Wr, Wi);
+    eval_quad_v2<K, QN, true>(xd, tcol, args.maps, lds + quad * C::XSTRIDE, fh, tbl, q, 0, args.cost_kind, f, gd, Wr, Wi);
     if (live) {
         if (q == 0) args.loss[item] = f;
         if (args.unitary) {
@@ -341,7 +411,133 @@ __global__ void __launch_bounds__(kWave, 1) eval_v2_kernel(EvalV2Args<K, QN> arg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// projected quasi-Newton minimisation: one item per quad, static assignment (the V2 callers run a few targets)
+// Where the packed fp32 inverse Hessian of a wavefront's 16 items lives.  Up to 32 parameters (NA <= 8) it fits the
+// registers next to the evaluation's working set (HMat, slam_device.hpp).  Beyond -- spans 4 and 5, span 3 with four
+// parameters per gate: up to n = 56, 105 blocks = 420 registers per lane -- it cannot, and LDS has no room either (a block is
+// 1 KiB per wavefront): those instantiations keep it in a per-wavefront slice of device memory, block b as one float4 per
+// lane at [b][lane] (every access a fully coalesced 1 KiB line), read once by the mat-vec and read + written once by the
+// rank-2 update per iteration.  Same arithmetic, same block order: the two variants give identical results.
+// ---------------------------------------------------------------------------------------------------------------
+template <int K, int QN>
+__host__ __device__ constexpr bool v2_h_in_memory() { return CfgV2<K, QN>::NA > 8; }
+template <int K, int QN>
+__host__ __device__ constexpr int v2_h_floats_per_wave() { return CfgV2<K, QN>::NA * (CfgV2<K, QN>::NA + 1) / 2 * 4 * kWave; }
+
+template <int NA>
+__device__ __forceinline__ void hm_set_identity_where(f32x4* Hm, int q, bool where) {
+    if (!where) return;
+#pragma unroll 1
+    for (int b = 0; b < NA; ++b)
+#pragma unroll 1
+        for (int a = 0; a <= b; ++a) {
+            f32x4 v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (a == b) v = f32x4{q == 0 ? 1.0f : 0.0f, q == 1 ? 1.0f : 0.0f, q == 2 ? 1.0f : 0.0f, q == 3 ? 1.0f : 0.0f};
+            Hm[blk(a, b) * kWave] = v;
+        }
+}
+// out = H v, the loops of h_matvec with the blocks loaded from memory (column block b's NA.. loads are independent of the
+// LDS broadcasts: they are in flight together)
+template <int NA>
+__device__ __forceinline__ void hm_matvec(const f32x4* Hm, const double (&vd)[NA], float* xq32, int q, double (&out)[NA]) {
+    float v32[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        v32[a] = (float)vd[a];
+        xq32[4 * a + q] = v32[a];
+    }
+    lds_fence();
+    float* xt = xq32 + 4 * NA - 16;
+    f32x2 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[a] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int b = 0; b < NA; ++b) {
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(xq32 + 4 * b);
+        const f32x2 vb0 = f32x2{vb.x, vb.y}, vb1 = f32x2{vb.z, vb.w};
+        f32x2 t0 = f32x2{0.0f, 0.0f}, t1 = f32x2{0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a <= b; ++a) {
+            const f32x4 h = Hm[blk(a, b) * kWave];
+            const f32x2 h0 = f32x2{h.x, h.y}, h1 = f32x2{h.z, h.w};
+            acc[a] = __builtin_elementwise_fma(h0, vb0, acc[a]);
+            acc[a] = __builtin_elementwise_fma(h1, vb1, acc[a]);
+            if (a < b) {
+                const f32x2 va = f32x2{v32[a], v32[a]};
+                t0 = __builtin_elementwise_fma(h0, va, t0);
+                t1 = __builtin_elementwise_fma(h1, va, t1);
+            }
+        }
+        if (b >= 1) {
+            xt[(4 * b + 0) * 4 + q] = t0.x;
+            xt[(4 * b + 1) * 4 + q] = t0.y;
+            xt[(4 * b + 2) * 4 + q] = t1.x;
+            xt[(4 * b + 3) * 4 + q] = t1.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one column block's loads in flight at a time: hoisted, all NBLK cost 4 registers each
+    }
+    lds_fence();
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        float o = acc[a].x + acc[a].y;
+        if (a >= 1) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xt + (4 * a + q) * 4);
+            o += (t.x + t.y) + (t.z + t.w);
+        }
+        out[a] = (double)o;
+    }
+    lds_fence();
+}
+// H += s w^T + v s^T
+template <int NA>
+__device__ __forceinline__ void hm_update(f32x4* Hm, const float (&s32)[NA], const float (&w32)[NA], const float (&v32)[NA], float* xq32, int q) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        xq32[4 * a + q] = w32[a];
+        xq32[4 * NA + 4 * a + q] = s32[a];
+    }
+    lds_fence();
+#pragma unroll
+    for (int b = 0; b < NA; ++b) {
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(xq32 + 4 * b);
+        const f32x4 sb = *reinterpret_cast<const f32x4*>(xq32 + 4 * NA + 4 * b);
+        const f32x2 wb0 = f32x2{wb.x, wb.y}, wb1 = f32x2{wb.z, wb.w};
+        const f32x2 sb0 = f32x2{sb.x, sb.y}, sb1 = f32x2{sb.z, sb.w};
+#pragma unroll
+        for (int a = 0; a <= b; ++a) {
+            const f32x2 sa = f32x2{s32[a], s32[a]};
+            const f32x2 va = f32x2{v32[a], v32[a]};
+            const f32x4 h = Hm[blk(a, b) * kWave];
+            f32x2 h0 = f32x2{h.x, h.y}, h1 = f32x2{h.z, h.w};
+            h0 = __builtin_elementwise_fma(va, sb0, h0);
+            h1 = __builtin_elementwise_fma(va, sb1, h1);
+            h0 = __builtin_elementwise_fma(sa, wb0, h0);
+            h1 = __builtin_elementwise_fma(sa, wb1, h1);
+            Hm[blk(a, b) * kWave] = f32x4{h0.x, h0.y, h1.x, h1.y};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_fence();
+}
+
+template <int NA, bool MEM>
+struct HStore {
+    HMat<NA> regs;
+    __device__ __forceinline__ void bind(float*, int) {}
+    __device__ __forceinline__ void set_identity_where(int q, bool w) { h_set_identity_where<NA>(regs, q, w); }
+    __device__ __forceinline__ void matvec(const double (&v)[NA], float* xq32, int q, double (&out)[NA]) { h_matvec<NA>(regs, v, xq32, q, out); }
+    __device__ __forceinline__ void update(const float (&s)[NA], const float (&w)[NA], const float (&v)[NA], float* xq32, int q) { h_update<NA>(regs, s, w, v, xq32, q); }
+};
+template <int NA>
+struct HStore<NA, true> {
+    f32x4* mem;  // this lane's first block; block b at mem[b * 64]
+    __device__ __forceinline__ void bind(float* wave_slice, int lane) { mem = reinterpret_cast<f32x4*>(wave_slice) + lane; }
+    __device__ __forceinline__ void set_identity_where(int q, bool w) { hm_set_identity_where<NA>(mem, q, w); }
+    __device__ __forceinline__ void matvec(const double (&v)[NA], float* xq32, int q, double (&out)[NA]) { hm_matvec<NA>(mem, v, xq32, q, out); }
+    __device__ __forceinline__ void update(const float (&s)[NA], const float (&w)[NA], const float (&v)[NA], float* xq32, int q) { hm_update<NA>(mem, s, w, v, xq32, q); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// projected quasi-Newton minimisation, persistent wavefronts over the stage's restart-major work queue
 // ---------------------------------------------------------------------------------------------------------------
 template <int K, int QN>
 struct MinimizeV2Args {
@@ -356,17 +552,21 @@ struct MinimizeV2Args {
     const double* bound_hi;
     int32_t maxiter;
     double gtol, stop_loss, gtol_far, far_loss;
+    double exit_loss;          // SLAM_FLAG_EARLY_EXIT: a finished restart below this stops the target's LATER restarts
+    uint32_t flags;
     uint64_t seed;
     int64_t target_base;
     int32_t cost_kind;
     const V2GateMap* maps;
+    int32_t* solved;           // [n_active], zeroed before launch: restarts - r of the lowest-index successful restart r, 0 = none
     double* item_loss;         // [M] outputs, [slot][restart]
     double* item_x;            // [M][n]
     int32_t* item_iters;
     int32_t* item_status;
     int32_t* item_evals;
     int32_t* item_acc;
-    StageCtl* ctl;
+    StageCtl* ctl;             // work queue head, round counter
+    float* hmem;               // v2_h_in_memory<K, QN>(): [gridDim.x][v2_h_floats_per_wave] inverse Hessians; else unused
 };
 
 template <int K, int QN>
@@ -384,53 +584,103 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
     for (int i = lane; i < 4 * NA; i += kWave)
         bnd[i] = (i < C::N) ? make_double2(args.bound_lo[i], args.bound_hi[i]) : make_double2(0.0, 0.0);
     lds_fence();
-    const int64_t n_items = (int64_t)args.n_active * args.restarts;
-    const int64_t item = (int64_t)blockIdx.x * kQuadsPerWave + quad;
-    bool live = item < n_items;
-    const int64_t it0 = live ? item : 0;
-    const int slot = (int)(it0 / args.restarts);
-    const int restart = (int)(it0 - (int64_t)slot * args.restarts);
-    const int tgt = args.active ? args.active[slot] : slot;
-    const double* tcol = args.targets + (int64_t)tgt * 32 + q * 2;
+    const int theta_bits = theta_slot_bits_v2<K, QN>(q);
+    const unsigned n_act = (unsigned)args.n_active;
+    const unsigned n_items = n_act * (unsigned)args.restarts;
+    const bool early = (args.flags & 1u) != 0;
 
-    double x[NA], g[NA], p[NA], lo[NA], hi[NA];
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-        const int i = 4 * a + q;
-        const double2 b = bnd[i];
-        lo[a] = b.x; hi[a] = b.y;
-        double xv = 0.0;
-        if (i < C::N) {
-            if (args.x0) {
-                xv = args.x0[it0 * C::N + i];
-            } else {
-                // same Philox stream layout as the fixed-gate path, span tagged with 0x100 (V2), mapped onto the
-                // parameter's start range
-                const double u = x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), (uint32_t)restart, (uint32_t)(K | 0x100), (uint32_t)i) *
-                                 (1.0 / 6.283185307179586476925286766559);
-                xv = fma(u, args.init_hi[i] - args.init_lo[i], args.init_lo[i]);
-            }
-            xv = fmin(fmax(xv, lo[a]), hi[a]);
-        }
-        x[a] = xv; g[a] = 0.0; p[a] = 0.0;
-    }
-    HMat<NA> H;
-    h_set_identity_where<NA>(H, q, true);
-    bool fresh = true, scaled = false;
+    // ---- per-quad state
+    bool live = false, fresh = false, scaled = false;
+    unsigned item = 0;
+    int slot = 0, restart = 0;
     int nev = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
-    double f = 0.0, alpha = 0.0, gs = 0.0, gp = 0.0, gnorm = 0.0, grow = 1.0;
+    double f = 0.0, alpha = 0.0, gp = 0.0, gnorm = 0.0, grow = 1.0, hs1 = 0.0;
+    const double* tcol = args.targets + q * 2;
+    double x[NA], g[NA], p[NA], hg[NA];  // hg = (H + hs1 I) g: the unprojected direction, negated
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { x[a] = 0.0; g[a] = 0.0; p[a] = 0.0; hg[a] = 0.0; }
+    HStore<NA, v2_h_in_memory<K, QN>()> H;
+    H.bind(args.hmem + (size_t)blockIdx.x * v2_h_floats_per_wave<K, QN>(), lane);
+    H.set_identity_where(q, true);
+    bool exhausted = false;  // wave-uniform
+    unsigned rounds = 0;
 
-    while (__any(live)) {
-        // ---- trial point: projection of x + alpha p onto the box; s = actual step
-        double xt[NA], sv[NA], gt[NA];
+    while (true) {
+        // ---- 1. idle quads pull the next queue positions (restart-major: position = restart * n_active + slot)
+        bool taken = false;
+        while (!exhausted && __any(!live)) {
+            const unsigned long long idle = __ballot(!live && q == 0);
+            const int n_idle = __popcll(idle);
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&args.ctl->work_counter, (unsigned)n_idle);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= n_items) { exhausted = true; break; }
+            const int qrank = __popcll(idle & ((1ull << (lane & ~3)) - 1ull));
+            const unsigned pos = base + (unsigned)qrank;
+            if (!live && pos < n_items) {
+                const unsigned rs = pos / n_act, sl = pos - rs * n_act;
+                const unsigned oidx = sl * (unsigned)args.restarts + rs;
+                bool skip = false;
+                if (early) {
+                    // ordered early exit: dropped iff a LOWER-index restart of the target has already succeeded
+                    const int fl = __hip_atomic_load(&args.solved[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    skip = fl > args.restarts - (int)rs;
+                }
+                if (skip) {
+                    if (q == 0) {
+                        args.item_loss[oidx] = INFINITY;
+                        args.item_iters[oidx] = 0;
+                        args.item_status[oidx] = ST_PREEMPTED;
+                        args.item_evals[oidx] = 0;
+                        args.item_acc[oidx] = 0;
+                    }
+                } else {
+                    item = oidx;
+                    slot = (int)sl;
+                    restart = (int)rs;
+                    const int tgt = args.active ? args.active[sl] : (int)sl;
+                    tcol = args.targets + (int64_t)tgt * 32 + q * 2;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const int i = 4 * a + q;
+                        double xv = 0.0;
+                        if (i < C::N) {
+                            if (args.x0) {
+                                xv = args.x0[(int64_t)oidx * C::N + i];
+                            } else {
+                                // same Philox stream layout as the fixed-gate path, span tagged with 0x100 (V2), mapped onto the
+                                // parameter's start range
+                                const double u = x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), (uint32_t)rs, (uint32_t)(K | 0x100), (uint32_t)i) *
+                                                 (1.0 / 6.283185307179586476925286766559);
+                                xv = fma(u, args.init_hi[i] - args.init_lo[i], args.init_lo[i]);
+                            }
+                            const double2 b = bnd[i];
+                            xv = fmin(fmax(xv, b.x), b.y);
+                        }
+                        x[a] = xv; g[a] = 0.0; p[a] = 0.0; hg[a] = 0.0;
+                    }
+                    alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0; hs1 = 0.0;
+                    nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
+                    scaled = false; fresh = true; live = true; taken = true;
+                }
+            }
+        }
+        if (__any(taken)) H.set_identity_where(q, taken);
+        if (!__any(live)) break;
+        ++rounds;
+
+        // ---- 2. trial point: projection of x + alpha p onto the box; s = actual step
+        double xt[NA], gt[NA];
+        double gs = 0.0;  // slope of the linear model along the projected step s = xt - x
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            xt[a] = fmin(fmax(fma(alpha, p[a], x[a]), lo[a]), hi[a]);
-            sv[a] = xt[a] - x[a];
+            const double2 b = bnd[4 * a + q];
+            xt[a] = fmin(fmax(fma(alpha, p[a], x[a]), b.x), b.y);
+            gs = fma(g[a], xt[a] - x[a], gs);
         }
-        gs = qdot<NA>(g, sv);  // slope of the linear model along the projected step
+        gs = quad_sum(gs);
         double ft, Wr[4], Wi[4];
-        eval_quad_v2<K, QN>(xt, tcol, args.maps, xq, fh, tbl, q, args.cost_kind, ft, gt, Wr, Wi);
+        eval_quad_v2<K, QN, false>(xt, tcol, args.maps, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
         const bool active = live;
         const bool finite = isfinite(ft);
         // The quasi-Newton algebra lives in the subspace of the variables that can move: the gradient component of a
@@ -439,7 +689,8 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
         // d alpha of a fixed gate is large -- enters y = g' - g with s = 0 there and poisons H.)
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const bool blocked = (xt[a] <= lo[a] && gt[a] > 0.0) || (xt[a] >= hi[a] && gt[a] < 0.0);
+            const double2 b = bnd[4 * a + q];
+            const bool blocked = (xt[a] <= b.x && gt[a] > 0.0) || (xt[a] >= b.y && gt[a] < 0.0);
             gt[a] = (finite && !blocked) ? gt[a] : 0.0;
         }
         const bool armijo = finite && (ft <= f + kArmijoC1 * gs);
@@ -447,65 +698,56 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
         const bool step = acc && !fresh;
         nev += active ? (acc ? 0x100001 : 1) : 0;
 
-        // ---- quasi-Newton update with s = the projected step (zero for quads that do not step)
+        // ---- 3. quasi-Newton update with s = the projected step (zero for quads that do not step).  ONE mat-vec:
+        //         q = H g'; with hg = (H + hs1 I) g carried over, u = (H + hs1 I) y = q + hs1 g' - fac hg
         double qv[NA];
-        h_matvec<NA>(H, gt, xq32, q, qv);
-        double sy = 0.0, yy = 0.0, ss = 0.0;
+        H.matvec(gt, xq32, q, qv);
+        double sy = 0.0, yy = 0.0, ss = 0.0, sg = 0.0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const double sa = step ? sv[a] : 0.0;
+            const double sa = step ? xt[a] - x[a] : 0.0;
             const double ya = gt[a] - g[a];
             sy = fma(sa, ya, sy);
             yy = fma(ya, ya, yy);
             ss = fma(sa, sa, ss);
+            sg = fma(sa, gt[a], sg);
         }
-        sy = quad_sum(sy); yy = quad_sum(yy); ss = quad_sum(ss);
+        quad_sum2(sy, yy);
+        quad_sum2(ss, sg);
         const bool curv = step && sy > 0.0 && (sy * sy > (kCurvEps * kCurvEps) * (ss * yy));
         const bool too_short = sy < (1.0 - kWolfeC2) * (-gs);
         const bool first = curv && !scaled;
         scaled = scaled || curv;
+        // first update of an item: the initial inverse Hessian (the identity then) scaled by s.y / y.y, as the scalar hs1
         const double fac = first ? (sy * fast_rcp(yy)) : 1.0;
-        {
-            const float f32 = (float)fac;
-            const f32x2 f2 = f32x2{f32, f32};
-#pragma unroll
-            for (int b = 0; b < NA * (NA + 1) / 2; ++b) {
-                H.h[b][0] *= f2;
-                H.h[b][1] *= f2;
-            }
-        }
-        // u = H y = H g' - H g.  With projected directions p is not -H g any more, so H g is formed explicitly:
-        // hg = H g  (second mat-vec; this path is not the tuned one)
-        double hg[NA];
-        h_matvec<NA>(H, g, xq32, q, hg);
+        hs1 = first ? fac - 1.0 : hs1;
         double yu = 0.0;
-        double ua[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            qv[a] *= fac;  // H was scaled after q = H g' was formed; hg already uses the scaled H
-            ua[a] = qv[a] - hg[a];
-            yu = fma(gt[a] - g[a], ua[a], yu);
+            qv[a] = fma(hs1, gt[a], qv[a]);              // (H + hs1 I) g'
+            const double ua = fma(-fac, hg[a], qv[a]);   // (H + hs1 I) y
+            yu = fma(gt[a] - g[a], ua, yu);
         }
         yu = quad_sum(yu);
         const double rho = curv ? fast_rcp(sy) : 0.0;
         const double cf = rho * (1.0 + rho * yu);
-        double wg = 0.0, sg = 0.0;
+        double wg = 0.0;
         {
             float s32[NA], w32[NA], v32[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const double sa = step ? sv[a] : 0.0;
-                const double wa = cf * sa - rho * ua[a];
-                const double va = -rho * ua[a];
+                const double sa = step ? xt[a] - x[a] : 0.0;
+                const double ua = fma(-fac, hg[a], qv[a]);
+                const double wa = cf * sa - rho * ua;  // rho = cf = 0 unless curv: w = v = 0, H unchanged
+                const double va = -rho * ua;
                 s32[a] = (float)sa; w32[a] = (float)wa; v32[a] = (float)va;
                 wg = fma(wa, gt[a], wg);
-                sg = fma(sa, gt[a], sg);
             }
-            h_update<NA>(H, s32, w32, v32, xq32, q);
+            H.update(s32, w32, v32, xq32, q);
         }
         wg = quad_sum(wg);
-        sg = quad_sum(sg);
 
+        // ---- 4. per-quad state machine
         bool done = false;
         if (acc) {
             nstall = (step && (f - ft) <= kStallDf) ? nstall + 1 : 0;
@@ -515,22 +757,25 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
             grow = (step && too_short) ? fmin(grow * kGrowFactor, kGrowMax) : 1.0;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const double sa = step ? sv[a] : 0.0;
-                const double va = -rho * ua[a];
+                const double sa = step ? xt[a] - x[a] : 0.0;
+                const double ua = fma(-fac, hg[a], qv[a]);
+                const double va = -rho * ua;
                 x[a] = xt[a];
                 g[a] = gt[a];
-                // new direction -H' g' = -(q + s (w.g') + v (s.g')), then projected: no component may point out of the box
-                double pn = -(qv[a] + sa * wg + va * sg);
-                const bool at_lo = x[a] <= lo[a], at_hi = x[a] >= hi[a];
-                if ((at_lo && pn < 0.0) || (at_hi && pn > 0.0)) pn = 0.0;
-                p[a] = pn;
+                // H' g' = (H + hs1 I) g' + s (w.g') + v (s.g'); the direction is its negative, projected: no component may
+                // point out of the box
+                const double hn = qv[a] + sa * wg + va * sg;
+                hg[a] = hn;
+                const double2 b = bnd[4 * a + q];
+                const bool out = (x[a] <= b.x && hn > 0.0) || (x[a] >= b.y && hn < 0.0);
+                p[a] = out ? 0.0 : -hn;
             }
         } else if (active) {
             if (fresh) {
                 f = ft; status = ST_NONFINITE; done = true;
             } else {
                 const double denom = 2.0 * (ft - f - gs);
-                const double anew = (finite && denom > 0.0 && isfinite(denom)) ? (-gs * alpha / denom) : 0.5 * alpha;
+                const double anew = (finite && denom > 0.0 && isfinite(denom)) ? (-gs * alpha * fast_rcp(denom)) : 0.5 * alpha;
                 alpha = fmin(fmax(anew, 0.1 * alpha), 0.5 * alpha);
                 grow = 1.0;
                 ++nback;
@@ -541,9 +786,9 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
             double m = 0.0;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const bool at_lo = x[a] <= lo[a], at_hi = x[a] >= hi[a];
-                const bool blocked = (at_lo && g[a] > 0.0) || (at_hi && g[a] < 0.0);
-                m = fmax(m, blocked ? 0.0 : fabs(g[a]));
+                const double2 b = bnd[4 * a + q];
+                const bool blocked = (x[a] <= b.x && g[a] > 0.0) || (x[a] >= b.y && g[a] < 0.0);
+                m = max_abs(m, blocked ? 0.0 : g[a]);
             }
             gnorm = quad_max(m);
         }
@@ -560,14 +805,16 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
         fresh = false;
         const bool reset = active && !done && !(gp < 0.0);
         if (__any(reset)) {
-            h_set_identity_where<NA>(H, q, reset);
+            H.set_identity_where(q, reset);
+            hs1 = reset ? 0.0 : hs1;
             double gg2 = 0.0;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const bool at_lo = x[a] <= lo[a], at_hi = x[a] >= hi[a];
+                const double2 b = bnd[4 * a + q];
                 double pn = -g[a];
-                if ((at_lo && pn < 0.0) || (at_hi && pn > 0.0)) pn = 0.0;
+                if ((x[a] <= b.x && pn < 0.0) || (x[a] >= b.y && pn > 0.0)) pn = 0.0;
                 p[a] = reset ? pn : p[a];
+                hg[a] = reset ? g[a] : hg[a];
                 gg2 = fma(g[a], pn, gg2);
             }
             gg2 = quad_sum(gg2);
@@ -576,6 +823,8 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
             if (reset && !(gg2 < 0.0)) { status = ST_CONVERGED; done = true; }
         }
         if (active && done) {
+            if (early && f < args.exit_loss && q == 0)
+                __hip_atomic_fetch_max(&args.solved[slot], args.restarts - restart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q == 0) {
                 args.item_loss[item] = f;
                 args.item_iters[item] = iters;
@@ -586,7 +835,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const int i = 4 * a + q;
-                if (i < C::N) args.item_x[item * C::N + i] = x[a];
+                if (i < C::N) args.item_x[(int64_t)item * C::N + i] = x[a];
             }
             live = false;
             alpha = 0.0;
@@ -594,6 +843,7 @@ __global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K,
             for (int a = 0; a < NA; ++a) p[a] = 0.0;
         }
     }
+    if (lane == 0 && rounds) atomicAdd(&args.ctl->rounds, (unsigned long long)rounds);
 }
 
 }  // namespace slamdev

@@ -299,7 +299,12 @@ class TemplateOptimizer:
                 break
             basis.build(k)
             _, idx, init_lo, init_hi, blo, bhi = basis.device_layout(k)
-            out = ctx.v2_minimize_stage(basis.gate_sequence(k), prm, self.success_threshold, init_lo, init_hi, blo, bhi, active=act)
+            try:
+                out = ctx.v2_minimize_stage(basis.gate_sequence(k), prm, self.success_threshold, init_lo, init_hi, blo, bhi, active=act)
+            except _ffi.SlamHipError as exc:
+                if exc.code == -3:  # SLAM_ERR_UNSUPPORTED: span x parameters-per-gate beyond what the device kernels hold
+                    raise NotImplementedError(str(exc)) from exc
+                raise
             for j, t in enumerate(act):
                 if best_k[t] < 0 or out["best_loss"][j] < best[t]:  # optimizer.py:281-284
                     best[t], best_k[t] = out["best_loss"][j], k

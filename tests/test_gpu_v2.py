@@ -201,10 +201,10 @@ def test_v2_stage_restart_order_and_errors(hip_ctx):
         want = below[0] if len(below) else int(np.argmin(out["item_loss"][t]))
         assert out["best_restart"][t] == want and out["best_loss"][t] == out["item_loss"][t, want]
     again = hip_ctx.v2_minimize_stage([0, 0], prm, 1e-10, ilo, ihi, blo, bhi)
-    assert np.array_equal(again["best_x"], out["best_x"])  # static assignment: bitwise reproducible
+    assert np.array_equal(again["best_x"], out["best_x"])  # no early-exit flag: every restart runs to its end, bitwise reproducible
     with pytest.raises(_ffi.SlamHipError) as e:
-        z = np.zeros(6 * 5 + 2 * 4)
-        hip_ctx.v2_minimize_stage([0] * 4, prm, 1e-10, z, z + 1, None, None)  # span 4
+        z = np.zeros(6 * 6 + 2 * 5)
+        hip_ctx.v2_minimize_stage([0] * 5, prm, 1e-10, z, z + 1, None, None)  # span 5 with two parameters per gate: n = 46 > 41
     assert e.value.code == -3
     with pytest.raises(_ffi.SlamHipError):
         hip_ctx.v2_minimize_stage([0, 3], prm, 1e-10, ilo, ihi, blo, bhi)  # gate index outside the table
@@ -216,3 +216,83 @@ def test_v2_stage_restart_order_and_errors(hip_ctx):
         b2 = CircuitTemplateV2()
         b2.build(1)
         b2.add_bound("Q7", 1, 0)
+
+
+@pytest.mark.parametrize("name,k", [("riswap", 4), ("riswap", 5), ("cg_gc_gg", 4)])
+def test_v2_long_spans_loss_and_gradient_match_the_oracle(hip_ctx, name, k):
+    """Spans 4 and 5 (the reference's default ``maximum_span_guess=5``, basisv2.py:35): loss and the full gradient against the
+    oracle, as for the short spans."""
+    fn = GATE_FNS[name]
+    qn, sel, scale, off = gate_map(fn)
+    basis = CircuitTemplateV2(base_gates=[fn])
+    basis.build(k)
+    rng = np.random.default_rng(7 * k + qn)
+    M = 19
+    targets = o.haar_batch(3, seed0=77)
+    X = rng.uniform(-4 * np.pi, 4 * np.pi, (M, basis.n_params))
+    tof = rng.integers(0, 3, M).astype(np.int32)
+    hip_ctx.set_targets(targets)
+    hip_ctx.v2_set_gates(basis._gate_maps)
+    loss, grad, W = hip_ctx.v2_eval(basis.gate_sequence(), basis.to_device_vector(X), tof, want_unitary=True)
+    _, idx, *_ = basis.device_layout(k)
+    fns = [lambda *q: fn(*q).to_matrix()] * k
+    for m in range(M):
+        assert np.max(np.abs(W[m] - v.template_eval(X[m], fns, qn, k))) < 1e-12
+        f, g = v.loss_and_grad(X[m], [(sel, scale, off)] * k, qn, k, targets[tof[m]])
+        assert abs(loss[m] - f) < 1e-12 and np.max(np.abs(grad[m][idx] - g)) < 1e-12
+
+
+def test_default_template_v2_runs_its_default_spanning_range(hip_ctx):
+    """``CircuitTemplateV2()`` with its defaults (RiSwapGate class, maximum_span_guess = 5, basisv2.py:31-35) through the
+    optimizer: alpha bounded to [0, 1/2] makes the template need several gates (sqrt(iSWAP) fragments), so spans 4 and 5 are
+    entered; converged losses against SciPy L-BFGS-B on the oracle from the same start points at the long spans."""
+    basis = CircuitTemplateV2()
+    assert list(basis.spanning_range) == [1, 2, 3, 4, 5]
+    # one target that three sqrt(iSWAP)-bounded gates reach, optimised at the LONG spans explicitly: the minimiser at k = 4, 5
+    T = o.haar_batch(2, seed0=505)
+    hip_ctx.set_targets(T)
+    hip_ctx.v2_set_gates(basis._gate_maps)
+    hip_ctx.set_cost(_ffi.COST_BASIC)
+    R = 4
+    for k in (4, 5):
+        basis.build(k)
+        for name in basis.parameter_names():
+            if "Q" in name:
+                basis.add_bound(name, max=0.5, min=0.0)
+        n_dev, idx, ilo, ihi, blo, bhi = basis.device_layout(k)
+        prm = _ffi.OptParams(restarts=R, seed=11 + k, flags=0)
+        rng = np.random.default_rng(k)
+        x0 = rng.uniform(ilo, ihi, (2, R, n_dev))
+        out = hip_ctx.v2_minimize_stage(basis.gate_sequence(k), prm, 1e-10, ilo, ihi, blo, bhi, x0=x0)
+        assert np.all(out["best_loss"] < 1e-10)                      # three or more sqrt(iSWAP)-class gates reach any target
+        qs = out["best_x"][:, 6 * (k + 1):]
+        assert np.all(qs >= 0.0) and np.all(qs <= 0.5)               # bounds respected exactly
+        gm = gate_map(RiSwapGate)[1:]
+        bounds = [(-np.inf, np.inf)] * (6 * (k + 1)) + [(0.0, 0.5)] * k
+        for t in range(2):
+            best = min(opt.minimize(lambda xx: v.loss_and_grad(xx, [gm] * k, 1, k, T[t]), np.clip(x0[t, r], [b[0] for b in bounds], [b[1] for b in bounds]),
+                                    jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": 2500, "ftol": 1e-15, "gtol": 1e-10}).fun for r in range(R))
+            assert abs(out["best_loss"][t] - best) < 1e-6
+    # and the whole default loop through the API
+    basis = CircuitTemplateV2()
+    td = TemplateOptimizer(basis=basis, objective=BasicCost(), training_restarts=4, seed=5).approximate_target_U(T[0])
+    assert td.success_label == 1 and 1 <= td.cycles <= 5
+
+
+def test_v2_early_exit_drops_later_restarts_only(hip_ctx):
+    """SLAM_FLAG_EARLY_EXIT on the V2 stage: a restart is not started once a LOWER-index restart of its target has ended
+    below exit_loss; the stage result is the one of the run without the flag (the reference's sequential break)."""
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate])
+    basis.build(2)
+    NT = 4096  # x 8 restarts = twice the quads the chip holds at one wavefront per SIMD: later restarts are pulled after earlier ones end
+    hip_ctx.set_targets(o.haar_batch(NT, seed0=901))
+    hip_ctx.v2_set_gates(basis._gate_maps)
+    _, idx, ilo, ihi, blo, bhi = basis.device_layout(2)
+    full = hip_ctx.v2_minimize_stage([0, 0], _ffi.OptParams(restarts=8, seed=2, flags=0), 1e-10, ilo, ihi, blo, bhi)
+    fast = hip_ctx.v2_minimize_stage([0, 0], _ffi.OptParams(restarts=8, seed=2, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED), 1e-10, ilo, ihi, blo, bhi)
+    assert np.array_equal(full["best_loss"], fast["best_loss"]) and np.array_equal(full["best_restart"], fast["best_restart"])
+    assert np.array_equal(full["best_x"], fast["best_x"])
+    skipped = fast["item_status"] == _ffi.ST_PREEMPTED
+    assert skipped.any()
+    for t in range(NT):
+        assert not skipped[t, : fast["best_restart"][t] + 1].any()  # nothing at or below the winner is ever dropped

@@ -71,7 +71,7 @@ def test_bounds_follow_the_reference_semantics():
         with pytest.raises(NotImplementedError):
             CircuitTemplateV2(**kw)
     with pytest.raises(NotImplementedError):
-        b.build(4)
+        b.build(6)  # spans above SLAM_V2_MAX_SPAN = 5
     with pytest.raises(ValueError):
         b.build(0)
     b.build(2)
