@@ -49,6 +49,13 @@ def f_eval(k: int) -> int:
     return 3036 * k + 1247
 
 
+def f_eval_v2(k: int) -> int:
+    """Parametrised-gate templates (CircuitTemplateV2): F_eval(k) plus, per gate, the four raw-angle derivatives
+    Re(u (dG/d angle) h) over the four columns -- 4 angles x 4 columns x (2x2 complex block times a 2-vector: 22 flop, real part
+    of the 2-term complex dot: 8 flop) = 480 flop -- and the gate's two block entries from its trig values (8 flop): 488 k."""
+    return f_eval(k) + 488 * k
+
+
 def f_forward(k: int) -> int:
     """Forward chain + loss only (what a rejected line-search trial is worth)."""
     return 1080 * k + 251
@@ -269,6 +276,74 @@ def make_comm(rank: int, world: int, local_rank: int):
     return comm
 
 
+def run_v2(rank: int, local_rank: int, steps: int = 10, warmup: int = 2, n_targets: int = 4096, restarts: int = 16):
+    """secondary.v2: CircuitTemplateV2(base_gates=[RiSwapGate]) -- every gate instance with its own free alpha -- SquareCost,
+    spans 1..3, `n_targets` Haar targets x `restarts` restarts per step.  The span loop is the one TemplateOptimizer runs for a
+    V2 template (optimizer.py:_run_batch_v2): one slam_v2_minimize_stage per template size over the targets still unsolved,
+    results of every stage on the host."""
+    from slam_decomposition_amd import _ffi
+    from slam_decomposition_amd.basisv2 import CircuitTemplateV2
+    from slam_decomposition_amd.gates import RiSwapGate
+
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=3)
+    ctx = _ffi.Context(local_rank % max(1, _ffi.device_count()))
+    total = steps + warmup
+    ctx.sample_haar(TARGET_SEED0 + 7_000_000 + rank * total * n_targets, total * n_targets)
+    ctx.v2_set_gates(basis._gate_maps)
+    ctx.set_cost(_ffi.COST_SQUARE)
+    prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+    threshold = 1e-10
+    layouts = {}
+    for k in (1, 2, 3):
+        basis.build(k)
+        layouts[k] = basis.device_layout(k)
+
+    def one_step(s: int):
+        best = np.full(n_targets, np.inf)
+        cyc = np.full(n_targets, -1, dtype=np.int32)
+        for k in (1, 2, 3):
+            act = (s * n_targets + np.nonzero(~(best < threshold))[0]).astype(np.int32)
+            if len(act) == 0:
+                break
+            _, _, ilo, ihi, blo, bhi = layouts[k]
+            out = ctx.v2_minimize_stage([0] * k, prm, threshold, ilo, ihi, blo, bhi, active=act, want_items=False)
+            loc = act - s * n_targets
+            better = (cyc[loc] < 0) | (out["best_loss"] < best[loc])  # optimizer.py:281-284
+            best[loc[better]] = out["best_loss"][better]
+            cyc[loc[better]] = k
+        return best, cyc
+
+    for s in range(warmup):
+        one_step(s)
+    ctx.synchronize()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    solved = 0
+    hist = np.zeros(4, dtype=np.int64)
+    for s in range(warmup, total):
+        best, cyc = one_step(s)
+        solved += int((best < SUCCESS_LOSS).sum())
+        hist += np.bincount(np.clip(cyc, 0, 3), minlength=4)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.close()
+    flops = sum(st["evals"][k] * f_eval_v2(k) for k in (1, 2, 3))
+    kms = sum(st["kernel_ms_span"][k] for k in (1, 2, 3))
+    return {
+        "workload": f"CircuitTemplateV2(base_gates=[RiSwapGate]) (one free alpha per gate), SquareCost, spans 1..3, {n_targets} Haar targets x {restarts} restarts per step",
+        "value": solved / elapsed, "unit": "decompositions/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "solved_fraction": solved / (steps * n_targets), "best_cycles_hist": {str(k): int(hist[k]) for k in range(4)},
+        "roofline_frac": flops / elapsed / 1e12 / PEAK_FP64_VALU_TFLOPS,
+        "roofline_frac_kernels": flops / (kms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if kms > 0 else None,
+        "kernel_ms_per_step": {str(k): st["kernel_ms_span"][k] / steps for k in (1, 2, 3)},
+        "evals_per_span": {str(k): st["evals"][k] for k in (1, 2, 3)},
+        "flops_per_eval": {str(k): f_eval_v2(k) for k in (1, 2, 3)},
+        "flops_note": "F_eval(k) + 488 k: the fixed-gate count plus the gate-angle derivatives (bench.py:f_eval_v2)",
+        "span_loop": "host-driven: one slam_v2_minimize_stage per template size, results of every stage fetched",
+    }
+
+
 # ------------------------------------------------------------------------------------------------
 def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool):
     """Run `warmup` untimed + `steps` timed steps of one workload; returns the dict of measurements."""
@@ -335,12 +410,44 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         from slam_decomposition_amd import span_rules
         from slam_decomposition_amd.weyl import c1c2c3 as host_c1c2c3
 
-        if len(table) != 1:
-            raise SystemExit("--span-rules needs a single basis gate (cfg2, cfg3)")
+        # one basis gate of a class with closed-form coverage regions: the exact template size per target; anything else
+        # (the mixed sequence of cfg4, the conversion-gain sweep of cfg5): a sound lower bound, the span loop starts there
         gate_coords = host_c1c2c3(table[0])
-        span_rules.family_of(gate_coords)
+        span_exact = False
+        if len(table) == 1 and not sweep:
+            try:
+                span_rules.family_of(gate_coords)
+                span_exact = True
+            except NotImplementedError:
+                pass
 
     def one_step(s: int, c):
+        if span_rules_mode and not span_exact:
+            first = 0 if sweep else s * n_per_step
+            if sweep:
+                g = sweep_gate(basis_of(s))
+                c.set_gates(np.stack([g]))
+                seq_coords = [host_c1c2c3(g)] * 3
+            else:
+                seq_coords = [host_c1c2c3(table[i]) for i in gate_seqs[2]]
+            # slack: the metric accepts loss < 1e-8, i.e. targets up to ~1e-4 in coordinates outside the exact reachable set
+            lb = span_rules.span_lower_bound(c.targets_c1c2c3(first, n_per_step), seq_coords, 3, slack=5e-4)
+            ran = False
+            for k in np.unique(lb):
+                k = int(k)
+                if k < 1 or k > 3:
+                    continue  # local targets need no gate; targets beyond the whole template's reach are not optimised
+                c.decompose_list(first + np.nonzero(lb == k)[0], k, 3, gate_seqs[k - 1 :], prm, threshold, k_layout=3)
+                ran = True
+            if ran:
+                best_loss, best_x, best_cycles = c.fetch_results_range(3, first, n_per_step)
+            else:  # a gate too weak for any target of the batch: nothing to optimise
+                best_loss, best_cycles = np.full(n_per_step, np.inf), np.full(n_per_step, -1, dtype=np.int32)
+            best_loss[lb < 1] = 0.0
+            best_cycles[lb < 1] = 0
+            best_loss[lb > 3] = np.inf  # not optimised in this step (their resident slots may hold an earlier step's result)
+            best_cycles[lb > 3] = -1
+            return best_loss, best_cycles
         if span_rules_mode:
             first = s * n_per_step
             spans = span_rules.minimal_span(c.targets_c1c2c3(first, n_per_step), gate_coords)
@@ -567,7 +674,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets of the CPU baseline sample (default 4 x host cores)")
     ap.add_argument("--per-span-steps", type=int, default=3, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 / v2 measurements")
+    ap.add_argument("--v2-only", action="store_true", help="dev: run only the secondary.v2 measurement (CircuitTemplateV2) and print it")
     args = ap.parse_args()
 
     stub = os.environ.get("SLAM_BENCH_TEST_STUB")
@@ -582,6 +690,9 @@ def main():
         spec.loader.exec_module(mod)
         mod.install()
 
+    if args.v2_only:
+        print(json.dumps(run_v2(0, 0)), flush=True)
+        return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):
         # plain `python bench.py --gpus N`: become the launcher (no GPU call has happened in this process)
@@ -611,6 +722,8 @@ def main():
             "solved_fraction": s2["solved_all"] / (world * 320 * s2["n_per_step"]),
             "roofline_frac": fl2 / s2["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
         }}
+        if rank == 0 and not os.environ.get("SLAM_BENCH_TEST_STUB"):
+            secondary["v2"] = run_v2(rank, local_rank)
 
     rank_devices = gather_strings(comm, rank, world, f"{m['dev_name'].strip()} cu={m['cus']} dev={local_rank}")
     if rank == 0:
@@ -647,7 +760,8 @@ def main():
                 "targets_per_step_per_gpu": m["n_per_step"],
                 "restarts": m["restarts"],
                 "span_max": 3,
-                "span_selection": "analytic span rules (use_polytopes mode)" if args.span_rules else "brute force 1..3 (reference default)",
+                "span_selection": ("analytic span rules (use_polytopes mode; exact template size for a single known basis gate, else a lower bound "
+                                   "from which the brute-force loop starts)") if args.span_rules else "brute force 1..3 (reference default)",
                 "success_threshold": m["threshold"],
                 "restart_early_exit": "first restart to finish below stop_loss wins (timing-dependent)" if args.fast_exit
                 else "ordered: lowest-index successful restart wins (reference semantics, bitwise reproducible)",

@@ -512,7 +512,7 @@ class Context:
         return loss, grad, (w.view(np.complex128).reshape(M, 4, 4) if want_unitary else None)
 
     def v2_minimize_stage(self, gate_seq: Sequence[int], params: OptParams, exit_loss: float, init_lo, init_hi, bound_lo=None,
-                          bound_hi=None, active: Optional[np.ndarray] = None, x0: Optional[np.ndarray] = None) -> dict:
+                          bound_hi=None, active: Optional[np.ndarray] = None, x0: Optional[np.ndarray] = None, want_items: bool = True) -> dict:
         k = len(gate_seq)
         n = 6 * (k + 1) + self.v2_qn * k
         gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
@@ -537,10 +537,10 @@ class Context:
             "best_loss": np.empty(na, dtype=np.float64),
             "best_x": np.empty((na, n), dtype=np.float64),
             "best_restart": np.empty(na, dtype=np.int32),
-            "item_loss": np.empty((na, R), dtype=np.float64),
-            "item_iters": np.empty((na, R), dtype=np.int32),
-            "item_status": np.empty((na, R), dtype=np.int32),
-            "item_evals": np.empty((na, R), dtype=np.int32),
+            "item_loss": np.empty((na, R), dtype=np.float64) if want_items else None,
+            "item_iters": np.empty((na, R), dtype=np.int32) if want_items else None,
+            "item_status": np.empty((na, R), dtype=np.int32) if want_items else None,
+            "item_evals": np.empty((na, R), dtype=np.int32) if want_items else None,
         }
         _check(
             self._lib.slam_v2_minimize_stage(

@@ -57,14 +57,20 @@ class CircuitTemplate(VariationalTemplate):
         self.spanning_range = None if use_polytopes else range(1, maximum_span_guess + 1)
         self.maximum_span_guess = maximum_span_guess
         self.coverage = None
+        self._span_exact = False
         if use_polytopes:
-            # the reference needs monodromy's precomputed coverage sets; here: analytic rules (span_rules.py)
-            if len(self.base_gates) != 1:
-                raise NotImplementedError("use_polytopes: analytic span rules cover templates with one basis gate")
+            # the reference needs monodromy's precomputed coverage sets; here: analytic rules (span_rules.py) -- exact for
+            # one basis gate of a known class, otherwise a sound LOWER bound from which the span loop starts
             from .weyl import c1c2c3
 
-            self._gate_coords = c1c2c3(self.gate_matrices[0])
-            span_rules.family_of(self._gate_coords)  # NotImplementedError for unsupported gates
+            self._gate_coords_all = [c1c2c3(m) for m in self.gate_matrices]
+            self._gate_coords = self._gate_coords_all[0]
+            if len(self.base_gates) == 1:
+                try:
+                    span_rules.family_of(self._gate_coords)
+                    self._span_exact = True
+                except NotImplementedError:
+                    pass
         super().__init__(preseed=preseed, use_polytopes=use_polytopes)
         self._reset()
         self.trotter = False
@@ -98,14 +104,31 @@ class CircuitTemplate(VariationalTemplate):
             return self.spanning_range
         from .weyl import c1c2c3
 
-        k = int(span_rules.minimal_span(np.array([c1c2c3(target_u)]), self._gate_coords)[0])
-        return range(k, k + 1)
+        k = int(self.minimal_spans(np.array([c1c2c3(target_u)]))[0])
+        if self._span_exact:
+            return range(k, k + 1)
+        return range(k, self.maximum_span_guess + 1)  # lower bound: brute force from there
+
+    @property
+    def span_rules_exact(self) -> bool:
+        """True: ``minimal_spans`` is the template size each target needs (one basis gate of a class with closed-form coverage
+        regions); False: a lower bound (mixed sequences, other gates) -- the span loop runs from it to ``maximum_span_guess``."""
+        return self._span_exact
 
     def minimal_spans(self, target_coords) -> np.ndarray:
-        """Batched form of the polytope lookup: minimal template size per target from its Weyl coordinates."""
+        """Batched form of the polytope lookup: template size per target from its Weyl coordinates (exact or a lower bound,
+        see ``span_rules_exact``).  A target that the whole template cannot reach raises, as the reference's lookup does
+        (polytope_wrap.py:91-93)."""
         if not self.use_polytopes:
             raise ValueError("minimal_spans needs use_polytopes=True")
-        return span_rules.minimal_span(target_coords, self._gate_coords)
+        if self._span_exact:
+            return span_rules.minimal_span(target_coords, self._gate_coords)
+        kmax = int(self.maximum_span_guess)
+        seq = [self._gate_coords_all[i] for i in self.gate_sequence(kmax)]
+        lb = span_rules.span_lower_bound(target_coords, seq, kmax)
+        if np.any(lb > kmax):
+            raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
+        return lb
 
     # ---- numerics -----------------------------------------------------------------------------
     def eval(self, Xk):

@@ -539,6 +539,9 @@ struct HStore<NA, true> {
 // ---------------------------------------------------------------------------------------------------------------
 // projected quasi-Newton minimisation, persistent wavefronts over the stage's restart-major work queue
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef SLAM_V2_WAVES
+#define SLAM_V2_WAVES(K, QN) 1
+#endif
 template <int K, int QN>
 struct MinimizeV2Args {
     const double* targets;     // resident targets
@@ -570,7 +573,7 @@ struct MinimizeV2Args {
 };
 
 template <int K, int QN>
-__global__ void __launch_bounds__(kWave, 1) minimize_v2_kernel(MinimizeV2Args<K, QN> args) {
+__global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kernel(MinimizeV2Args<K, QN> args) {
     using C = CfgV2<K, QN>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];

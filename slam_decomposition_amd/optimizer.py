@@ -263,9 +263,14 @@ class TemplateOptimizer:
         ctx.set_gates(self.basis.gate_matrices)
         ctx.set_cost(self._cost_kind)
         ctx.reset_stats()
+        exact = getattr(self.basis, "span_rules_exact", True)
+        if not exact:
+            k_top = int(self.basis.maximum_span_guess)  # lower bounds: the span loop runs from the bound to the template's maximum
         for k in np.unique(spans):
             k = int(k)
-            ctx.decompose_list(np.nonzero(spans == k)[0], k, k, [self.basis.gate_sequence(k)], prm, self.success_threshold, k_layout=k_top)
+            k_hi = k if exact else k_top
+            ctx.decompose_list(np.nonzero(spans == k)[0], k, k_hi, [self.basis.gate_sequence(kk) for kk in range(k, k_hi + 1)], prm,
+                               self.success_threshold, k_layout=k_top)
         best_loss, best_x, best_cycles = ctx.fetch_results_range(k_top, 0, len(targets))
         self._span_losses = ctx.fetch_span_losses(0, len(targets))
         self.last_stats = ctx.stats()
@@ -489,7 +494,8 @@ class TemplateOptimizer:
             best_loss, best_xs, best_cycles = self._run_batch_v2(stacked, spanning_range)
         elif self.use_callback:
             if self.basis.use_polytopes:
-                spans_of = [list(range(int(k), int(k) + 1)) for k in self.basis.minimal_spans(coords_arr)]
+                top = None if getattr(self.basis, "span_rules_exact", True) else int(self.basis.maximum_span_guess)
+                spans_of = [list(range(int(k), (int(k) if top is None else top) + 1)) for k in self.basis.minimal_spans(coords_arr)]
             else:
                 spans_of = [list(self.basis.get_spanning_range(stacked[0]))] * n
             best_loss, best_xs, best_cycles = self._run_batch_callback(stacked, spans_of)
@@ -497,7 +503,10 @@ class TemplateOptimizer:
             # get_spanning_range per target (optimizer.py:233 with basis.py:95-100): only the template size
             # the target needs.  Targets are grouped by that size; each group is one batch.
             spans = self.basis.minimal_spans(coords_arr)
-            spans_of = [[int(k)] for k in spans]
+            if getattr(self.basis, "span_rules_exact", True):
+                spans_of = [[int(k)] for k in spans]
+            else:
+                spans_of = [list(range(int(k), int(self.basis.maximum_span_guess) + 1)) for k in spans]
             best_loss, best_xs, best_cycles = self._run_batch_by_span(stacked, spans)
         else:
             spanning_range = self.basis.get_spanning_range(stacked[0])

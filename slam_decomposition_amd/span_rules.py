@@ -16,6 +16,22 @@ closed form the same answer comes from a few comparisons on (c1, c2, c3) (SURVEY
   (src/slam/utils/transpiler_pass/weyl_decompose.py:343-387, arXiv:2105.06074) -- otherwise 3;
 * B class (0.5, 0.25, 0): every non-local target in 2 (Zhang et al., PRL 93, 020502).
 
+For every other template -- a basis gate outside those classes (the ConversionGain(0, 0, gc, gg, 1) family of config 5),
+or a SEQUENCE of different gates (``[iSWAP, B]``, the territory of ``MixedOrderBasisCircuitTemplate``, basis.py:213-359) --
+the exact coverage polytopes are not available here, but a LOWER bound on the template size is:
+
+* 0 gates iff the target is local; 1 gate iff the target is in the first gate's own class (exact);
+* k >= 2 gates g_1 .. g_k only if  m(T) <= m(g_1) + ... + m(g_k)  for the two interaction-strength measures
+  ``m1 = x + y + |z|`` and ``m2 = max(x, (x + y + |z|) / 2)`` of the folded coordinates (x >= y >= |z|, x <= 1/2).
+  m1 and m2 are the minimal times to simulate the gate with the Hamiltonians XX and XX + YY and fast local unitaries
+  (Childs, Haselgrove, Nielsen, PRA 68, 052311: optimal simulation time = the smallest t with a representative of the
+  canonical parameters s-majorised by t lambda(H); the folded representative minimises both expressions), and a
+  simulation time is subadditive under composition with local gates in between ("chaining").
+
+``span_lower_bound`` is sound (a target is never placed above its true size: tests/test_gpu_round3.py checks it against the
+brute-force span loop on the config-4 and config-5 bases) but not tight: the span loop starts at the bound instead of at 1
+and targets whose bound exceeds the template's maximum are not optimised at all.
+
 Coordinates are in units of pi, as returned by ``weylchamber.c1c2c3`` (8 digits).
 """
 from __future__ import annotations
@@ -69,3 +85,36 @@ def minimal_span(target_coords, gate_coords) -> np.ndarray:
     k = np.where(same, 1, k)
     k = np.where(local, 0, k)
     return k.astype(np.int64)
+
+
+def strength(coords) -> np.ndarray:
+    """(m1, m2) per row: interaction-strength measures of Weyl coordinates (subadditive under composition with locals)."""
+    c = np.abs(_fold(coords))
+    c = -np.sort(-c, axis=1)  # x >= y >= |z|
+    m1 = c.sum(axis=1)
+    return np.stack([m1, np.maximum(c[:, 0], 0.5 * m1)], axis=1)
+
+
+def span_lower_bound(target_coords, gate_coords_seq, k_max=None, slack: float = 4 * _TOL) -> np.ndarray:
+    """Lower bound on the number of leading gates of the template sequence ``gate_coords_seq`` (Weyl coordinates of
+    g_1, g_2, ... in circuit order) that reach each target: int array [N] with values 0 .. k_max + 1 (k_max + 1 = not
+    reachable with the whole sequence).  ``slack`` (in coordinate units) widens the test: a caller that accepts a loss
+    below L as success accepts targets up to about sqrt(L) outside the reachable set (|coordinate error| ~ sqrt(loss))."""
+    g = np.asarray(gate_coords_seq, dtype=np.float64).reshape(-1, 3)
+    k_max = len(g) if k_max is None else int(k_max)
+    if k_max > len(g):
+        raise ValueError("gate sequence shorter than k_max")
+    c = _fold(target_coords)
+    n = len(c)
+    mt = strength(c)
+    cum = np.cumsum(strength(g[:k_max]), axis=0)  # [k][2]: strength available with k + 1 gates
+    local = np.max(np.abs(c), axis=1) < _TOL
+    gf = _fold(g[:1])[0]
+    same = np.max(np.abs(np.abs(c) - np.abs(gf)), axis=1) < _TOL
+    lb = np.full(n, k_max + 1, dtype=np.int64)
+    for k in range(k_max, 1, -1):
+        ok = np.all(mt <= cum[k - 1] + slack, axis=1)
+        lb = np.where(ok, k, lb)
+    lb = np.where(same, 1, lb)
+    lb = np.where(local, 0, lb)
+    return lb

@@ -119,3 +119,33 @@ def test_two_rccl_ranks_on_two_gpus_merge_device_to_device(tmp_path):
     assert np.array_equal(full[a["first"] : a["first"] + a["count"]], a["loss"]) and np.array_equal(full[b["first"] : b["first"] + b["count"]], b["loss"])
     assert a["n_below"] == b["n_below"] == int((full < 1e-8).sum()) == N
     assert a["refused"] is True and b["refused"] is True
+
+
+def test_span_lower_bounds_are_sound_against_the_brute_force_loop(hip_ctx):
+    """span_rules.span_lower_bound (mixed sequences, gates without closed-form coverage regions) must never place a target
+    ABOVE the template size the brute-force span loop solves it at, and a target it declares out of reach of the whole
+    template must stay unsolved -- on BASELINE configs[3]'s [iSWAP, B] sequence and on bases of configs[4]'s conversion-gain
+    sweep (weak to strong).  Also reports how much work the bound saves."""
+    import bench
+    from oracle import slam_oracle as o
+    from slam_decomposition_amd import span_rules
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    N = 1536
+    hip_ctx.sample_haar(424242, N)
+    coords = hip_ctx.targets_c1c2c3(0, N)
+    prm = _ffi.OptParams(restarts=16, seed=8, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+    cases = [("iswap+b", bench.gate_table("iswap+b"), [[0], [0, 1], [0, 1, 0]])]
+    for bidx in (8, 24, 40, 64, 100):
+        cases.append((f"cg{bidx}", np.stack([bench.sweep_gate(bidx)]), [[0], [0, 0], [0, 0, 0]]))
+    for name, table, seqs in cases:
+        hip_ctx.set_gates(table)
+        loss, _, cyc = hip_ctx.decompose(1, 3, seqs, prm, 1e-10)
+        solved = loss < 1e-8
+        lb = span_rules.span_lower_bound(coords, [c1c2c3(table[i]) for i in seqs[2]], 3)
+        assert np.all(cyc[solved] >= lb[solved]), name          # never above the true template size
+        assert not np.any(solved & (lb > 3)), name              # "out of reach" targets are indeed not solved
+        if name == "iswap+b":
+            assert np.all(lb == 2) and solved.all()             # strong gates: the bound only rules out the k = 1 stage
+        if name == "cg8":
+            assert (lb > 3).mean() > 0.9 and solved.mean() < 0.01  # a weak gate: nearly every Haar target is out of reach

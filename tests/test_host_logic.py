@@ -86,9 +86,7 @@ def test_circuit_template_structure():
     assert gl[0] == ("u", 0, (0.0, 1.0, 2.0)) and gl[1] == ("u", 1, (3.0, 4.0, 5.0)) and gl[3] == ("u", 0, (6.0, 7.0, 8.0))
     assert t.target_invariant(o.cx_matrix()) == (0.5, 0.0, 0.0)
     assert t.target_invariant(np.eye(8)) == (-1, -1, -1, -1)
-    for kwargs in (dict(no_exterior_1q=True), dict(n_qubits=3), dict(edge_params=[[(1, 0)]]),
-                   dict(use_polytopes=True, base_gates=[RiSwapGate(0.3)]),  # no analytic rule for a generic XY gate
-                   dict(use_polytopes=True, base_gates=[RiSwapGate(0.5), CXGate()])):
+    for kwargs in (dict(no_exterior_1q=True), dict(n_qubits=3), dict(edge_params=[[(1, 0)]])):
         with pytest.raises(NotImplementedError):
             CircuitTemplate(**kwargs)
 
@@ -112,6 +110,39 @@ def test_span_rules_and_polytope_mode_ranges():
     assert t.get_spanning_range(o.cx_matrix()) == range(2, 3)
     assert t.get_spanning_range(np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex)) == range(3, 4)
     assert t.get_spanning_range(np.eye(4)) == range(0, 1)  # polytope_wrap.py:55-56
+
+
+def test_span_lower_bounds_for_mixed_sequences_and_other_gates():
+    """use_polytopes=True without closed-form coverage regions -- a sequence of different gates (MixedOrderBasisCircuitTemplate
+    territory, basis.py:213-359) or a gate outside the known classes: a sound LOWER bound on the template size from the
+    interaction-strength measures (span_rules.span_lower_bound); the span loop starts there."""
+    from slam_decomposition_amd import span_rules
+    from slam_decomposition_amd.gates import BerkeleyGate
+
+    isw, b, cx = (0.5, 0.5, 0.0), (0.5, 0.25, 0.0), (0.5, 0.0, 0.0)
+    coords = np.array([(0, 0, 0), isw, b, (0.4, 0.3, 0.2), (0.5, 0.5, 0.5), (0.7, 0.2, 0.05)])
+    # [iSWAP, B, iSWAP]: local 0, the FIRST gate's class 1, everything else at least 2 (strong gates: the bound stops there)
+    assert span_rules.span_lower_bound(coords, [isw, b, isw]).tolist() == [0, 1, 2, 2, 2, 2]
+    # the bound never exceeds the exact rules of the single-gate families
+    rng = np.random.default_rng(0)
+    c = np.sort(rng.uniform(0, 0.5, (2000, 3)), axis=1)[:, ::-1]
+    for g in (cx, isw, (0.25, 0.25, 0.0), b):
+        assert np.all(span_rules.span_lower_bound(c, [g] * 3) <= span_rules.minimal_span(c, g))
+    # a weak gate: three applications offer m1 = 3 (x + y) of interaction strength; SWAP (m1 = 1.5) is out of reach
+    weak = (0.1, 0.1, 0.0)
+    lb = span_rules.span_lower_bound(np.array([(0.05, 0.05, 0.0), (0.15, 0.1, 0.05), (0.3, 0.2, 0.1), (0.5, 0.5, 0.5)]), [weak] * 3)
+    assert lb.tolist() == [2, 2, 3, 4]  # 4 = not reachable with the whole sequence
+    assert np.allclose(span_rules.strength(np.array([(0.7, 0.2, 0.05)])), [[0.55, 0.3]])  # folds to (0.3, 0.2, -0.05)
+    # the template: exact for one known gate, lower bound + brute force from there otherwise
+    t = CircuitTemplate(base_gates=[RiSwapGate(1.0), BerkeleyGate()], use_polytopes=True, maximum_span_guess=3)
+    assert not t.span_rules_exact and CircuitTemplate(base_gates=[RiSwapGate(0.5)], use_polytopes=True).span_rules_exact
+    assert t.get_spanning_range(o.riswap_matrix(1.0)) == range(1, 4)       # iSWAP's own class: from one gate on
+    assert t.get_spanning_range(o.cx_matrix()) == range(2, 4)
+    assert t.get_spanning_range(np.eye(4)) == range(0, 4)
+    w = CircuitTemplate(base_gates=[RiSwapGate(0.2)], use_polytopes=True, maximum_span_guess=3)  # (0.1, 0.1, 0): no closed form
+    assert not w.span_rules_exact
+    with pytest.raises(ValueError, match="did not find a polytope"):          # polytope_wrap.py:91-93
+        w.get_spanning_range(np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex))  # SWAP
 
 
 def test_qiskit_parameter_order_helpers():
