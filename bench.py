@@ -375,7 +375,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     # the ordered early exit every step's results are bit for bit those of its own call (tests/test_gpu_round2.py).
     group = 1
     if small and not (gname == "cgsweep") and not (main and args.span_rules):
-        group = args.group if (main and args.group) else 10
+        group = args.group if (main and args.group) else 20  # measured (320 steps, 4 streams): 10 -> 0.40, 16 -> 0.44, 20 -> 0.445, 32 -> 0.44 of peak
     group = max(1, min(group, steps))
     n_streams = n_streams_arg if n_streams_arg else (4 if small else 5)
     n_streams = max(1, min(n_streams, (steps + group - 1) // group))
@@ -656,7 +656,7 @@ def main():
                          "(measured on cfg3: 3 -> 2.95e6, 4 -> 3.0e6, 5 -> 3.19e6, 6 -> 3.20e6 decompositions/s)")
     ap.add_argument("--group", type=int, default=0,
                     help="small batches: consecutive steps handed to the library as one call = one device-side work queue per span "
-                         "(default 10 for cfg2-sized batches, 1 otherwise)")
+                         "(default 20 for cfg2-sized batches, 1 otherwise)")
     ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "-1")),
                     help="launch shaping (slam_opt_params.items_per_quad); 0 = library default (one item per quad, lowest "
                          "latency); default here: 3 for small batches with several in flight (+4.7 %% measured), else 0")

@@ -77,8 +77,8 @@ class TemplateOptimizer:
         if not isinstance(basis, (CircuitTemplate, CircuitTemplateV2)):
             raise NotImplementedError("the HIP optimizer needs a slam_decomposition_amd CircuitTemplate / CircuitTemplateV2")
         self._v2 = isinstance(basis, CircuitTemplateV2)
-        if self._v2 and (use_callback or (devices is not None and len(devices) > 1)):
-            raise NotImplementedError("CircuitTemplateV2 on the HIP path: use_callback and several devices are not implemented")
+        if self._v2 and use_callback:
+            raise NotImplementedError("CircuitTemplateV2 on the HIP path: use_callback is not implemented")
         if self._v2 and basis.using_constraints:
             raise NotImplementedError("cost constraints (SLSQP, optimizer.py:260-265) are not implemented on the HIP path")
         if isinstance(self.objective, SquareCost):
@@ -280,44 +280,90 @@ class TemplateOptimizer:
     def _run_batch_v2(self, targets: np.ndarray, spanning_range):
         """``_run`` for a CircuitTemplateV2 (optimizer.py:233-303 with method "L-BFGS-B" when the template has bounds, "BFGS"
         otherwise, :255-268): the span loop is driven from the host, one ``slam_v2_minimize_stage`` per template size over the
-        targets still unsolved.  Every restart runs to its end on the device; a stage's result is the restart the
-        reference's sequential loop ends with (the first one below the threshold, else the lowest loss)."""
+        targets still unsolved.  A stage's result is the restart the reference's sequential loop ends with (the first one
+        below the threshold, else the lowest loss); restarts behind a successful one are not started (ordered early exit).
+        Several ``devices``: contiguous target shards, one host thread + context each, seeds keyed on the global target index
+        (``target_base``) -- the sharded job returns the single-device results bit for bit."""
         basis = self.basis
         n = len(targets)
         prm = self._opt_params()
-        ctx = runtime.get_context(self.devices[0])
-        ctx.set_targets(targets)
-        ctx.v2_set_gates(basis._gate_maps)
-        ctx.set_cost(self._cost_kind)
-        best = np.full(n, np.inf)
-        best_x = [None] * n
-        best_k = np.full(n, -1, dtype=np.int32)
-        self._span_losses = np.full((n, _ffi.MAX_SPAN_EVAL), np.nan)
-        for k in spanning_range:
-            k = int(k)
+        ks = [int(k) for k in spanning_range]
+        for k in ks:
             if k <= 0:
                 raise ValueError()  # build(n_repetitions <= 0), basisv2.py:221-222
             if k > _ffi.V2_MAX_SPAN:
                 raise NotImplementedError(f"parametrised-gate templates run spans 1..{_ffi.V2_MAX_SPAN} on the HIP path (got {k})")
-            act = np.nonzero(~(best < self.success_threshold))[0].astype(np.int32)
-            if len(act) == 0:
-                break
+        layouts = {}
+        for k in ks:
             basis.build(k)
-            _, idx, init_lo, init_hi, blo, bhi = basis.device_layout(k)
+            layouts[k] = (basis.gate_sequence(k),) + tuple(basis.device_layout(k))
+
+        def run_shard(device, first, count):
+            single = len(self.devices) == 1
+            ctx = runtime.get_context(device) if single else _ffi.Context(device)
             try:
-                out = ctx.v2_minimize_stage(basis.gate_sequence(k), prm, self.success_threshold, init_lo, init_hi, blo, bhi, active=act)
-            except _ffi.SlamHipError as exc:
-                if exc.code == -3:  # SLAM_ERR_UNSUPPORTED: span x parameters-per-gate beyond what the device kernels hold
-                    raise NotImplementedError(str(exc)) from exc
-                raise
-            for j, t in enumerate(act):
-                if best_k[t] < 0 or out["best_loss"][j] < best[t]:  # optimizer.py:281-284
-                    best[t], best_k[t] = out["best_loss"][j], k
-                    best_x[t] = out["best_x"][j][idx].copy()  # user parameters (index order)
-                self._span_losses[t, k - 1] = best[t]
+                ctx.set_targets(targets[first : first + count])
+                ctx.v2_set_gates(basis._gate_maps)
+                ctx.set_cost(self._cost_kind)
+                ctx.reset_stats()
+                sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
+                                    flags=prm.flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, target_base=first)
+                best = np.full(count, np.inf)
+                best_x = [None] * count
+                best_k = np.full(count, -1, dtype=np.int32)
+                span_losses = np.full((count, _ffi.MAX_SPAN_EVAL), np.nan)
+                for k in ks:
+                    act = np.nonzero(~(best < self.success_threshold))[0].astype(np.int32)
+                    if len(act) == 0:
+                        break
+                    seq, _, idx, init_lo, init_hi, blo, bhi = layouts[k]
+                    try:
+                        out = ctx.v2_minimize_stage(seq, sp, self.success_threshold, init_lo, init_hi, blo, bhi, active=act, want_items=False)
+                    except _ffi.SlamHipError as exc:
+                        if exc.code == -3:  # SLAM_ERR_UNSUPPORTED: span x parameters-per-gate beyond what the device kernels hold
+                            raise NotImplementedError(str(exc)) from exc
+                        raise
+                    for j, t in enumerate(act):
+                        if best_k[t] < 0 or out["best_loss"][j] < best[t]:  # optimizer.py:281-284
+                            best[t], best_k[t] = out["best_loss"][j], k
+                            best_x[t] = out["best_x"][j][idx].copy()  # user parameters (index order)
+                        span_losses[t, k - 1] = best[t]
+                return (best, best_x, best_k, span_losses), ctx.stats()
+            finally:
+                if not single:
+                    ctx.close()
+
+        if len(self.devices) == 1 or n < len(self.devices):
+            (best, best_x, best_k, self._span_losses), self.last_stats = run_shard(self.devices[0], 0, n)
+        else:
+            import threading
+
+            from .parallel import shard_range
+
+            parts = [None] * len(self.devices)
+            errors = []
+
+            def work(r):
+                try:
+                    first, count = shard_range(n, r, len(self.devices))
+                    parts[r] = run_shard(self.devices[r], first, count)
+                except Exception as exc:  # surfaced below
+                    errors.append(exc)
+
+            threads = [threading.Thread(target=work, args=(r,)) for r in range(len(self.devices))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            best = np.concatenate([p[0][0] for p in parts])
+            best_x = [x for p in parts for x in p[0][1]]
+            best_k = np.concatenate([p[0][2] for p in parts])
+            self._span_losses = np.concatenate([p[0][3] for p in parts])
+            self.last_stats = [p[1] for p in parts]
         if np.any(best_k < 0):
             raise ValueError("empty spanning range")
-        self.last_stats = ctx.stats()
         return best, best_x, best_k
 
     def _run_batch_callback(self, targets: np.ndarray, spans_per_target):

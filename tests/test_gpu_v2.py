@@ -296,3 +296,19 @@ def test_v2_early_exit_drops_later_restarts_only(hip_ctx):
     assert skipped.any()
     for t in range(NT):
         assert not skipped[t, : fast["best_restart"][t] + 1].any()  # nothing at or below the winner is ever dropped
+
+
+def test_v2_sharded_devices_equal_the_single_device_run():
+    """``TemplateOptimizer(devices=[...])`` with a CircuitTemplateV2 (round 3): contiguous target shards, seeds keyed on the
+    global target index -- the sharded job returns the single-device results bit for bit (two contexts on the one GPU here)."""
+    targets = o.haar_batch(7, seed0=321)
+
+    def run(devices):
+        basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=3)
+        opt_ = TemplateOptimizer(basis=basis, objective=SquareCost(), training_restarts=6, seed=17, devices=devices)
+        return opt_._approximate_batch(targets, log_index=False)
+
+    a, b = run([0]), run([0, 0, 0])
+    assert [d.cycles for d in a] == [d.cycles for d in b] and all(d.success_label == 1 for d in a)
+    assert [d.loss_result for d in a] == [d.loss_result for d in b]
+    assert all(np.array_equal(x.Xk, y.Xk) for x, y in zip(a, b))
