@@ -343,6 +343,15 @@ int slam_v2_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const 
                            const slam_opt_params* params, double exit_loss, double* best_loss, double* best_x, int32_t* best_restart,
                            double* item_loss, int32_t* item_iters, int32_t* item_status, int32_t* item_evals);
 
+/* slam_v2_minimize_stage that also records every accepted iteration of every restart (use_callback=True for a
+ * CircuitTemplateV2, src/slam/optimizer.py:217-224): trace_loss [M][trace_cap], trace_x [M][trace_cap][n] as
+ * slam_minimize_stage_trace; rows no iteration reaches read as NaN. */
+int slam_v2_minimize_stage_trace(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active, const double* x0,
+                                 const double* init_lo, const double* init_hi, const double* bound_lo, const double* bound_hi,
+                                 const slam_opt_params* params, double exit_loss, int32_t trace_cap, double* best_loss, double* best_x,
+                                 int32_t* best_restart, double* item_loss, int32_t* item_iters, int32_t* item_status, double* trace_loss,
+                                 double* trace_x);
+
 /*
  * Multi-GPU: one process per GPU, RCCL over xGMI, reached through this ABI (no torch, no MPI).  The path shards by
  * target, every rank keeps all restarts of its targets, so the only exchange is the FINAL min-all-reduce of the

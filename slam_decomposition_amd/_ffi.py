@@ -58,6 +58,7 @@ EXPORTED_SYMBOLS = (
     "slam_v2_set_gates",
     "slam_v2_eval_loss_grad",
     "slam_v2_minimize_stage",
+    "slam_v2_minimize_stage_trace",
     "slam_set_cost",
     "slam_synchronize",
     "slam_get_stats",
@@ -176,6 +177,8 @@ def load_library() -> C.CDLL:
         lib.slam_v2_set_gates.argtypes = [P, C.POINTER(V2Gate), C.c_int32]
         lib.slam_v2_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P, P]
         lib.slam_v2_minimize_stage.argtypes = [P, C.c_int, P, P, C.c_int64, P, P, P, P, P, C.POINTER(OptParams), C.c_double] + [P] * 7
+        if hasattr(lib, "slam_v2_minimize_stage_trace"):
+            lib.slam_v2_minimize_stage_trace.argtypes = [P, C.c_int, P, P, C.c_int64, P, P, P, P, P, C.POINTER(OptParams), C.c_double, C.c_int32] + [P] * 8
     lib.slam_set_cost.argtypes = [P, C.c_int]
     lib.slam_synchronize.argtypes = [P]
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
@@ -549,6 +552,35 @@ class Context:
                 _ptr(out["item_loss"]), _ptr(out["item_iters"]), _ptr(out["item_status"]), _ptr(out["item_evals"]),
             )
         )
+        return out
+
+    def v2_minimize_stage_trace(self, gate_seq: Sequence[int], params: OptParams, exit_loss: float, trace_cap: int, init_lo, init_hi,
+                                bound_lo=None, bound_hi=None, active: Optional[np.ndarray] = None) -> dict:
+        """``v2_minimize_stage`` plus the loss / parameters after every accepted iteration of every restart
+        (``trace_loss`` [na, R, cap], ``trace_x`` [na, R, cap, n]; NaN beyond an item's iterations)."""
+        k = len(gate_seq)
+        n = 6 * (k + 1) + self.v2_qn * k
+        gs = np.ascontiguousarray(gate_seq, dtype=np.int32)
+        if active is not None:
+            active = np.ascontiguousarray(active, dtype=np.int32)
+            na = active.shape[0]
+        else:
+            na = self.n_targets
+        R, cap = int(params.restarts), int(trace_cap)
+        vecs = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in (init_lo, init_hi, bound_lo, bound_hi)]
+        for v in vecs:
+            if v is not None and v.shape != (n,):
+                raise ValueError(f"per-parameter arrays must have shape [{n}]")
+        out = {
+            "best_loss": np.empty(na, dtype=np.float64), "best_x": np.empty((na, n), dtype=np.float64),
+            "best_restart": np.empty(na, dtype=np.int32), "item_loss": np.empty((na, R), dtype=np.float64),
+            "item_iters": np.empty((na, R), dtype=np.int32), "item_status": np.empty((na, R), dtype=np.int32),
+            "trace_loss": np.empty((na, R, cap), dtype=np.float64), "trace_x": np.empty((na, R, cap, n), dtype=np.float64),
+        }
+        _check(self._lib.slam_v2_minimize_stage_trace(
+            self._h, k, _ptr(gs), _ptr(active), na, None, _ptr(vecs[0]), _ptr(vecs[1]), _ptr(vecs[2]), _ptr(vecs[3]), C.byref(params),
+            float(exit_loss), cap, _ptr(out["best_loss"]), _ptr(out["best_x"]), _ptr(out["best_restart"]), _ptr(out["item_loss"]),
+            _ptr(out["item_iters"]), _ptr(out["item_status"]), _ptr(out["trace_loss"]), _ptr(out["trace_x"])))
         return out
 
     def set_cost(self, kind: int) -> None:

@@ -1217,6 +1217,9 @@ int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
     a.item_evals = c->item_evals.as<int32_t>();
     a.item_acc = c->item_acc.as<int32_t>();
     a.ctl = stage_ctl(c, K);
+    a.trace_cap = c->trace_cap;
+    a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
+    a.trace_x = c->trace_cap > 0 ? c->trace_x.as<double>() : nullptr;
     // persistent wavefronts: never more than can be resident; every quad pulls items from the stage's queue
     const int64_t M = (int64_t)sgt.n_active * sgt.prm->restarts;
     int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
@@ -1422,6 +1425,38 @@ int slam_v2_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const 
                            double* item_loss, int32_t* item_iters, int32_t* item_status, int32_t* item_evals) {
     return drained(ctx, v2_minimize_body(ctx, k, gate_seq, active, n_active, x0, init_lo, init_hi, bound_lo, bound_hi, params, exit_loss,
                                          best_loss, best_x, best_restart, item_loss, item_iters, item_status, item_evals));
+}
+
+int slam_v2_minimize_stage_trace(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active, const double* x0,
+                                 const double* init_lo, const double* init_hi, const double* bound_lo, const double* bound_hi,
+                                 const slam_opt_params* params, double exit_loss, int32_t trace_cap, double* best_loss, double* best_x,
+                                 int32_t* best_restart, double* item_loss, int32_t* item_iters, int32_t* item_status, double* trace_loss,
+                                 double* trace_x) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (!params) return fail(SLAM_ERR_INVALID, "params is NULL");
+    if (trace_cap <= 0 || !trace_loss || !trace_x) return fail(SLAM_ERR_INVALID, "trace buffers and trace_cap > 0 are required");
+    if (k < 1 || k > SLAM_V2_MAX_SPAN) return fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates support spans 1..%d (got %d)", SLAM_V2_MAX_SPAN, k);
+    if (!active) n_active = ctx->n_targets;
+    if (n_active <= 0 || params->restarts <= 0) return fail(SLAM_ERR_INVALID, "nothing to trace");
+    const int n = 6 * (k + 1) + ctx->v2_qn * k;
+    const int64_t M = n_active * (int64_t)params->restarts;
+    const size_t rows = (size_t)M * (size_t)trace_cap;
+    if (rows * (size_t)(n + 1) * sizeof(double) > ((size_t)4 << 30))
+        return fail(SLAM_ERR_INVALID, "trace of %lld items x %d iterations exceeds 4 GiB: trace fewer targets at a time", (long long)M, trace_cap);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->trace_loss.reserve(rows * sizeof(double)));
+    HIP_TRY(ctx->trace_x.reserve(rows * n * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(ctx->trace_loss.p, 0xFF, rows * sizeof(double), ctx->stream));  // rows no iteration reaches read as NaN
+    HIP_TRY(hipMemsetAsync(ctx->trace_x.p, 0xFF, rows * n * sizeof(double), ctx->stream));
+    ctx->trace_cap = trace_cap;
+    int rc = slam_v2_minimize_stage(ctx, k, gate_seq, active, n_active, x0, init_lo, init_hi, bound_lo, bound_hi, params, exit_loss, best_loss, best_x,
+                                    best_restart, item_loss, item_iters, item_status, nullptr);
+    ctx->trace_cap = 0;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(trace_loss, ctx->trace_loss.p, rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(trace_x, ctx->trace_x.p, rows * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
 }
 
 }  // extern "C"

@@ -570,6 +570,11 @@ struct MinimizeV2Args {
     int32_t* item_acc;
     StageCtl* ctl;             // work queue head, round counter
     float* hmem;               // v2_h_in_memory<K, QN>(): [gridDim.x][v2_h_floats_per_wave] inverse Hessians; else unused
+    // optional per-iteration trace (use_callback, optimizer.py:217-224), as MinimizeArgs: after accepted step number it >= 1 of
+    // item m, trace_loss[m][it - 1] = loss and trace_x[m][it - 1][:] = parameters; nullptr = off
+    double* trace_loss;        // [M][trace_cap]
+    double* trace_x;           // [M][trace_cap][n]
+    int32_t trace_cap;
 };
 
 template <int K, int QN>
@@ -772,6 +777,17 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kerne
                 const double2 b = bnd[4 * a + q];
                 const bool out = (x[a] <= b.x && hn > 0.0) || (x[a] >= b.y && hn < 0.0);
                 p[a] = out ? 0.0 : -hn;
+            }
+            if (args.trace_loss) {  // wave-uniform: nothing when off
+                if (step && iters <= args.trace_cap) {
+                    const int64_t row = (int64_t)item * args.trace_cap + (iters - 1);
+                    if (q == 0) args.trace_loss[row] = f;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const int i = 4 * a + q;
+                        if (i < C::N) args.trace_x[row * C::N + i] = x[a];
+                    }
+                }
             }
         } else if (active) {
             if (fresh) {

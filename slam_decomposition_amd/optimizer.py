@@ -77,8 +77,6 @@ class TemplateOptimizer:
         if not isinstance(basis, (CircuitTemplate, CircuitTemplateV2)):
             raise NotImplementedError("the HIP optimizer needs a slam_decomposition_amd CircuitTemplate / CircuitTemplateV2")
         self._v2 = isinstance(basis, CircuitTemplateV2)
-        if self._v2 and use_callback:
-            raise NotImplementedError("CircuitTemplateV2 on the HIP path: use_callback is not implemented")
         if self._v2 and basis.using_constraints:
             raise NotImplementedError("cost constraints (SLSQP, optimizer.py:260-265) are not implemented on the HIP path")
         if isinstance(self.objective, SquareCost):
@@ -379,7 +377,10 @@ class TemplateOptimizer:
         prm = self._opt_params()
         ctx = runtime.get_context(self.devices[0])
         ctx.set_targets(targets)
-        ctx.set_gates(self.basis.gate_matrices)
+        if self._v2:
+            ctx.v2_set_gates(self.basis._gate_maps)
+        else:
+            ctx.set_gates(self.basis.gate_matrices)
         ctx.set_cost(self._cost_kind)
         ctx.reset_stats()
         R = int(self.training_restarts)
@@ -393,20 +394,38 @@ class TemplateOptimizer:
         for k in all_ks:
             if k <= 0:
                 raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
-            if k > _ffi.MAX_SPAN_MINIMIZE:
+            if k > (_ffi.V2_MAX_SPAN if self._v2 else _ffi.MAX_SPAN_MINIMIZE):
                 raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path")
             act = np.array([t for t in range(n) if k in spans_per_target[t] and not (best[t] is not None and best[t] < self.success_threshold)],
                            dtype=np.int32)
             if len(act) == 0:
                 continue
             seq = self.basis.gate_sequence(k)
+            v2_idx = None
+            if self._v2:
+                self.basis.build(k)
+                _, v2_idx, v2_ilo, v2_ihi, v2_blo, v2_bhi = self.basis.device_layout(k)
             cap = 256
             while True:
-                out = ctx.minimize_stage_trace(seq, prm, self.success_threshold, cap, active=act)
+                if self._v2:
+                    out = ctx.v2_minimize_stage_trace(seq, prm, self.success_threshold, cap, v2_ilo, v2_ihi, v2_blo, v2_bhi, active=act)
+                else:
+                    out = ctx.minimize_stage_trace(seq, prm, self.success_threshold, cap, active=act)
                 need = int(out["item_iters"].max())
                 if need <= cap:
                     break
                 cap = need  # deterministic: the same run again, now with room for the longest restart
+
+            def coords_of(X):
+                """c1c2c3 of the template unitaries of the traced points (optimizer.py:223-224)"""
+                if not len(X):
+                    return []
+                if self._v2:
+                    _, _, W = ctx.v2_eval(seq, X, want_grad=False, want_unitary=True)  # X is in device layout already
+                    C3 = ctx.c1c2c3(W)
+                else:
+                    C3 = ctx.eval_c1c2c3(seq, X)
+                return [tuple(float(v) for v in c) for c in C3]
             for j, t in enumerate(act):
                 temp_loss[t].extend([-1, k])  # flags for the plotting function (optimizer.py:238)
                 rows = []  # (restart, iterations) of the restarts the sequential loop runs
@@ -419,8 +438,8 @@ class TemplateOptimizer:
                         best[t], best_k[t] = result, k
                     hit = best[t] < self.success_threshold
                     if hit or (self.override_fail and r == R - 1):
-                        X = np.concatenate([out["trace_x"][j, rr, :ii] for rr, ii in rows]) if rows else np.zeros((0, 6 * (k + 1)))
-                        coords = [tuple(float(v) for v in c) for c in ctx.eval_c1c2c3(seq, X)] if len(X) else []
+                        X = np.concatenate([out["trace_x"][j, rr, :ii] for rr, ii in rows]) if rows else np.zeros((0, out["trace_x"].shape[-1]))
+                        coords = coords_of(X)
                         # the reference appends the SAME growing list object every time (optimizer.py:289-292)
                         self._callback_records[t].append((temp_loss[t], coords))
                     if hit:
@@ -429,7 +448,7 @@ class TemplateOptimizer:
                     # the sequential best of this span is the stage's ordered winner: the first restart below the
                     # threshold, else the lowest loss (first occurrence)
                     assert best[t] == float(out["best_loss"][j])
-                    best_x[t] = out["best_x"][j].copy()
+                    best_x[t] = out["best_x"][j][v2_idx].copy() if self._v2 else out["best_x"][j].copy()
                 self._span_losses[t, k - 1] = best[t]
         self.last_stats = ctx.stats()
         if any(b is None for b in best):
@@ -534,7 +553,7 @@ class TemplateOptimizer:
         coords_arr = ctx0.c1c2c3(stacked) if need_coords else None
         self.basis.assign_seed(None)  # optimizer.py:150-152
         spans_of = None
-        if self._v2:
+        if self._v2 and not self.use_callback:
             spanning_range = list(self.basis.get_spanning_range(stacked[0]))
             spans_of = [spanning_range] * n
             best_loss, best_xs, best_cycles = self._run_batch_v2(stacked, spanning_range)

@@ -312,3 +312,27 @@ def test_v2_sharded_devices_equal_the_single_device_run():
     assert [d.cycles for d in a] == [d.cycles for d in b] and all(d.success_label == 1 for d in a)
     assert [d.loss_result for d in a] == [d.loss_result for d in b]
     assert all(np.array_equal(x.Xk, y.Xk) for x, y in zip(a, b))
+
+
+def test_v2_use_callback_records_the_restart_loop():
+    """``use_callback=True`` with a CircuitTemplateV2 (optimizer.py:217-224 applies to any template; round 3): the
+    ``[-1, k, loss ...]`` training-loss record and one coordinate triple per recorded loss, the final result that of the run
+    without the callback, the last recorded loss of the winning span = the reported loss."""
+    T = o.haar_batch(2, seed0=777)
+
+    def make():
+        return CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=3)
+
+    plain = TemplateOptimizer(basis=make(), objective=BasicCost(), training_restarts=4, seed=23)._approximate_batch(T, log_index=False)
+    cb = TemplateOptimizer(basis=make(), objective=BasicCost(), training_restarts=4, seed=23, use_callback=True)
+    data = cb._approximate_batch(T, log_index=False)
+    assert [d.cycles for d in data] == [d.cycles for d in plain] and [d.loss_result for d in data] == [d.loss_result for d in plain]
+    assert all(np.array_equal(a.Xk, b.Xk) for a, b in zip(data, plain))
+    assert len(cb.training_loss) == len(cb.coordinate_list) >= 2
+    for tl, cl in zip(cb.training_loss, cb.coordinate_list):
+        assert tl[0] == -1 and tl[1] in (1, 2, 3)
+        n_loss = sum(1 for i, v in enumerate(tl) if not (v == -1 or (i > 0 and tl[i - 1] == -1)))
+        assert len(cl) <= n_loss and all(len(c) == 3 for c in cl)
+    # the last firing of target 0: its final recorded loss is the reported one (f(x_k) after the last accepted step)
+    firing = [tl for tl in cb.training_loss][len([1 for _ in range(1)]) - 1]
+    assert min(abs(v - data[0].loss_result) for v in firing if v >= 0) < 1e-15
