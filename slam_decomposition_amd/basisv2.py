@@ -13,9 +13,10 @@ with every raw angle an affine function of at most one parameter -- ``RiSwapGate
 probing the callable; anything else raises ``NotImplementedError``.
 
 Parameter order of ``Xk`` here is *index order*: ``P0 .. P{m-1}, Q0 .. Q{QN k - 1}`` (the reference zips ``Xk`` with
-qiskit's name-sorted ``circuit.parameters``; ``to_qiskit_order`` / ``from_qiskit_order`` convert).  Not implemented:
-``no_exterior_1q``, ``param_vec_expand`` (time-sliced "smush" gates), cost constraints (``set_constraint`` -> SLSQP),
-polytopes.
+qiskit's name-sorted ``circuit.parameters``; ``to_qiskit_order`` / ``from_qiskit_order`` convert).  ``no_exterior_1q`` (no 1Q
+layer before the first and after the last 2Q gate, basisv2.py:264,291) maps onto the device template by fixing those two
+layers at ``U(0, 0, 0)`` = identity, like ``vz_only`` fixes theta and phi.  Not implemented: ``param_vec_expand`` (time-sliced
+"smush" gates: not conversion-gain family members), cost constraints (``set_constraint`` -> SLSQP), polytopes.
 """
 from __future__ import annotations
 
@@ -91,8 +92,6 @@ class CircuitTemplateV2(VariationalTemplate):
             edge_params = [[(0, 1)]]
         if n_qubits != 2:
             raise NotImplementedError("the HIP template optimizer handles 2-qubit templates only")
-        if no_exterior_1q:
-            raise NotImplementedError("no_exterior_1q=True is not implemented on the HIP path")
         if param_vec_expand is not None:
             raise NotImplementedError("param_vec_expand (time-sliced smush gates, basisv2.py:47-50) is not implemented on the HIP path")
         if use_polytopes:
@@ -103,7 +102,7 @@ class CircuitTemplateV2(VariationalTemplate):
                     raise NotImplementedError("only edge (0, 1) is implemented on the HIP path")
         self.filename = None
         self.n_qubits = n_qubits
-        self.no_exterior_1q = no_exterior_1q
+        self.no_exterior_1q = bool(no_exterior_1q)
         self.param_vec_expand = None
         self.vz_only = bool(vz_only)
         self.base_gates = list(base_gates)
@@ -152,7 +151,10 @@ class CircuitTemplateV2(VariationalTemplate):
 
     def _n_p(self, k=None) -> int:
         k = self.cycles if k is None else k
-        return (2 if self.vz_only else 6) * (k + 1)  # rz: one parameter per qubit and layer (basisv2.py:256-259)
+        # rz: one parameter per qubit and layer (basisv2.py:256-259); no_exterior_1q: the layers before the first and after the
+        # last 2Q gate do not exist (basisv2.py:264,291): k - 1 interior layers
+        layers = (k - 1) if self.no_exterior_1q else (k + 1)
+        return (2 if self.vz_only else 6) * max(layers, 0)
 
     def parameter_names(self, k=None) -> List[str]:
         """Index order: P0.., then Q0.. (gate 1's parameters first)."""
@@ -217,8 +219,10 @@ class CircuitTemplateV2(VariationalTemplate):
         n_dev = n_p_dev + self._dev_qn * k
         names = self.parameter_names(k)
         idx = []
+        first_layer = 1 if self.no_exterior_1q else 0  # no_exterior_1q: device layers 0 and k stay fixed at U(0, 0, 0) = 1
         for i in range(self._n_p(k)):
-            idx.append(3 * i + 2 if self.vz_only else i)  # rz of (layer j, qubit b) = P{2j+b} -> lambda slot 6j + 3b + 2
+            # rz of (layer j, qubit b) = P{2j+b} -> lambda slot 6j + 3b + 2
+            idx.append(6 * first_layer + (3 * i + 2 if self.vz_only else i))
         for j in range(k):
             for m in range(self.n_gate_params):
                 idx.append(n_p_dev + self._dev_qn * j + m)

@@ -336,3 +336,23 @@ def test_v2_use_callback_records_the_restart_loop():
     # the last firing of target 0: its final recorded loss is the reported one (f(x_k) after the last accepted step)
     firing = [tl for tl in cb.training_loss][len([1 for _ in range(1)]) - 1]
     assert min(abs(v - data[0].loss_result) for v in firing if v >= 0) < 1e-15
+
+
+def test_v2_no_exterior_1q_template():
+    """``no_exterior_1q=True`` (basisv2.py:264,291; fsim_continuous.ipynb): no 1Q layer before the first and after the last 2Q
+    gate -- W = G_k K_{k-1} ... K_1 G_1.  The device template fixes the two exterior layers at U(0, 0, 0) = identity."""
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate], no_exterior_1q=True, maximum_span_guess=3)
+    basis.build(3)
+    assert basis.parameter_names() == [f"P{i}" for i in range(12)] + ["Q0", "Q1", "Q2"]
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-3, 3, 15)
+    W = basis.eval(x)
+    G = lambda a: RiSwapGate(a).to_matrix()
+    ref = G(x[14]) @ o.layer_matrix(x[6:12]) @ G(x[13]) @ o.layer_matrix(x[0:6]) @ G(x[12])
+    assert np.max(np.abs(W - ref)) < 1e-13
+    basis.build(1)
+    assert basis.parameter_names() == ["Q0"] and np.max(np.abs(basis.eval([0.7]) - G(0.7))) < 1e-14
+    # the optimizer recovers a target of exactly that form (there are no exterior locals to absorb anything else)
+    td = TemplateOptimizer(basis=CircuitTemplateV2(base_gates=[RiSwapGate], no_exterior_1q=True, maximum_span_guess=3), objective=BasicCost(),
+                           training_restarts=24, seed=6).approximate_target_U(ref)
+    assert td.success_label == 1 and td.cycles == 3 and len(td.Xk) == 15

@@ -67,7 +67,7 @@ def test_bounds_follow_the_reference_semantics():
     assert (blo[idx[18]], bhi[idx[18]]) == (0.5, 0.5) and blo[idx[19]] == 0.0 and np.isinf(bhi[idx[19]])
     with pytest.raises(NotImplementedError):
         b.set_constraint(1.0)
-    for kw in (dict(no_exterior_1q=True), dict(param_vec_expand=[1, 2]), dict(use_polytopes=True), dict(n_qubits=3)):
+    for kw in (dict(param_vec_expand=[1, 2]), dict(use_polytopes=True), dict(n_qubits=3)):
         with pytest.raises(NotImplementedError):
             CircuitTemplateV2(**kw)
     with pytest.raises(NotImplementedError):
