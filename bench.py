@@ -126,13 +126,38 @@ def _cpu_one(args):
     return best, k, time.perf_counter() - t0, stats["nfev"]
 
 
+def usable_cores():
+    """(worker count, cgroup CPU quota or None): affinity mask, limited by cpu.max (cgroup v2) / cpu.cfs_quota_us (v1)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return min(n, 64), quota  # (64: beyond that the sample below would exceed the bench's time budget)
+
+
 def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool):
     import multiprocessing as mp
 
-    # every core the box gives this process (affinity mask when the platform has one): `value` is a whole-box number
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # every core the box GIVES this process: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box of
+    # the pool shows 256 CPUs and grants 16: 256 workers on that share ran 17x slower per core than 16) -- `value` is a
+    # whole-share number, `host_cpu_count` / `cpu_quota` say what the share is
+    cores, quota = usable_cores()
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, "1")  # one target per worker process: no BLAS thread pools on top
     if n_sample <= 0:
-        n_sample = 4 * cores  # every core busy for several targets
+        n_sample = 12 * cores  # every core busy for a dozen targets: ~15-25 s of wall time for the two passes
     with mp.get_context("spawn").Pool(cores) as pool:
         pool.map(abs, range(cores))  # workers up (interpreter + NumPy/SciPy import) before the clock starts
         t0 = time.perf_counter()
@@ -151,6 +176,7 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
         "unit": "decompositions/s",
         "cores": cores,
         "host_cpu_count": os.cpu_count(),
+        "cpu_quota": quota,
         "kind": "port",
         "sample": f"{n_sample} targets of the same workload{' (sweep basis %d only)' % SWEEP_CPU_BASIS if gname == 'cgsweep' else ''} "
         f"(SciPy BFGS + finite differences on the NumPy oracle, "

@@ -1,7 +1,8 @@
 """Cost functions (reference: src/slam/cost_function.py:117-145).
 
-``BasicCost`` is the only objective the HIP optimizer implements.  The class keeps the
-reference's interface; ``unitary_fidelity`` on two single matrices is the reference's own
+``BasicCost`` and ``SquareCost`` (the monotone map 0.8 (2 L - L^2) of BasicCost L, cost_function.py:169-173) are the
+objectives the HIP optimizer implements (``slam_set_cost``); anything else makes ``TemplateOptimizer`` raise the reference's
+"Unrecognized Cost Function".  The classes keep the reference's interface; ``unitary_fidelity`` on two single matrices is the reference's own
 one-line NumPy expression (used for spot checks and logging, never inside the optimizer loop --
 there the loss is fused into the HIP kernel).
 """

@@ -494,7 +494,7 @@ class TemplateOptimizer:
 
     def _found_coordinates(self, best_xs, best_cycles) -> np.ndarray:
         """c1c2c3 of the found circuits (optimizer.py:85,103): one batched CircuitTemplate.eval on the GPU
-        per distinct span, one batched eigen-decomposition on the host."""
+        per distinct span, the Weyl coordinates of the template unitaries on the device too (``slam_eval_c1c2c3``)."""
         n = len(best_xs)
         found = np.zeros((n, 3))
         ctx = runtime.get_context(self.devices[0])
