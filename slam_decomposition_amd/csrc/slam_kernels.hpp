@@ -830,6 +830,7 @@ __global__ void __launch_bounds__(NT) stage_epilogue_kernel(EpilogueArgs a) {
 __global__ void __launch_bounds__(256) stage_epilogue_grid_kernel(EpilogueArgs a) {
     __shared__ int32_t wave_counts[4];
     __shared__ int32_t s_base;
+    __shared__ int32_t kept_t[256];  // the workgroup's kept targets, in order
     const int tid = threadIdx.x;
     const int64_t n_in = a.r.ctl->n_active;
     const int64_t s = (int64_t)blockIdx.x * 256 + tid;
@@ -847,24 +848,23 @@ __global__ void __launch_bounds__(256) stage_epilogue_grid_kernel(EpilogueArgs a
     const int lane = tid & 63, w = tid >> 6;
     if (lane == 0) wave_counts[w] = __popcll(m);
     __syncthreads();
-    if (tid == 0) {
-        const int32_t tot = wave_counts[0] + wave_counts[1] + wave_counts[2] + wave_counts[3];
-        s_base = tot ? atomicAdd(&a.next->n_active, tot) : 0;
+    const int32_t tot = wave_counts[0] + wave_counts[1] + wave_counts[2] + wave_counts[3];
+    if (tid == 0) s_base = tot ? atomicAdd(&a.next->n_active, tot) : 0;
+    if (keep) {
+        int32_t r = __popcll(m & ((1ull << lane) - 1ull));
+        for (int i = 0; i < w; ++i) r += wave_counts[i];
+        kept_t[r] = t;
     }
     __syncthreads();
-    if (keep) {
-        int32_t o = s_base + __popcll(m & ((1ull << lane) - 1ull));
-        for (int i = 0; i < w; ++i) o += wave_counts[i];
-        a.active_out[o] = t;
-        a.solved[o] = 0;
-        const double2* src = reinterpret_cast<const double2*>(a.targets) + (int64_t)t * 16;
-        double2* dst = reinterpret_cast<double2*>(a.stage_targets) + (int64_t)o * 16;
-        double2 v[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = src[e];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dst[e] = v[e];
+    const int32_t base = s_base;
+    if (tid < tot) {
+        a.active_out[base + tid] = kept_t[tid];
+        a.solved[base + tid] = 0;
     }
+    // the kept targets' matrices, copied by the whole workgroup: 16 double2 per target, destination contiguous
+    const double2* src = reinterpret_cast<const double2*>(a.targets);
+    double2* dst = reinterpret_cast<double2*>(a.stage_targets) + (int64_t)base * 16;
+    for (int e = tid; e < tot * 16; e += 256) dst[e] = src[(int64_t)kept_t[e >> 4] * 16 + (e & 15)];
 }
 
 }  // namespace slamdev

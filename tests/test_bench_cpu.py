@@ -63,3 +63,21 @@ def test_launcher_path_with_one_rank_and_plain_path_agree():
     assert c.returncode != 0
     assert not [l for l in c.stdout.splitlines() if l.startswith("{")]
     assert "RCCL communicator failed" in c.stderr
+
+
+def test_two_ranks_under_torch_distributed_run():
+    """The driver's N > 1 launch line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with bench.py as one of the ranks (RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment, rendezvous path from the launcher's pid + port).  torch only launches; bench.py itself never imports it."""
+    pytest.importorskip("torch")
+    env = dict(os.environ, SLAM_BENCH_TEST_STUB=os.path.join(ROOT, "tests", "bench_stub.py"), SLAM_BENCH_COMM="file")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SLAM_COMM_FILE", "SLAM_COMM_DIR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--targets", "256",
+                        "--restarts", "4", "--no-cpu-baseline", "--no-secondary", "--per-span-steps", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["comm"] == "FileComm" and len(out["rank_devices"]) == 2 and out["steps"] == 3
