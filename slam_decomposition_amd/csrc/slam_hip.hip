@@ -1171,6 +1171,8 @@ int v2_launch_eval(slam_ctx* c, const V2GateMap* d_maps, const double* d_x, cons
 }
 
 struct V2Stage {
+    bool bounded;        // some parameter has a finite bound (or is fixed): projected steps; else plain BFGS
+    bool riswap_like;    // every gate of the span: only the angle a moves, phi_c = b = 0
     double exit_loss;
     const V2GateMap* d_maps;
     const int32_t* d_active;
@@ -1180,12 +1182,12 @@ struct V2Stage {
     const slam_opt_params* prm;
 };
 
-template <int K, int QN>
-int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
+template <int K, int QN, int GQ, bool FREE>
+int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
     const size_t lds = v2_lds_bytes<K, QN>();
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN, GQ, FREE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN>), kWave, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN, GQ, FREE>), kWave, lds));
     if (per_cu < 1) per_cu = 1;
     constexpr int n = CfgV2<K, QN>::N;
     MinimizeV2Args<K, QN> a{};
@@ -1220,6 +1222,7 @@ int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
     a.trace_cap = c->trace_cap;
     a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
     a.trace_x = c->trace_cap > 0 ? c->trace_x.as<double>() : nullptr;
+    a.bounded = sgt.bounded ? 1 : 0;
     // persistent wavefronts: never more than can be resident; every quad pulls items from the stage's queue
     const int64_t M = (int64_t)sgt.n_active * sgt.prm->restarts;
     int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
@@ -1230,10 +1233,20 @@ int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
         a.hmem = c->v2_hmem.as<float>();
     }
     HIP_TRY(hipEventRecord(c->ev_a[K], c->stream));
-    hipLaunchKernelGGL((minimize_v2_kernel<K, QN>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
+    hipLaunchKernelGGL((minimize_v2_kernel<K, QN, GQ, FREE>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_b[K], c->stream));
     return SLAM_OK;
+}
+
+// gate sub-class of the stage (slam_v2.hpp): one parameter per gate that only moves the angle a, phi_c = b = 0 (RiSwapGate)
+template <int K, int QN>
+int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
+    if constexpr (QN == 1 && K <= 3) {
+        if (sgt.riswap_like && !sgt.bounded) return v2_launch_minimize_gq<K, QN, 1, true>(c, sgt);  // RiSwapGate class, plain BFGS
+        if (sgt.riswap_like) return v2_launch_minimize_gq<K, QN, 1, false>(c, sgt);
+    }
+    return v2_launch_minimize_gq<K, QN, 0, false>(c, sgt);
 }
 
 // spans 1..3 with 1, 2 or 4 parameters per gate; spans 4 and 5 (the reference's default maximum_span_guess = 5,
@@ -1357,7 +1370,14 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     HIP_TRY(hipGetLastError());
     HIP_TRY(c->solved.reserve((size_t)n_active * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->solved.p, 0, (size_t)n_active * sizeof(int32_t), c->stream));
-    V2Stage sgt{exit_loss, d_maps, d_active, (int32_t)n_active, d_x0, c->v2_bounds.as<double>(), prm};
+    bool bounded = false;
+    for (int i = 0; i < n; ++i) bounded = bounded || std::isfinite(b[2 * n + i]) || std::isfinite(b[3 * n + i]);
+    bool riswap_like = c->v2_qn == 1;
+    for (int j = 0; j < k && riswap_like; ++j) {
+        const V2GateMap& gm = c->v2_gates_host[(size_t)gate_seq[j]];
+        riswap_like = gm.sel[1] < 0 && gm.sel[2] < 0 && gm.offset[1] == 0.0 && gm.offset[2] == 0.0;  // phi_c = 0, b = 0 (phi_g: no effect then)
+    }
+    V2Stage sgt{bounded, riswap_like, exit_loss, d_maps, d_active, (int32_t)n_active, d_x0, c->v2_bounds.as<double>(), prm};
     SLAM_V2_DISPATCH(v2_launch_minimize, c, sgt);
     if (rc) return rc;
     ReduceArgs r{};

@@ -106,6 +106,24 @@ __device__ __forceinline__ double cg_block_dot(double d, double er, double ei, d
     return (ulr * vlr - uli * vli) + (uhr * vhr - uhi * vhi);
 }
 
+// Gate sub-class GQ = 1 ("a only"): phi_c = 0, b = 0, phi_g irrelevant -- RiSwapGate(alpha), the gate class of most V2 callers
+// (decomp_trajectory.ipynb cell 5, basisv2.py:31).  The gate is the identity on |00>, |11> and [[c, -i s'], [-i s', c]] ... with
+// w = -i sin a on {|01>, |10>}: 8 real products per application instead of 32, one raw-angle derivative instead of four.
+__device__ __forceinline__ void ra_apply(double c, double sa, double (&Fr)[4], double (&Fi)[4]) {
+    const double lr = Fr[1], li = Fi[1], hr = Fr[2], hi = Fi[2];  // w = (0, -sa): the block is symmetric, column and row action agree
+    Fr[1] = fma(c, lr, sa * hi);
+    Fi[1] = fma(c, li, -(sa * hr));
+    Fr[2] = fma(c, hr, sa * li);
+    Fi[2] = fma(c, hi, -(sa * lr));
+}
+// Re( u (dG/da) h ) on the (1, 2) block: d = -sin a, e = -i cos a
+__device__ __forceinline__ double ra_dot(double c, double sa, double ulr, double uli, double uhr, double uhi, double hlr, double hli, double hhr,
+                                         double hhi) {
+    const double vlr = fma(c, hhi, -(sa * hlr)), vli = -fma(c, hhr, sa * hli);
+    const double vhr = fma(c, hli, -(sa * hhr)), vhi = -fma(c, hlr, sa * hhi);
+    return (ulr * vlr - uli * vli) + (uhr * vhr - uhi * vhi);
+}
+
 // bit a set: slot a of lane q (parameter 4a + q) is a theta of a U gate (index < NP and divisible by 3)
 template <int K, int QN>
 __device__ __forceinline__ int theta_slot_bits_v2(int q) {
@@ -124,7 +142,7 @@ __device__ __forceinline__ int theta_slot_bits_v2(int q) {
 //          seeds and guaranteed by the optimizer for its own points (HUGE_ARGS = true: the evaluation entry point, any x)
 //   maps   gate maps of G_1..G_K (wave-uniform, global memory)
 // ---------------------------------------------------------------------------------------------------------------
-template <int K, int QN, bool HUGE_ARGS>
+template <int K, int QN, bool HUGE_ARGS, int GQ = 0>
 __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA], const double* tcol, const V2GateMap* maps, double* xq,
                                              double2* fh, const double2* tbl, int q, int theta_bits, int cost_kind, double& fout,
                                              double (&gd)[CfgV2<K, QN>::NA], double (&Wr)[4], double (&Wi)[4]) {
@@ -236,7 +254,12 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         if (j < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) fh[(j * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);  // h_j
-            cg_col(load_cg(xq + C::OFF_GTRIG + 8 * j), Fr, Fi);
+            if constexpr (GQ == 1) {
+                const double2 ta = *reinterpret_cast<const double2*>(xq + C::OFF_GTRIG + 8 * j);
+                ra_apply(ta.x, ta.y, Fr, Fi);
+            } else {
+                cg_col(load_cg(xq + C::OFF_GTRIG + 8 * j), Fr, Fi);
+            }
         }
         // long templates: keep the scheduler from pulling every layer's table reads to the front (12 registers per layer)
         if constexpr (K >= 3) __builtin_amdgcn_sched_barrier(0);
@@ -301,7 +324,8 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
                 fr[r] = v.x; fi[r] = v.y;
             }
             g = load_cg(xq + C::OFF_GTRIG + 8 * (j - 1));
-            cg_col(g, fr, fi);
+            if constexpr (GQ == 1) ra_apply(g.ca, g.sa, fr, fi);
+            else cg_col(g, fr, fi);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fr[r] = (r == q) ? 1.0 : 0.0; fi[r] = 0.0; }
@@ -321,6 +345,10 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         if (j > 0) {
             // gate j: d loss / d raw angle = Re( u~ (dG / d angle) h_{j-1} ), summed over the four columns
             double d[4];
+            if constexpr (GQ == 1) {
+                park(C::OFF_DQ, 4 * (j - 1), ra_dot(g.ca, g.sa, Ur[1], Ui[1], Ur[2], Ui[2], Pr[1], Pi[1], Pr[2], Pi[2]));
+                ra_apply(g.ca, g.sa, Ur, Ui);  // u <- u~ G_j
+            } else {
             // a:     d = -sin a,  e = -i e^{i phi_c} cos a = cos a (sin phi_c, -cos phi_c)
             d[0] = cg_block_dot(-g.sa, g.ca * g.spc, -g.ca * g.cpc, Ur[1], Ui[1], Ur[2], Ui[2], Pr[1], Pi[1], Pr[2], Pi[2]);
             // phi_c: d = 0,       e = i w,  w = sin a (sin phi_c, -cos phi_c)  ->  i w = sin a (cos phi_c, sin phi_c)
@@ -330,6 +358,7 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
 #pragma unroll
             for (int r = 0; r < 4; ++r) park(C::OFF_DQ, 4 * (j - 1) + r, d[r]);
             cg_row(g, Ur, Ui);  // u <- u~ G_j
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { Hr[r] = Pr[r]; Hi[r] = Pi[r]; }
         }
@@ -347,7 +376,7 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         } else if (i < C::N) {
             const int j = (i - C::NP) / QN, m = (i - C::NP) - QN * j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < (GQ == 1 ? 1 : 4); ++r) {  // (GQ = 1: only the angle a depends on a parameter)
                 const double2 ps = *reinterpret_cast<const double2*>(xq + C::OFF_DQ + 2 * (4 * j + r));
                 if (maps[j].sel[r] == m) v = fma(maps[j].scale[r], ps.x + ps.y, v);
             }
@@ -540,7 +569,7 @@ struct HStore<NA, true> {
 // projected quasi-Newton minimisation, persistent wavefronts over the stage's restart-major work queue
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef SLAM_V2_WAVES
-#define SLAM_V2_WAVES(K, QN) 1
+#define SLAM_V2_WAVES(K, QN, GQ, FREE) (((K) == 1 && (GQ) == 1 && (FREE)) ? 2 : 1)
 #endif
 template <int K, int QN>
 struct MinimizeV2Args {
@@ -575,10 +604,13 @@ struct MinimizeV2Args {
     double* trace_loss;        // [M][trace_cap]
     double* trace_x;           // [M][trace_cap][n]
     int32_t trace_cap;
+    int32_t bounded;           // 0: every bound is (-inf, +inf) -- plain BFGS (optimizer.py:255): no projection, no blocked components
 };
 
-template <int K, int QN>
-__global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kernel(MinimizeV2Args<K, QN> args) {
+// FREE = true: instantiated for launches without any finite bound (plain BFGS): the projection code and the trial point kept
+// across the evaluation (2 NA registers) are compiled out; FREE = false handles both (args.bounded, wave-uniform)
+template <int K, int QN, int GQ = 0, bool FREE = false>
+__global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimize_v2_kernel(MinimizeV2Args<K, QN> args) {
     using C = CfgV2<K, QN>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -680,26 +712,38 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kerne
         // ---- 2. trial point: projection of x + alpha p onto the box; s = actual step
         double xt[NA], gt[NA];
         double gs = 0.0;  // slope of the linear model along the projected step s = xt - x
+        const bool bounded = !FREE && args.bounded != 0;  // wave-uniform
+        if (bounded) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const double2 b = bnd[4 * a + q];
-            xt[a] = fmin(fmax(fma(alpha, p[a], x[a]), b.x), b.y);
-            gs = fma(g[a], xt[a] - x[a], gs);
+            for (int a = 0; a < NA; ++a) {
+                const double2 b = bnd[4 * a + q];
+                xt[a] = fmin(fmax(fma(alpha, p[a], x[a]), b.x), b.y);
+                gs = fma(g[a], xt[a] - x[a], gs);
+            }
+            gs = quad_sum(gs);
+        } else {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
+            gs = alpha * gp;  // s = alpha p
         }
-        gs = quad_sum(gs);
         double ft, Wr[4], Wi[4];
-        eval_quad_v2<K, QN, false>(xt, tcol, args.maps, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
+        eval_quad_v2<K, QN, false, GQ>(xt, tcol, args.maps, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
         const bool active = live;
         const bool finite = isfinite(ft);
         // The quasi-Newton algebra lives in the subspace of the variables that can move: the gradient component of a
         // parameter that is fixed (lo == hi: a bounded-to-a-point Q, the theta / phi of an rz layer) or that sits on a
         // bound with the descent direction pointing out of the box is dropped.  (Left in, such a component -- d loss /
         // d alpha of a fixed gate is large -- enters y = g' - g with s = 0 there and poisons H.)
+        if (bounded) {
 #pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const double2 b = bnd[4 * a + q];
-            const bool blocked = (xt[a] <= b.x && gt[a] > 0.0) || (xt[a] >= b.y && gt[a] < 0.0);
-            gt[a] = (finite && !blocked) ? gt[a] : 0.0;
+            for (int a = 0; a < NA; ++a) {
+                const double2 b = bnd[4 * a + q];
+                const bool blocked = (xt[a] <= b.x && gt[a] > 0.0) || (xt[a] >= b.y && gt[a] < 0.0);
+                gt[a] = (finite && !blocked) ? gt[a] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) gt[a] = finite ? gt[a] : 0.0;
         }
         const bool armijo = finite && (ft <= f + kArmijoC1 * gs);
         const bool acc = active && (fresh ? finite : armijo);
@@ -713,7 +757,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kerne
         double sy = 0.0, yy = 0.0, ss = 0.0, sg = 0.0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const double sa = step ? xt[a] - x[a] : 0.0;
+            const double sa = FREE ? (step ? alpha : 0.0) * p[a] : (step ? xt[a] - x[a] : 0.0);
             const double ya = gt[a] - g[a];
             sy = fma(sa, ya, sy);
             yy = fma(ya, ya, yy);
@@ -744,7 +788,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kerne
             float s32[NA], w32[NA], v32[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const double sa = step ? xt[a] - x[a] : 0.0;
+                const double sa = FREE ? (step ? alpha : 0.0) * p[a] : (step ? xt[a] - x[a] : 0.0);
                 const double ua = fma(-fac, hg[a], qv[a]);
                 const double wa = cf * sa - rho * ua;  // rho = cf = 0 unless curv: w = v = 0, H unchanged
                 const double va = -rho * ua;
@@ -765,18 +809,24 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kerne
             grow = (step && too_short) ? fmin(grow * kGrowFactor, kGrowMax) : 1.0;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                const double sa = step ? xt[a] - x[a] : 0.0;
+                const double sa = FREE ? (step ? alpha : 0.0) * p[a] : (step ? xt[a] - x[a] : 0.0);
                 const double ua = fma(-fac, hg[a], qv[a]);
                 const double va = -rho * ua;
-                x[a] = xt[a];
+                x[a] = FREE ? fma(step ? alpha : 0.0, p[a], x[a]) : xt[a];  // (FREE: the same fma that formed the trial point)
                 g[a] = gt[a];
                 // H' g' = (H + hs1 I) g' + s (w.g') + v (s.g'); the direction is its negative, projected: no component may
                 // point out of the box
                 const double hn = qv[a] + sa * wg + va * sg;
                 hg[a] = hn;
-                const double2 b = bnd[4 * a + q];
-                const bool out = (x[a] <= b.x && hn > 0.0) || (x[a] >= b.y && hn < 0.0);
-                p[a] = out ? 0.0 : -hn;
+                p[a] = -hn;
+            }
+            if (bounded) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const double2 b = bnd[4 * a + q];
+                    const bool out = (x[a] <= b.x && hg[a] > 0.0) || (x[a] >= b.y && hg[a] < 0.0);
+                    p[a] = out ? 0.0 : p[a];
+                }
             }
             if (args.trace_loss) {  // wave-uniform: nothing when off
                 if (step && iters <= args.trace_cap) {
@@ -803,11 +853,16 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN)) minimize_v2_kerne
         {
             // projected gradient norm: components whose descent direction -g leaves the box do not count
             double m = 0.0;
+            if (bounded) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                const double2 b = bnd[4 * a + q];
-                const bool blocked = (x[a] <= b.x && g[a] > 0.0) || (x[a] >= b.y && g[a] < 0.0);
-                m = max_abs(m, blocked ? 0.0 : g[a]);
+                for (int a = 0; a < NA; ++a) {
+                    const double2 b = bnd[4 * a + q];
+                    const bool blocked = (x[a] <= b.x && g[a] > 0.0) || (x[a] >= b.y && g[a] < 0.0);
+                    m = max_abs(m, blocked ? 0.0 : g[a]);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) m = max_abs(m, g[a]);
             }
             gnorm = quad_max(m);
         }
