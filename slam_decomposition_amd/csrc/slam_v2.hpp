@@ -241,16 +241,28 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
 
     // ---- 2. forward; only the layer outputs h_j (j < K) are stored
     double Fr[4], Fi[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { Fr[r] = (r == q) ? 1.0 : 0.0; Fi[r] = 0.0; }
+    // this lane's unit vector e_q as real pairs per qubit: (1 - bit, bit)
+    const double e0[2] = {(q & 1) ? 0.0 : 1.0, (q & 1) ? 1.0 : 0.0};
+    const double e1[2] = {(q & 2) ? 0.0 : 1.0, (q & 2) ? 1.0 : 0.0};
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
         const U3t B = load_u3(xq, 6 * j);
         const U3t A = load_u3(xq, 6 * j + 3);
-        u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
-        u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
-        u3_col(A, Fr[0], Fi[0], Fr[2], Fi[2]);
-        u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
+        if (j == 0) {
+            // layer 0 acts on the unit vector e_q:  K_0 e_q = (A e_{q >> 1}) (x) (B e_{q & 1}) -- 40 operations instead of 64
+            double b0r, b0i, b1r, b1i, a0r, a0i, a1r, a1i;
+            u3_unit(B, e0[0], e0[1], b0r, b0i, b1r, b1i);
+            u3_unit(A, e1[0], e1[1], a0r, a0i, a1r, a1i);
+            Fr[0] = a0r * b0r - a0i * b0i; Fi[0] = a0r * b0i + a0i * b0r;
+            Fr[1] = a0r * b1r - a0i * b1i; Fi[1] = a0r * b1i + a0i * b1r;
+            Fr[2] = a1r * b0r - a1i * b0i; Fi[2] = a1r * b0i + a1i * b0r;
+            Fr[3] = a1r * b1r - a1i * b1i; Fi[3] = a1r * b1i + a1i * b1r;
+        } else {
+            u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
+            u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
+            u3_col(A, Fr[0], Fi[0], Fr[2], Fi[2]);
+            u3_col(A, Fr[1], Fi[1], Fr[3], Fi[3]);
+        }
         if (j < K) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) fh[(j * 4 + r) * kRow] = make_double2(Fr[r], Fi[r]);  // h_j
@@ -299,7 +311,7 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
         if ((q & 1) == 0) xq[off + 2 * i + (q >> 1)] = ps;
     };
 #pragma unroll
-    for (int j = K; j >= 0; --j) {
+    for (int j = K; j >= 1; --j) {
         const U3t B = load_u3(xq, 6 * j);
         const U3t A = load_u3(xq, 6 * j + 3);
         double part[6];
@@ -326,9 +338,6 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
             g = load_cg(xq + C::OFF_GTRIG + 8 * (j - 1));
             if constexpr (GQ == 1) ra_apply(g.ca, g.sa, fr, fi);
             else cg_col(g, fr, fi);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { fr[r] = (r == q) ? 1.0 : 0.0; fi[r] = 0.0; }
         }
         double th01, la01, th23, la23;
         dtheta_dlam_last(B, Ur[0], Ui[0], tB01r, tB01i, fr[0], fi[0], fr[1], fi[1], th01, la01);
@@ -363,6 +372,23 @@ __device__ __forceinline__ void eval_quad_v2(const double (&xd)[CfgV2<K, QN>::NA
             for (int r = 0; r < 4; ++r) { Hr[r] = Pr[r]; Hi[r] = Pi[r]; }
         }
         if constexpr (K >= 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        // layer 0 from its output side (slam_device.hpp:l0_gate_partials): Ur/Ui is the backward vector behind G_1
+        const U3t B = load_u3(xq, 0);
+        const U3t A = load_u3(xq, 3);
+        double b0r, b0i, b1r, b1i, tbr, tbi, a0r, a0i, a1r, a1i, tar, tai;
+        u3_unit_t(B, e0[0], e0[1], b0r, b0i, b1r, b1i, tbr, tbi);
+        u3_unit_t(A, e1[0], e1[1], a0r, a0i, a1r, a1i, tar, tai);
+        const double wB0r = (Ur[0] * a0r - Ui[0] * a0i) + (Ur[2] * a1r - Ui[2] * a1i), wB0i = (Ur[0] * a0i + Ui[0] * a0r) + (Ur[2] * a1i + Ui[2] * a1r);
+        const double wB1r = (Ur[1] * a0r - Ui[1] * a0i) + (Ur[3] * a1r - Ui[3] * a1i), wB1i = (Ur[1] * a0i + Ui[1] * a0r) + (Ur[3] * a1i + Ui[3] * a1r);
+        const double wA0r = (Ur[0] * b0r - Ui[0] * b0i) + (Ur[1] * b1r - Ui[1] * b1i), wA0i = (Ur[0] * b0i + Ui[0] * b0r) + (Ur[1] * b1i + Ui[1] * b1r);
+        const double wA1r = (Ur[2] * b0r - Ui[2] * b0i) + (Ur[3] * b1r - Ui[3] * b1i), wA1i = (Ur[2] * b0i + Ui[2] * b0r) + (Ur[3] * b1i + Ui[3] * b1r);
+        double part[6];
+        l0_gate_partials(B, e0[0], e0[1], wB0r, wB0i, wB1r, wB1i, b0r, b0i, b1r, b1i, tbr, tbi, part[0], part[1], part[2]);
+        l0_gate_partials(A, e1[0], e1[1], wA0r, wA0i, wA1r, wA1i, a0r, a0i, a1r, a1i, tar, tai, part[3], part[4], part[5]);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) park(C::OFF_GP, m, part[m]);
     }
     // ---- 5. gradient in the owners' slots
     lds_fence();
