@@ -305,8 +305,8 @@ def make_comm(rank: int, world: int, local_rank: int):
 def run_v2(rank: int, local_rank: int, steps: int = 12, warmup: int = 4, n_targets: int = 4096, restarts: int = 16, n_streams: int = 4):
     """secondary.v2: CircuitTemplateV2(base_gates=[RiSwapGate]) -- every gate instance with its own free alpha -- SquareCost,
     spans 1..3, `n_targets` Haar targets x `restarts` restarts per step.  The span loop is the one TemplateOptimizer runs for a
-    V2 template (optimizer.py:_run_batch_v2): one slam_v2_minimize_stage per template size over the targets still unsolved,
-    results of every stage on the host.  `n_streams` steps in flight (host thread + context + stream each), as the headline."""
+    V2 template (optimizer.py:_run_batch_v2 -> slam_v2_decompose_range): enqueued on the device as one chain of kernels per
+    step.  `n_streams` steps in flight (host thread + context + stream each), as the headline."""
     from slam_decomposition_amd import _ffi
     from slam_decomposition_amd.basisv2 import CircuitTemplateV2
     from slam_decomposition_amd.gates import RiSwapGate
@@ -327,18 +327,10 @@ def run_v2(rank: int, local_rank: int, steps: int = 12, warmup: int = 4, n_targe
         layouts[k] = basis.device_layout(k)
 
     def one_step(s: int, ctx):
-        best = np.full(n_targets, np.inf)
-        cyc = np.full(n_targets, -1, dtype=np.int32)
-        for k in (1, 2, 3):
-            act = (s * n_targets + np.nonzero(~(best < threshold))[0]).astype(np.int32)
-            if len(act) == 0:
-                break
-            _, _, ilo, ihi, blo, bhi = layouts[k]
-            out = ctx.v2_minimize_stage([0] * k, prm, threshold, ilo, ihi, blo, bhi, active=act, want_items=False)
-            loc = act - s * n_targets
-            better = (cyc[loc] < 0) | (out["best_loss"] < best[loc])  # optimizer.py:281-284
-            best[loc[better]] = out["best_loss"][better]
-            cyc[loc[better]] = k
+        # the whole span loop on the device (slam_v2_decompose_range): optimizer kernel + epilogue per template size, no host
+        # round trip in between; (best_loss, best_x, best_cycles) of the step's targets come back at the end
+        best, _, cyc = ctx.v2_decompose_range(s * n_targets, n_targets, 1, 3, [[0] * k for k in (1, 2, 3)], [layouts[k][2:6] for k in (1, 2, 3)],
+                                              prm, threshold)
         return best, cyc
 
     def run(step_ids):
@@ -386,7 +378,7 @@ def run_v2(rank: int, local_rank: int, steps: int = 12, warmup: int = 4, n_targe
         "evals_per_span": {str(k): ev[k] for k in (1, 2, 3)},
         "flops_per_eval": {str(k): f_eval_v2(k) for k in (1, 2, 3)},
         "flops_note": "F_eval(k) + 488 k: the fixed-gate count plus the gate-angle derivatives (bench.py:f_eval_v2)",
-        "span_loop": "host-driven: one slam_v2_minimize_stage per template size, results of every stage fetched",
+        "span_loop": "on the device (slam_v2_decompose_range): one chain of kernels per step, results fetched at its end",
     }
 
 

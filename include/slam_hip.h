@@ -343,6 +343,19 @@ int slam_v2_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const 
                            const slam_opt_params* params, double exit_loss, double* best_loss, double* best_x, int32_t* best_restart,
                            double* item_loss, int32_t* item_iters, int32_t* item_status, int32_t* item_evals);
 
+/* The whole span loop of a CircuitTemplateV2 (TemplateOptimizer._run, src/slam/optimizer.py:233-303, with a V2 template) for the
+ * resident targets [first, first + count), enqueued as one chain of kernels like slam_decompose_range: per span k = k_min..k_max the
+ * V2 optimizer kernel over the targets still above success_threshold (ordered early exit per params->flags), the reduction over
+ * restarts, the merge into the running best and the compaction -- no host round trip between the spans.
+ *   gate_seqs                        concatenated gate sequences (k_min entries, then k_min + 1, ...), indices into slam_v2_set_gates' table
+ *   init_lo/hi, bound_lo/hi          concatenated per span: n_k = 6 (k + 1) + n_params k entries for k = k_min, then k_min + 1, ...
+ *                                    (bound_* may be NULL: no bounds)
+ *   best_loss [count], best_cycles [count], best_x [count][n_kmax]: a target solved at span k has the n_k parameters of that
+ *   span's layout in the front of its row, zeros behind (any of the three may be NULL). */
+int slam_v2_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const double* init_lo,
+                            const double* init_hi, const double* bound_lo, const double* bound_hi, const slam_opt_params* params,
+                            double success_threshold, double* best_loss, double* best_x, int32_t* best_cycles);
+
 /* slam_v2_minimize_stage that also records every accepted iteration of every restart (use_callback=True for a
  * CircuitTemplateV2, src/slam/optimizer.py:217-224): trace_loss [M][trace_cap], trace_x [M][trace_cap][n] as
  * slam_minimize_stage_trace; rows no iteration reaches read as NaN. */

@@ -59,6 +59,7 @@ EXPORTED_SYMBOLS = (
     "slam_v2_eval_loss_grad",
     "slam_v2_minimize_stage",
     "slam_v2_minimize_stage_trace",
+    "slam_v2_decompose_range",
     "slam_set_cost",
     "slam_synchronize",
     "slam_get_stats",
@@ -177,6 +178,8 @@ def load_library() -> C.CDLL:
         lib.slam_v2_set_gates.argtypes = [P, C.POINTER(V2Gate), C.c_int32]
         lib.slam_v2_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P, P]
         lib.slam_v2_minimize_stage.argtypes = [P, C.c_int, P, P, C.c_int64, P, P, P, P, P, C.POINTER(OptParams), C.c_double] + [P] * 7
+        if hasattr(lib, "slam_v2_decompose_range"):
+            lib.slam_v2_decompose_range.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, P, P, P, P, C.POINTER(OptParams), C.c_double, P, P, P]
         if hasattr(lib, "slam_v2_minimize_stage_trace"):
             lib.slam_v2_minimize_stage_trace.argtypes = [P, C.c_int, P, P, C.c_int64, P, P, P, P, P, C.POINTER(OptParams), C.c_double, C.c_int32] + [P] * 8
     lib.slam_set_cost.argtypes = [P, C.c_int]
@@ -553,6 +556,25 @@ class Context:
             )
         )
         return out
+
+    def v2_decompose_range(self, first: int, count: int, k_min: int, k_max: int, gate_seqs, layouts, params: OptParams, threshold: float):
+        """The span loop of a V2 template on the device (``slam_v2_decompose_range``).  ``layouts[i]`` = (init_lo, init_hi, bound_lo,
+        bound_hi) of span ``k_min + i`` in device order.  Returns (best_loss [count], best_x [count, n_kmax], best_cycles [count]); a
+        row holds the n_k parameters of its target's span k in front, zeros behind."""
+        qn = self.v2_qn
+        nmax = 6 * (k_max + 1) + qn * k_max
+        gs = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int32) for g in gate_seqs]))
+        cat = [np.ascontiguousarray(np.concatenate([np.asarray(l[j], dtype=np.float64) for l in layouts])) for j in range(4)]
+        n_tot = sum(6 * (k + 1) + qn * k for k in range(k_min, k_max + 1))
+        if len(gs) != sum(range(k_min, k_max + 1)) or any(len(v) != n_tot for v in cat):
+            raise ValueError("gate_seqs / layouts do not match the span range")
+        best_loss = np.empty(count, dtype=np.float64)
+        best_x = np.empty((count, nmax), dtype=np.float64)
+        best_cycles = np.empty(count, dtype=np.int32)
+        _check(self._lib.slam_v2_decompose_range(self._h, int(first), int(count), int(k_min), int(k_max), _ptr(gs), _ptr(cat[0]), _ptr(cat[1]),
+                                                 _ptr(cat[2]), _ptr(cat[3]), C.byref(params), float(threshold), _ptr(best_loss), _ptr(best_x),
+                                                 _ptr(best_cycles)))
+        return best_loss, best_x, best_cycles
 
     def v2_minimize_stage_trace(self, gate_seq: Sequence[int], params: OptParams, exit_loss: float, trace_cap: int, init_lo, init_hi,
                                 bound_lo=None, bound_hi=None, active: Optional[np.ndarray] = None) -> dict:

@@ -480,8 +480,9 @@ int collect_stats(slam_ctx* c, int k_min, int k_max, const StageCtl* h_ctl, int 
     return SLAM_OK;
 }
 
-int ensure_results(slam_ctx* c, int k_max) {
-    const int nmax = 6 * (k_max + 1);
+int ensure_results_n(slam_ctx* c, int nmax);
+int ensure_results(slam_ctx* c, int k_max) { return ensure_results_n(c, 6 * (k_max + 1)); }
+int ensure_results_n(slam_ctx* c, int nmax) {
     const void* p0 = c->best_loss.p;
     const void* p1 = c->best_cycles.p;
     HIP_TRY(c->best_loss.reserve(c->n_targets * sizeof(double)));
@@ -511,10 +512,13 @@ struct FetchReq {
     bool staged = false;
 };
 
+int enqueue_fetch_n(slam_ctx* ctx, int nmax, int64_t first, int64_t count, FetchReq& fr);
 int enqueue_fetch(slam_ctx* ctx, int k_layout, int64_t first, int64_t count, FetchReq& fr) {
-    const int nmax = 6 * (k_layout + 1);
+    return enqueue_fetch_n(ctx, 6 * (k_layout + 1), first, count, fr);
+}
+int enqueue_fetch_n(slam_ctx* ctx, int nmax, int64_t first, int64_t count, FetchReq& fr) {
     if (ctx->result_nmax != nmax || ctx->n_targets <= 0)
-        return fail(SLAM_ERR_STATE, "no resident results for k_max = %d", k_layout);
+        return fail(SLAM_ERR_STATE, "no resident results with rows of %d parameters", nmax);
     if (first < 0 || count < 0 || first + count > ctx->n_targets)
         return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
     const size_t N = (size_t)count;
@@ -1173,6 +1177,8 @@ int v2_launch_eval(slam_ctx* c, const V2GateMap* d_maps, const double* d_x, cons
 struct V2Stage {
     bool bounded;        // some parameter has a finite bound (or is fixed): projected steps; else plain BFGS
     bool riswap_like;    // every gate of the span: only the angle a moves, phi_c = b = 0
+    bool count_on_device = false;  // the kernel reads the stage's target count from its control block (n_active = upper bound)
+    int k = 0;
     double exit_loss;
     const V2GateMap* d_maps;
     const int32_t* d_active;
@@ -1193,7 +1199,7 @@ int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
     MinimizeV2Args<K, QN> a{};
     a.targets = c->targets.as<double>();
     a.active = sgt.d_active;
-    a.n_active = sgt.n_active;
+    a.n_active = sgt.count_on_device ? -1 : sgt.n_active;
     a.restarts = sgt.prm->restarts;
     a.x0 = sgt.d_x0;
     a.init_lo = sgt.d_bounds;
@@ -1377,7 +1383,7 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
         const V2GateMap& gm = c->v2_gates_host[(size_t)gate_seq[j]];
         riswap_like = gm.sel[1] < 0 && gm.sel[2] < 0 && gm.offset[1] == 0.0 && gm.offset[2] == 0.0;  // phi_c = 0, b = 0 (phi_g: no effect then)
     }
-    V2Stage sgt{bounded, riswap_like, exit_loss, d_maps, d_active, (int32_t)n_active, d_x0, c->v2_bounds.as<double>(), prm};
+    V2Stage sgt{bounded, riswap_like, false, k, exit_loss, d_maps, d_active, (int32_t)n_active, d_x0, c->v2_bounds.as<double>(), prm};
     SLAM_V2_DISPATCH(v2_launch_minimize, c, sgt);
     if (rc) return rc;
     ReduceArgs r{};
@@ -1408,9 +1414,160 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     return collect_stats(c, k, k, c->h_ctl, prm->restarts);
 }
 
+// The span loop of a CircuitTemplateV2 (optimizer.py:233-303) enqueued as ONE chain, like decompose_body: results reset +
+// first stage's active list, then per span the V2 optimizer kernel (target count from the device) and the shared epilogue
+// kernel (reduction over restarts, merge into the running best -- rows of n_k parameters into rows of nmax --, compaction).
+int v2_decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const double* init_lo,
+                      const double* init_hi, const double* bound_lo, const double* bound_hi, const slam_opt_params* prm,
+                      double success_threshold, FetchReq* fetch) {
+    if (!c) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets: call slam_set_targets first");
+    if (c->v2_gates_host.empty()) return fail(SLAM_ERR_STATE, "no parametrised gates: call slam_v2_set_gates first");
+    if (k_min < 1 || k_max < k_min || k_max > SLAM_V2_MAX_SPAN) return fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates support spans 1..%d (got [%d, %d])", SLAM_V2_MAX_SPAN, k_min, k_max);
+    int rc = check_params(prm);
+    if (rc) return rc;
+    if (!gate_seqs || !init_lo || !init_hi) return fail(SLAM_ERR_INVALID, "gate_seqs, init_lo and init_hi must be non-NULL");
+    if (first < 0 || count <= 0 || first + count > c->n_targets) return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    const int qn = c->v2_qn;
+    const int nmax = 6 * (k_max + 1) + qn * k_max;
+    // per span: gate maps and (init_lo | init_hi | bound_lo | bound_hi), staged once
+    std::vector<V2GateMap> maps;
+    std::vector<double> b;
+    std::vector<size_t> map_off, b_off;
+    std::vector<bool> bounded_k, riswap_k;
+    {
+        const int32_t* gs = gate_seqs;
+        size_t po = 0;  // offset into the caller's concatenated per-parameter arrays
+        for (int k = k_min; k <= k_max; ++k) {
+            const int n = 6 * (k + 1) + qn * k;
+            map_off.push_back(maps.size());
+            bool rl = qn == 1;
+            for (int j = 0; j < k; ++j) {
+                if (gs[j] < 0 || gs[j] >= (int)c->v2_gates_host.size()) return fail(SLAM_ERR_INVALID, "gate_seqs: index %d outside the parametrised gate table", gs[j]);
+                const V2GateMap& gm = c->v2_gates_host[(size_t)gs[j]];
+                maps.push_back(gm);
+                rl = rl && gm.sel[1] < 0 && gm.sel[2] < 0 && gm.offset[1] == 0.0 && gm.offset[2] == 0.0;
+            }
+            riswap_k.push_back(rl);
+            b_off.push_back(b.size());
+            bool bd = false;
+            for (int part = 0; part < 4; ++part)
+                for (int i = 0; i < n; ++i) {
+                    double v;
+                    if (part == 0) v = init_lo[po + i];
+                    else if (part == 1) v = init_hi[po + i];
+                    else if (part == 2) v = bound_lo ? bound_lo[po + i] : -INFINITY;
+                    else v = bound_hi ? bound_hi[po + i] : INFINITY;
+                    if (part < 2 && !std::isfinite(v)) return fail(SLAM_ERR_INVALID, "start range of parameter %d at span %d must be finite", i, k);
+                    if (part >= 2 && std::isfinite(v)) bd = true;
+                    b.push_back(v);
+                }
+            for (int i = 0; i < n; ++i) {
+                if (!(init_lo[po + i] <= init_hi[po + i])) return fail(SLAM_ERR_INVALID, "start range of parameter %d at span %d: lo > hi", i, k);
+                if (bound_lo && bound_hi && !(bound_lo[po + i] <= bound_hi[po + i])) return fail(SLAM_ERR_INVALID, "bounds of parameter %d at span %d: lo > hi", i, k);
+            }
+            bounded_k.push_back(bd);
+            po += (size_t)n;
+            gs += k;
+        }
+    }
+    HIP_TRY(c->v2_maps.reserve(sizeof(V2GateMap) * maps.size()));
+    HIP_TRY(c->v2_bounds.reserve(b.size() * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->v2_maps.p, maps.data(), sizeof(V2GateMap) * maps.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->v2_bounds.p, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // local buffers
+    const int64_t N = count, M = N * (int64_t)prm->restarts;
+    if (M > 0x7fff0000LL) return fail(SLAM_ERR_INVALID, "too many work items in one stage (%lld)", (long long)M);
+    rc = ensure_results_n(c, nmax);
+    if (rc) return rc;
+    HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
+    HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));
+    HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
+    HIP_TRY(c->item_x.reserve(M * nmax * sizeof(double)));
+    HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->item_acc.reserve(M * sizeof(int32_t)));
+    HIP_TRY(c->stage_loss.reserve(N * sizeof(double)));
+    HIP_TRY(c->stage_x.reserve(N * nmax * sizeof(double)));
+    HIP_TRY(c->stage_restart.reserve(N * sizeof(int32_t)));
+    HIP_TRY(c->solved.reserve(N * sizeof(int32_t)));
+    HIP_TRY(c->stage_targets.reserve((size_t)N * 32 * sizeof(double)));
+    HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+    hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)((N * 16 + 255) / 256)), dim3(256), 0, c->stream, c->best_loss.as<double>(),
+                       c->best_cycles.as<int32_t>(), c->span_loss.as<double>(), c->active.as<int32_t>(), first, N, stage_ctl(c, k_min),
+                       c->targets.as<double>(), c->stage_targets.as<double>(), c->solved.as<int32_t>(), c->counters.as<StageCtl>(),
+                       (int32_t)(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2) / 8), 0);
+    HIP_TRY(hipGetLastError());
+    DevBuf* cur = &c->active;
+    DevBuf* nxt = &c->active2;
+    for (int k = k_min, si = 0; k <= k_max; ++k, ++si) {
+        const int n = 6 * (k + 1) + qn * k;
+        V2Stage sgt{bounded_k[(size_t)si], riswap_k[(size_t)si], true, k, success_threshold, c->v2_maps.as<V2GateMap>() + map_off[(size_t)si],
+                    cur->as<int32_t>(), (int32_t)N, nullptr, c->v2_bounds.as<double>() + b_off[(size_t)si], prm};
+        SLAM_V2_DISPATCH(v2_launch_minimize, c, sgt);
+        if (rc) return rc;
+        EpilogueArgs e{};
+        e.r.item_loss = c->item_loss.as<double>();
+        e.r.item_x = c->item_x.as<double>();
+        e.r.item_evals = c->item_evals.as<int32_t>();
+        e.r.item_acc = c->item_acc.as<int32_t>();
+        e.r.item_status = c->item_status.as<int32_t>();
+        e.r.exit_loss = success_threshold;
+        e.r.ordered = 1;
+        e.r.ctl = stage_ctl(c, k);
+        e.r.restarts = prm->restarts;
+        e.r.n = n;
+        e.r.stage_loss = c->stage_loss.as<double>();
+        e.r.stage_x = c->stage_x.as<double>();
+        e.r.stage_restart = c->stage_restart.as<int32_t>();
+        e.r.active = cur->as<int32_t>();
+        e.r.nmax = nmax;
+        e.r.k = k;
+        e.r.best_loss = c->best_loss.as<double>();
+        e.r.best_x = c->best_x.as<double>();
+        e.r.best_cycles = c->best_cycles.as<int32_t>();
+        e.r.span_loss = c->span_loss.as<double>();
+        e.has_next = k < k_max ? 1 : 0;
+        e.threshold = success_threshold;
+        e.active_out = nxt->as<int32_t>();
+        e.next = stage_ctl(c, k + 1);
+        e.targets = c->targets.as<double>();
+        e.stage_targets = c->stage_targets.as<double>();
+        e.solved = c->solved.as<int32_t>();
+        if (N <= 2048) hipLaunchKernelGGL(stage_epilogue_kernel<256>, dim3(1), dim3(256), 0, c->stream, e);
+        else if (N <= kEpilogueMaxTargets) hipLaunchKernelGGL(stage_epilogue_kernel<1024>, dim3(1), dim3(1024), 0, c->stream, e);
+        else hipLaunchKernelGGL(stage_epilogue_grid_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, e);
+        HIP_TRY(hipGetLastError());
+        DevBuf* t = cur; cur = nxt; nxt = t;
+    }
+    HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    if (fetch) {
+        rc = enqueue_fetch_n(c, nmax, first, count, *fetch);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_ctl, c->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_done, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_done));
+    if (fetch) finish_fetch(c, *fetch);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    c->stats.total_ms = ms;
+    return collect_stats(c, k_min, k_max, c->h_ctl, prm->restarts);
+}
+
 }  // namespace
 
 extern "C" {
+
+int slam_v2_decompose_range(slam_ctx* ctx, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const double* init_lo,
+                            const double* init_hi, const double* bound_lo, const double* bound_hi, const slam_opt_params* params,
+                            double success_threshold, double* best_loss, double* best_x, int32_t* best_cycles) {
+    FetchReq fr{best_loss, best_x, best_cycles};
+    return drained(ctx, v2_decompose_body(ctx, first, count, k_min, k_max, gate_seqs, init_lo, init_hi, bound_lo, bound_hi, params, success_threshold,
+                                          (best_loss || best_x || best_cycles) ? &fr : nullptr));
+}
 
 int slam_v2_set_gates(slam_ctx* ctx, const slam_v2_gate* gates, int32_t n_gates) {
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");

@@ -651,7 +651,9 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         bnd[i] = (i < C::N) ? make_double2(args.bound_lo[i], args.bound_hi[i]) : make_double2(0.0, 0.0);
     lds_fence();
     const int theta_bits = theta_slot_bits_v2<K, QN>(q);
-    const unsigned n_act = (unsigned)args.n_active;
+    // n_active < 0: the stage's target count is produced on the device by the previous stage's compaction (span loop enqueued
+    // without host round trips, as for the fixed-gate path)
+    const unsigned n_act = (unsigned)(args.n_active < 0 ? args.ctl->n_active : args.n_active);
     const unsigned n_items = n_act * (unsigned)args.restarts;
     const bool early = (args.flags & 1u) != 0;
 

@@ -306,6 +306,23 @@ class TemplateOptimizer:
                 ctx.reset_stats()
                 sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
                                     flags=prm.flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, target_base=first)
+                if ks == list(range(ks[0], ks[-1] + 1)):
+                    # the usual case, a run of template sizes: the whole span loop as one chain of kernels on the device
+                    try:
+                        bl, bx, bc = ctx.v2_decompose_range(0, count, ks[0], ks[-1], [layouts[k][0] for k in ks],
+                                                            [layouts[k][3:7] for k in ks], sp, self.success_threshold)
+                    except _ffi.SlamHipError as exc:
+                        if exc.code == -3:
+                            raise NotImplementedError(str(exc)) from exc
+                        raise
+                    xs = [None] * count
+                    for k in np.unique(bc):
+                        idx = layouts[int(k)][2]
+                        sel = np.nonzero(bc == k)[0]
+                        block = np.ascontiguousarray(bx[sel][:, idx])  # user parameters (index order) of the span's device layout
+                        for i, row in zip(sel.tolist(), block):
+                            xs[i] = row
+                    return (bl, xs, bc.astype(np.int32), ctx.fetch_span_losses(0, count)), ctx.stats()
                 best = np.full(count, np.inf)
                 best_x = [None] * count
                 best_k = np.full(count, -1, dtype=np.int32)

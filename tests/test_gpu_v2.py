@@ -356,3 +356,46 @@ def test_v2_no_exterior_1q_template():
     td = TemplateOptimizer(basis=CircuitTemplateV2(base_gates=[RiSwapGate], no_exterior_1q=True, maximum_span_guess=3), objective=BasicCost(),
                            training_restarts=24, seed=6).approximate_target_U(ref)
     assert td.success_label == 1 and td.cycles == 3 and len(td.Xk) == 15
+
+
+def test_v2_device_span_loop_equals_the_host_driven_one(hip_ctx):
+    """``slam_v2_decompose_range`` (the V2 span loop as one chain of kernels, round 3) against the loop driven from the host with
+    one ``slam_v2_minimize_stage`` per template size over the unsolved targets: same seeds, ordered early exit -> the same
+    (loss, parameters, cycles) bit for bit, for a bounded and an unbounded template."""
+    N, R = 48, 6
+    targets = o.haar_batch(N, seed0=1234)
+    for bounded in (False, True):
+        basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=3)
+        lay = {}
+        for k in (1, 2, 3):
+            basis.build(k)
+            if bounded:
+                for name in basis.parameter_names():
+                    if "Q" in name:
+                        basis.add_bound(name, max=0.5, min=0.0)  # sqrt(iSWAP) fragments: spans up to 3 are needed
+            lay[k] = basis.device_layout(k)
+        hip_ctx.set_targets(targets)
+        hip_ctx.v2_set_gates(basis._gate_maps)
+        hip_ctx.set_cost(_ffi.COST_BASIC)
+        prm = _ffi.OptParams(restarts=R, seed=77, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+        thr = 1e-10
+        best = np.full(N, np.inf)
+        cyc = np.full(N, -1, dtype=np.int32)
+        bx = np.zeros((N, lay[3][0]))
+        for k in (1, 2, 3):
+            act = np.nonzero(~(best < thr))[0].astype(np.int32)
+            if not len(act):
+                break
+            out = hip_ctx.v2_minimize_stage([0] * k, prm, thr, *lay[k][2:6], active=act, want_items=False)
+            better = (cyc[act] < 0) | (out["best_loss"] < best[act])
+            for j, t in enumerate(act):
+                if better[j]:
+                    best[t], cyc[t] = out["best_loss"][j], k
+                    bx[t] = 0.0
+                    bx[t, : lay[k][0]] = out["best_x"][j]
+        dl, dx, dc = hip_ctx.v2_decompose_range(0, N, 1, 3, [[0] * k for k in (1, 2, 3)], [lay[k][2:6] for k in (1, 2, 3)], prm, thr)
+        assert np.array_equal(dc, cyc) and np.array_equal(dl, best) and np.array_equal(dx, bx)
+        assert np.all(dl < 1e-10) and (len(np.unique(dc)) >= 2)
+    # a window of the resident batch, and the optimizer path built on it
+    wl, _, wc = hip_ctx.v2_decompose_range(16, 8, 1, 3, [[0] * k for k in (1, 2, 3)], [lay[k][2:6] for k in (1, 2, 3)], prm, thr)
+    assert np.array_equal(wl, dl[16:24]) and np.array_equal(wc, dc[16:24])
