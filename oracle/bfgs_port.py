@@ -33,6 +33,7 @@ STALL_GNORM = 1e-5
 WOLFE_C2 = 0.9     # an accepted step whose slope along p fell by less than (1 - c2) was too short ...
 GROW_FACTOR = 4.0  # ... the next first trial step is this much longer (compounding while it keeps happening)
 GROW_MAX = 1048576.0
+RESTART_PERIOD = 128  # every so many accepted iterations the quasi-Newton metric starts over from the identity (see below)
 
 
 def minimize_port(
@@ -124,6 +125,16 @@ def minimize_port(
             p = pn
             grow = min(grow * GROW_FACTOR, GROW_MAX) if short else 1.0
             alpha = min(grow, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
+            if it % RESTART_PERIOD == 0:
+                # Periodic restart.  One item in 1e3..1e5 ends up with a metric that has stopped learning (steps nearly
+                # orthogonal to the gradient on a plateau: 400..1300 iterations where SciPy's BFGS needs 50..170 from the
+                # same start); restarted from the identity it is through in ~40 more.  Items this long are past the 99th
+                # percentile of the iteration counts, so the mean does not notice -- the stage's critical path does.
+                H = np.eye(n, dtype=h_dtype)
+                hs1 = 0.0
+                scaled = False
+                p = -g
+                alpha = min(grow, STEP_MAX / max(np.sqrt(p @ p), 1e-300))
         else:
             # safeguarded quadratic interpolation backtrack
             denom = 2.0 * (ft - f - gp * alpha)

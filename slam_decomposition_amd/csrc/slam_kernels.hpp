@@ -6,13 +6,22 @@ namespace slamdev {
 
 constexpr double kArmijoC1 = 1e-4;
 constexpr int kMaxBacktrack = 20;
-constexpr double kStepMax = 2.0;  // cap on |alpha p|_2 of the first trial step (parameters are angles)
+#ifndef SLAM_STEP_MAX
+#define SLAM_STEP_MAX 2.0
+#endif
+constexpr double kStepMax = SLAM_STEP_MAX;  // cap on |alpha p|_2 of the first trial step (parameters are angles)
 constexpr double kCurvEps = 1e-10;
 constexpr double kStallDf = 1e-15;
 constexpr double kStallGnorm = 1e-5;
 constexpr double kWolfeC2 = 0.9;      // an accepted step whose slope along p fell by less than (1 - c2) was too short:
 constexpr double kGrowFactor = 4.0;   // the next first trial step is this much longer (compounding while it keeps
 constexpr double kGrowMax = 1048576.0;  // happening).  Covers negative curvature, where the update is skipped.
+// Every kRestartPeriod accepted iterations an item's quasi-Newton metric starts over from the identity.  One item in 1e3..1e5
+// ends up with a metric that has stopped learning (steps nearly orthogonal to the gradient on a plateau of the loss): 400..1300
+// evaluations where SciPy's BFGS needs 50..170 from the same start, and ONE such item sets the duration of its whole stage
+// (CNOT k = 2, 1 M items: pct 99.99 of the evaluation counts 197, maximum 1309).  Restarted, it is through in ~40 more.  128 is
+// past the 99th percentile of the iteration counts at every span: the mean does not notice.  (oracle/bfgs_port.py: RESTART_PERIOD)
+constexpr int kRestartPeriod = 128;
 
 enum : int { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_NONFINITE = 3, ST_STALLED = 4, ST_PREEMPTED = 5 };
 
@@ -539,16 +548,19 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
             if (nback > kMaxBacktrack) { status = (gnorm < kStallGnorm) ? ST_STALLED : ST_LINESEARCH; done = true; }
         }
         fresh = false;
-        // not a descent direction (H lost positive definiteness numerically): restart from steepest descent
-        const bool reset = active && !done && !(gp < 0.0);
+        // not a descent direction (H lost positive definiteness numerically), or the periodic restart: steepest descent again
+        const bool periodic = step && !done && ((iters & (kRestartPeriod - 1)) == 0);
+        const bool reset = active && !done && (!(gp < 0.0) || periodic);
         if (__any(reset)) {
             h_set_identity_where<NA>(H, q, reset);
             hs1 = reset ? 0.0 : hs1;
+            scaled = periodic ? false : scaled;  // the restarted metric gets its initial scaling again
 #pragma unroll
             for (int a = 0; a < NA; ++a) p[a] = reset ? -g[a] : p[a];
             const double gg2 = qdot<NA>(g, g);
             gp = reset ? -gg2 : gp;
             pp = reset ? gg2 : pp;
+            alpha = periodic ? ((gg2 > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(gg2)) : grow) : alpha;
         }
         // ---- 5. early exit across the restarts of one target (optimizer.py:287-295)
         if (args.flags & 1u) {

@@ -905,10 +905,12 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
             if (nback > kMaxBacktrack) { status = (gnorm < kStallGnorm) ? ST_STALLED : ST_LINESEARCH; done = true; }
         }
         fresh = false;
-        const bool reset = active && !done && !(gp < 0.0);
+        const bool periodic = step && !done && ((iters & (kRestartPeriod - 1)) == 0);  // periodic restart of the metric (slam_kernels.hpp)
+        const bool reset = active && !done && (!(gp < 0.0) || periodic);
         if (__any(reset)) {
             H.set_identity_where(q, reset);
             hs1 = reset ? 0.0 : hs1;
+            scaled = periodic ? false : scaled;
             double gg2 = 0.0;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
@@ -921,6 +923,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
             }
             gg2 = quad_sum(gg2);
             gp = reset ? gg2 : gp;
+            alpha = periodic ? ((gg2 < -1e-300) ? fmin(grow, kStepMax * fast_rsqrt(-gg2)) : grow) : alpha;  // (-gg2 = |projected g|^2)
             // nothing left to move along: a KKT point of the box-constrained problem
             if (reset && !(gg2 < 0.0)) { status = ST_CONVERGED; done = true; }
         }
