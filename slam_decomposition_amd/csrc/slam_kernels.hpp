@@ -21,7 +21,10 @@ constexpr double kGrowMax = 1048576.0;  // happening).  Covers negative curvatur
 // evaluations where SciPy's BFGS needs 50..170 from the same start, and ONE such item sets the duration of its whole stage
 // (CNOT k = 2, 1 M items: pct 99.99 of the evaluation counts 197, maximum 1309).  Restarted, it is through in ~40 more.  128 is
 // past the 99th percentile of the iteration counts at every span: the mean does not notice.  (oracle/bfgs_port.py: RESTART_PERIOD)
-constexpr int kRestartPeriod = 128;
+#ifndef SLAM_RESTART_PERIOD
+#define SLAM_RESTART_PERIOD 128
+#endif
+constexpr int kRestartPeriod = SLAM_RESTART_PERIOD;
 
 enum : int { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_NONFINITE = 3, ST_STALLED = 4, ST_PREEMPTED = 5 };
 
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
         }
         fresh = false;
         // not a descent direction (H lost positive definiteness numerically), or the periodic restart: steepest descent again
-        const bool periodic = step && !done && ((iters & (kRestartPeriod - 1)) == 0);
+        const bool periodic = step && !done && ((kRestartPeriod & (kRestartPeriod - 1)) == 0 ? ((iters & (kRestartPeriod - 1)) == 0) : (iters % kRestartPeriod == 0));
         const bool reset = active && !done && (!(gp < 0.0) || periodic);
         if (__any(reset)) {
             h_set_identity_where<NA>(H, q, reset);

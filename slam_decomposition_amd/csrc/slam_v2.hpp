@@ -905,7 +905,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
             if (nback > kMaxBacktrack) { status = (gnorm < kStallGnorm) ? ST_STALLED : ST_LINESEARCH; done = true; }
         }
         fresh = false;
-        const bool periodic = step && !done && ((iters & (kRestartPeriod - 1)) == 0);  // periodic restart of the metric (slam_kernels.hpp)
+        const bool periodic = step && !done && ((kRestartPeriod & (kRestartPeriod - 1)) == 0 ? ((iters & (kRestartPeriod - 1)) == 0) : (iters % kRestartPeriod == 0));  // periodic restart of the metric (slam_kernels.hpp)
         const bool reset = active && !done && (!(gp < 0.0) || periodic);
         if (__any(reset)) {
             H.set_identity_where(q, reset);
