@@ -794,8 +794,8 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         }
         quad_sum2(sy, yy);
         quad_sum2(ss, sg);
-        const bool curv = step && sy > 0.0 && (sy * sy > (kCurvEps * kCurvEps) * (ss * yy));
         const bool too_short = sy < (1.0 - kWolfeC2) * (-gs);
+        const bool curv = step && !too_short && sy > 0.0 && (sy * sy > (kCurvEps * kCurvEps) * (ss * yy));
         const bool first = curv && !scaled;
         scaled = scaled || curv;
         // first update of an item: the initial inverse Hessian (the identity then) scaled by s.y / y.y, as the scalar hs1
