@@ -563,8 +563,16 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
 
     # set-up, not a step: every context runs one batch once so that its device buffers exist and its
     # kernels are loaded (with 8 contexts, W < 8 warm-up steps would leave some of them cold)
-    if n_streams > 1:
-        prime = [threading.Thread(target=one_step, args=(0, c)) for c in ctxs]
+    def prime_one(c):
+        if group > 1:
+            # the grouped call's work buffers are sized by its item count: allocate them here, not inside the timed region
+            # (W < group warm-up steps would make a smaller call), and bring the device out of its idle clock state
+            c.decompose_range(0, min(group, total_steps) * n_per_step, 1, 3, gate_seqs, prm, threshold)
+        else:
+            one_step(0, c)
+
+    if n_streams > 1 or group > 1:
+        prime = [threading.Thread(target=prime_one, args=(c,)) for c in ctxs]
         for t in prime:
             t.start()
         for t in prime:

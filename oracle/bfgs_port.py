@@ -30,8 +30,8 @@ STEP_MAX = 2.0  # cap on |alpha p|_2 of the first trial step (parameters are ang
 CURV_EPS = 1e-10
 STALL_DF = 1e-15
 STALL_GNORM = 1e-5
-WOLFE_C2 = 0.8     # an accepted step whose slope along p fell by less than (1 - c2) was too short: no metric update from it ...
-GROW_FACTOR = 4.0  # ... the next first trial step is this much longer (compounding while it keeps happening)
+WOLFE_C2 = 0.7     # an accepted step whose slope along p fell by less than (1 - c2) was too short: no metric update from it ...
+GROW_FACTOR = 8.0  # ... the next first trial step is this much longer (compounding while it keeps happening)
 GROW_MAX = 1048576.0
 RESTART_PERIOD = 128  # every so many accepted iterations the quasi-Newton metric starts over from the identity (see below)
 
