@@ -672,65 +672,99 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
     H.set_identity_where(q, true);
     bool exhausted = false;  // wave-uniform
     unsigned rounds = 0;
+    // chunk of queue positions a wave takes per atomicAdd: big chunks mean few atomics, small batches need every wave busy
+    const unsigned per_wave = n_items / gridDim.x;
+    const unsigned kChunk = per_wave >= 256u ? 64u : (per_wave >= 64u ? 32u : 16u);
+    unsigned cur_next = 0, cur_end = 0;  // wave-uniform
+    unsigned pre_base = 0;               // lane 0: base of the prefetched chunk
+    if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
 
     while (true) {
-        // ---- 1. idle quads pull the next queue positions (restart-major: position = restart * n_active + slot)
+        // ---- 1. idle quads pull the next queue positions (restart-major: position = restart * n_active + slot).
+        // As in minimize_kernel: positions come in wave-private chunks (one atomicAdd per chunk, the next one requested
+        // while the current one is consumed) and are scanned 64 at a time, so that the positions a successful sibling
+        // restart has made void -- 15 of 16 at k = 2, 3 for the RiSwap class -- cost one flag load per window instead of
+        // one atomic round trip each (first version: 0.5 G evaluations/s at k = 2 against 3.8 at k = 1: the stage was
+        // bound by its single counter).
         bool taken = false;
         while (!exhausted && __any(!live)) {
+            if (cur_next >= cur_end) {
+                const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)pre_base);
+                if (b >= n_items) { exhausted = true; break; }
+                cur_next = b;
+                cur_end = (b + kChunk < n_items) ? b + kChunk : n_items;
+                if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
+            }
+            const unsigned wlen = (cur_end - cur_next < (unsigned)kWave) ? cur_end - cur_next : (unsigned)kWave;
+            const bool valid = (unsigned)lane < wlen;
+            const unsigned pos = cur_next + (unsigned)lane;
+            const unsigned prs = pos / n_act, psl = pos - prs * n_act;
+            bool skipv = false;
+            if (early && valid) {
+                // ordered early exit: dropped iff a LOWER-index restart of the target has already succeeded
+                const int fl = __hip_atomic_load(&args.solved[psl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                skipv = fl > args.restarts - (int)prs;
+            }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long avail = __ballot(valid && !skipv);
             const unsigned long long idle = __ballot(!live && q == 0);
-            const int n_idle = __popcll(idle);
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&args.ctl->work_counter, (unsigned)n_idle);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (base >= n_items) { exhausted = true; break; }
-            const int qrank = __popcll(idle & ((1ull << (lane & ~3)) - 1ull));
-            const unsigned pos = base + (unsigned)qrank;
-            if (!live && pos < n_items) {
-                const unsigned rs = pos / n_act, sl = pos - rs * n_act;
+            const int n_av = __popcll(avail), n_idle_now = __popcll(idle);
+            const int n_take = n_av < n_idle_now ? n_av : n_idle_now;
+            const int myrank = __popcll(avail & lt);
+            const bool handed = valid && !skipv && myrank < n_take;
+            const unsigned long long handed_mask = __ballot(handed);
+            // the window is consumed up to the last position handed out (all of it when every position with work found a
+            // quad); the rest is looked at again next time
+            const unsigned consumed = (n_take == n_av) ? wlen : (unsigned)(64 - __builtin_clzll(handed_mask));
+            if (valid && skipv && (unsigned)lane < consumed) {
+                const unsigned o = psl * (unsigned)args.restarts + prs;
+                args.item_loss[o] = INFINITY;
+                args.item_iters[o] = 0;
+                args.item_status[o] = ST_PREEMPTED;
+                args.item_evals[o] = 0;
+                args.item_acc[o] = 0;
+            }
+            int* wp = reinterpret_cast<int*>(lds);  // quad 0's exchange area, dead between rounds: [16] slots, [16] restarts
+            if (handed) {
+                wp[myrank] = (int)psl;
+                wp[16 + myrank] = (int)prs;
+            }
+            lds_fence();
+            const int qrank = __popcll(idle & ((1ull << (lane & ~3)) - 1ull));  // rank of this quad among the idle ones
+            const bool get = !live && qrank < n_take;
+            const unsigned sl = get ? (unsigned)wp[qrank] : 0u;
+            const unsigned rs = get ? (unsigned)wp[16 + qrank] : 0u;
+            lds_fence();
+            cur_next += consumed;
+            if (get) {
                 const unsigned oidx = sl * (unsigned)args.restarts + rs;
-                bool skip = false;
-                if (early) {
-                    // ordered early exit: dropped iff a LOWER-index restart of the target has already succeeded
-                    const int fl = __hip_atomic_load(&args.solved[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    skip = fl > args.restarts - (int)rs;
-                }
-                if (skip) {
-                    if (q == 0) {
-                        args.item_loss[oidx] = INFINITY;
-                        args.item_iters[oidx] = 0;
-                        args.item_status[oidx] = ST_PREEMPTED;
-                        args.item_evals[oidx] = 0;
-                        args.item_acc[oidx] = 0;
-                    }
-                } else {
-                    item = oidx;
-                    slot = (int)sl;
-                    restart = (int)rs;
-                    const int tgt = args.active ? args.active[sl] : (int)sl;
-                    tcol = args.targets + (int64_t)tgt * 32 + q * 2;
+                item = oidx;
+                slot = (int)sl;
+                restart = (int)rs;
+                const int tgt = args.active ? args.active[sl] : (int)sl;
+                tcol = args.targets + (int64_t)tgt * 32 + q * 2;
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        const int i = 4 * a + q;
-                        double xv = 0.0;
-                        if (i < C::N) {
-                            if (args.x0) {
-                                xv = args.x0[(int64_t)oidx * C::N + i];
-                            } else {
-                                // same Philox stream layout as the fixed-gate path, span tagged with 0x100 (V2), mapped onto the
-                                // parameter's start range
-                                const double u = x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), (uint32_t)rs, (uint32_t)(K | 0x100), (uint32_t)i) *
-                                                 (1.0 / 6.283185307179586476925286766559);
-                                xv = fma(u, args.init_hi[i] - args.init_lo[i], args.init_lo[i]);
-                            }
-                            const double2 b = bnd[i];
-                            xv = fmin(fmax(xv, b.x), b.y);
+                for (int a = 0; a < NA; ++a) {
+                    const int i = 4 * a + q;
+                    double xv = 0.0;
+                    if (i < C::N) {
+                        if (args.x0) {
+                            xv = args.x0[(int64_t)oidx * C::N + i];
+                        } else {
+                            // same Philox stream layout as the fixed-gate path, span tagged with 0x100 (V2), mapped onto the
+                            // parameter's start range
+                            const double u = x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), (uint32_t)rs, (uint32_t)(K | 0x100), (uint32_t)i) *
+                                             (1.0 / 6.283185307179586476925286766559);
+                            xv = fma(u, args.init_hi[i] - args.init_lo[i], args.init_lo[i]);
                         }
-                        x[a] = xv; g[a] = 0.0; p[a] = 0.0; hg[a] = 0.0;
+                        const double2 b = bnd[i];
+                        xv = fmin(fmax(xv, b.x), b.y);
                     }
-                    alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0; hs1 = 0.0;
-                    nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
-                    scaled = false; fresh = true; live = true; taken = true;
+                    x[a] = xv; g[a] = 0.0; p[a] = 0.0; hg[a] = 0.0;
                 }
+                alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0; hs1 = 0.0;
+                nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
+                scaled = false; fresh = true; live = true; taken = true;
             }
         }
         if (__any(taken)) H.set_identity_where(q, taken);
