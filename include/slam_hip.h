@@ -327,6 +327,16 @@ int slam_ctx_device(slam_ctx* ctx, int* device);
  *                            ended below exit_loss (the loop's break); without it every restart runs to its end.
  *                            Persistent wavefronts over a restart-major queue, as slam_minimize_stage.
  *                            Outputs as in slam_minimize_stage with rows of n parameters.
+ *   slam_v2_set_constraint   CircuitTemplateV2.set_constraint (basisv2.py:192-200: circuit_cost(x) <= param_max_cost, handed to
+ *                            SciPy's SLSQP by optimizer.py:260-265) for circuit costs that are affine in the parameters over
+ *                            the box: sum_i weights[i] x_i <= cost_max for the span-k template (n = its parameter count, index
+ *                            order; RiSwapGate.cost() = alpha: weight 1 on every gate parameter).  Every later stage of that
+ *                            span minimises the augmented Lagrangian loss + rho / 2 max(0, w.x - cost_max + mu / rho)^2 over the
+ *                            box with the same projected quasi-Newton loop and updates the multiplier estimate mu per item
+ *                            until w.x <= cost_max and mu (w.x - cost_max) = 0 to 1e-8; returned points are feasible, the
+ *                            returned loss is the plain loss.
+ *                            weights = NULL or n = 0 removes the constraint of span k (remove_constraint, basisv2.py:202-204);
+ *                            slam_v2_set_gates removes all of them.
  */
 #define SLAM_V2_MAX_SPAN 5 /* spans 4 and 5 for gates with few parameters: see slam_v2_minimize_stage */
 typedef struct slam_v2_gate {
@@ -336,6 +346,7 @@ typedef struct slam_v2_gate {
     double offset[4];
 } slam_v2_gate;
 int slam_v2_set_gates(slam_ctx* ctx, const slam_v2_gate* gates, int32_t n_gates);
+int slam_v2_set_constraint(slam_ctx* ctx, int k, const double* weights, int n, double cost_max);
 int slam_v2_eval_loss_grad(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, const int32_t* target_of, int64_t M,
                            double* loss, double* grad, double* unitary);
 int slam_v2_minimize_stage(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active, const double* x0,

@@ -56,6 +56,7 @@ EXPORTED_SYMBOLS = (
     "slam_fetch_span_losses",
     "slam_minimize_stage_trace",
     "slam_v2_set_gates",
+    "slam_v2_set_constraint",
     "slam_v2_eval_loss_grad",
     "slam_v2_minimize_stage",
     "slam_v2_minimize_stage_trace",
@@ -176,6 +177,8 @@ def load_library() -> C.CDLL:
         lib.slam_minimize_stage_trace.argtypes = [P, C.c_int, P, P, C.c_int64, P, C.POINTER(OptParams), C.c_double, C.c_int32] + [P] * 8
     if hasattr(lib, "slam_v2_set_gates"):
         lib.slam_v2_set_gates.argtypes = [P, C.POINTER(V2Gate), C.c_int32]
+        if hasattr(lib, "slam_v2_set_constraint"):
+            lib.slam_v2_set_constraint.argtypes = [P, C.c_int, P, C.c_int, C.c_double]
         lib.slam_v2_eval_loss_grad.argtypes = [P, C.c_int, P, P, P, C.c_int64, P, P, P]
         lib.slam_v2_minimize_stage.argtypes = [P, C.c_int, P, P, C.c_int64, P, P, P, P, P, C.POINTER(OptParams), C.c_double] + [P] * 7
         if hasattr(lib, "slam_v2_decompose_range"):
@@ -500,6 +503,15 @@ class Context:
         arr = (V2Gate * len(gates))(*gates)
         _check(self._lib.slam_v2_set_gates(self._h, arr, len(gates)))
         self.v2_qn = int(gates[0].n_params)
+
+    def v2_set_constraint(self, k: int, weights: Optional[np.ndarray], cost_max: float = 0.0) -> None:
+        """sum_i weights[i] x_i <= cost_max for every later stage of span k (device parameter order); None removes it.
+        ``v2_set_gates`` removes the constraints of every span."""
+        if weights is None:
+            _check(self._lib.slam_v2_set_constraint(self._h, int(k), None, 0, 0.0))
+            return
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        _check(self._lib.slam_v2_set_constraint(self._h, int(k), w.ctypes.data, int(w.size), float(cost_max)))
 
     def v2_eval(self, gate_seq: Sequence[int], x: np.ndarray, target_of: Optional[np.ndarray] = None, want_grad=True, want_unitary=False):
         """Loss, gradient w.r.t. all n = 6 (k + 1) + QN k parameters and (optionally) W(x) for ``x[M, n]``."""

@@ -15,8 +15,11 @@ probing the callable; anything else raises ``NotImplementedError``.
 Parameter order of ``Xk`` here is *index order*: ``P0 .. P{m-1}, Q0 .. Q{QN k - 1}`` (the reference zips ``Xk`` with
 qiskit's name-sorted ``circuit.parameters``; ``to_qiskit_order`` / ``from_qiskit_order`` convert).  ``no_exterior_1q`` (no 1Q
 layer before the first and after the last 2Q gate, basisv2.py:264,291) maps onto the device template by fixing those two
-layers at ``U(0, 0, 0)`` = identity, like ``vz_only`` fixes theta and phi.  Not implemented: ``param_vec_expand`` (time-sliced
-"smush" gates: not conversion-gain family members), cost constraints (``set_constraint`` -> SLSQP), polytopes.
+layers at ``U(0, 0, 0)`` = identity, like ``vz_only`` fixes theta and phi.  ``set_constraint(c)`` (basisv2.py:192-200:
+``circuit_cost(x) <= c``, which the reference hands to SciPy's SLSQP, optimizer.py:260-265) is implemented for circuit costs that
+are affine in the parameters over the box -- ``RiSwapGate`` (cost = alpha), ``ConversionGainGate`` lambdas whose drive strengths
+are bounded to one sign -- as a projected quasi-Newton method on the box cut by the half-space (slam_v2_set_constraint).
+Not implemented: ``param_vec_expand`` (time-sliced "smush" gates: not conversion-gain family members), polytopes.
 """
 from __future__ import annotations
 
@@ -186,11 +189,62 @@ class CircuitTemplateV2(VariationalTemplate):
         self.using_bounds = True
 
     def set_constraint(self, param_max_cost):
-        raise NotImplementedError("cost constraints (SLSQP, basisv2.py:192-200) are not implemented on the HIP path")
+        """basisv2.py:192-200: the current basis must not cost more than ``param_max_cost`` (C(x) >= 0 form for SciPy)."""
+        self.constraint_func = {"type": "ineq", "fun": lambda x: param_max_cost - self.circuit_cost(x)}
+        self.param_max_cost = float(param_max_cost)
+        self.using_constraints = True
 
     def remove_constraint(self):
         self.constraint_func = None
         self.using_constraints = False
+
+    def constraint_layout(self, k: int):
+        """The constraint ``circuit_cost(x) <= param_max_cost`` of the span-k template as (weights[n_dev], cost_max) with
+        sum_i weights[i] x_dev[i] <= cost_max, for the device (slam_v2_set_constraint).  The circuit cost is probed: it has to be
+        affine in the gate parameters over the box (RiSwapGate: alpha; ConversionGainGate: (|gc| + |gg|) t / (pi / 2) with
+        gc, gg bounded to one sign); otherwise NotImplementedError.  ValueError when no point of the box satisfies it."""
+        if not self.using_constraints:
+            raise ValueError("no constraint set")
+        saved = self.cycles
+        try:
+            self.cycles = int(k)
+            n_dev, idx, _, _, blo, bhi = self.device_layout(k)
+            n_p, n_q = self._n_p(k), self.n_gate_params * k
+            lo = np.array([blo[d] for d in idx[n_p:]])
+            hi = np.array([bhi[d] for d in idx[n_p:]])
+            plo = np.where(np.isfinite(lo), lo, np.where(np.isfinite(hi), hi - 2.0, -1.0))  # a finite probing box
+            phi = np.where(np.isfinite(hi), hi, plo + 2.0)
+            phi = np.where(phi > plo, phi, plo)
+            zeros_p = np.zeros(n_p)
+            cost = lambda qv: float(self.circuit_cost(np.concatenate([zeros_p, qv])))
+            q0 = 0.5 * (plo + phi)
+            c_q0 = cost(q0)
+            w = np.zeros(n_q)
+            for j in range(n_q):
+                h = 0.25 * (phi[j] - plo[j])
+                if h <= 0.0:
+                    continue  # a parameter fixed by its bound: constant contribution, inside c_q0
+                e = np.zeros(n_q)
+                e[j] = h
+                w[j] = (cost(q0 + e) - c_q0) / h
+            rng = np.random.default_rng(2024)
+            for _ in range(8):
+                qv = rng.uniform(plo, phi)
+                if abs(cost(qv) - (c_q0 + w @ (qv - q0))) > 1e-9 * (1.0 + abs(c_q0)):
+                    raise NotImplementedError(
+                        "set_constraint on the HIP path needs a circuit cost that is affine in the gate parameters over their bounds "
+                        "(ConversionGainGate: bound gc and gg to one sign with add_bound)")
+        finally:
+            self.cycles = saved
+        w_dev = np.zeros(n_dev)
+        w_dev[idx[n_p:]] = w
+        cost_max = self.param_max_cost - (c_q0 - w @ q0)
+        cheapest = float(np.sum(np.where(w > 0, w * lo, np.where(w < 0, w * hi, 0.0))))  # -inf when an unbounded side is cheap
+        if cheapest > cost_max + 1e-12:
+            raise ValueError(f"set_constraint({self.param_max_cost}): the cheapest circuit inside the bounds costs {cheapest + (c_q0 - w @ q0):.6g}")
+        if not np.any(w != 0.0):
+            raise ValueError("set_constraint: the circuit cost does not depend on any free parameter")
+        return w_dev, float(cost_max)
 
     def parameter_guess(self, t=0):
         """basisv2.py:150-172: uniform in the parameter's bound, (-4 pi, 4 pi) by default; also (re)builds bounds_list."""

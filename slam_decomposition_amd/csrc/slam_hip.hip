@@ -105,6 +105,11 @@ struct slam_ctx {
     DevBuf v2_maps, v2_bounds;   // slam_v2_*: staged gate maps [SLAM_MAX_SPAN_EVAL], (init_lo, init_hi, bound_lo, bound_hi)[n]
     std::vector<V2GateMap> v2_gates_host;
     int v2_qn = 0;
+    // cost constraint per span (slam_v2_set_constraint): weights [n(k)] on the device, right-hand side; empty = none
+    DevBuf v2_cons_w[SLAM_V2_MAX_SPAN + 1];
+    int v2_cons_n[SLAM_V2_MAX_SPAN + 1] = {0};
+    double v2_cons_max[SLAM_V2_MAX_SPAN + 1] = {0};
+    double v2_cons_rho[SLAM_V2_MAX_SPAN + 1] = {0};  // penalty parameter of the multiplier method: 30 / max w^2
     DevBuf trace_loss, trace_x;  // slam_minimize_stage_trace
     int32_t trace_cap = 0;       // > 0 only inside slam_minimize_stage_trace
     double stage_exit_loss = -1.0;  // single-stage calls: >= 0 overrides stop_loss as the ordered early-exit level
@@ -128,7 +133,7 @@ struct slam_ctx {
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
                          &item_status, &item_evals, &item_acc, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
+                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &v2_cons_w[0], &v2_cons_w[1], &v2_cons_w[2], &v2_cons_w[3], &v2_cons_w[4], &v2_cons_w[5], &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -1229,6 +1234,16 @@ int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
     a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
     a.trace_x = c->trace_cap > 0 ? c->trace_x.as<double>() : nullptr;
     a.bounded = sgt.bounded ? 1 : 0;
+    if (c->v2_cons_n[K] > 0) {
+        if (c->v2_cons_n[K] != n) return fail(SLAM_ERR_STATE, "the cost constraint of span %d was set for %d parameters, the template has %d (set the gates first)", K, c->v2_cons_n[K], n);
+        if (FREE) return fail(SLAM_ERR_STATE, "internal: constrained stage dispatched to the unbounded kernel");
+        a.cons_w = c->v2_cons_w[K].as<double>();
+        // results are feasible: the multiplier loop ends with c <= tol against a right-hand side lowered by tol
+        a.cons_tol = 1e-8 * (1.0 + std::fabs(c->v2_cons_max[K]));
+        a.cons_max = c->v2_cons_max[K] - a.cons_tol;
+        a.cons_rho = c->v2_cons_rho[K];
+        a.bounded = 1;
+    }
     // persistent wavefronts: never more than can be resident; every quad pulls items from the stage's queue
     const int64_t M = (int64_t)sgt.n_active * sgt.prm->restarts;
     int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
@@ -1249,7 +1264,7 @@ int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
 template <int K, int QN>
 int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
     if constexpr (QN == 1 && K <= 3) {
-        if (sgt.riswap_like && !sgt.bounded) return v2_launch_minimize_gq<K, QN, 1, true>(c, sgt);  // RiSwapGate class, plain BFGS
+        if (sgt.riswap_like && !sgt.bounded && c->v2_cons_n[K] == 0) return v2_launch_minimize_gq<K, QN, 1, true>(c, sgt);  // RiSwapGate class, plain BFGS
         if (sgt.riswap_like) return v2_launch_minimize_gq<K, QN, 1, false>(c, sgt);
     }
     return v2_launch_minimize_gq<K, QN, 0, false>(c, sgt);
@@ -1588,6 +1603,34 @@ int slam_v2_set_gates(slam_ctx* ctx, const slam_v2_gate* gates, int32_t n_gates)
     }
     ctx->v2_gates_host.swap(tmp);
     ctx->v2_qn = qn;
+    for (int k = 0; k <= SLAM_V2_MAX_SPAN; ++k) ctx->v2_cons_n[k] = 0;  // a constraint belongs to the gate table it was set for
+    return SLAM_OK;
+}
+
+int slam_v2_set_constraint(slam_ctx* ctx, int k, const double* weights, int n, double cost_max) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (k < 1 || k > SLAM_V2_MAX_SPAN) return fail(SLAM_ERR_UNSUPPORTED, "parametrised-gate templates support spans 1..%d (got %d)", SLAM_V2_MAX_SPAN, k);
+    if (!weights || n == 0) {  // remove_constraint (basisv2.py:202-204)
+        ctx->v2_cons_n[k] = 0;
+        return SLAM_OK;
+    }
+    if (ctx->v2_gates_host.empty()) return fail(SLAM_ERR_STATE, "no parametrised gates: call slam_v2_set_gates first");
+    const int want = 6 * (k + 1) + ctx->v2_qn * k;
+    if (n != want) return fail(SLAM_ERR_INVALID, "span %d with %d parameters per gate has %d parameters (got %d weights)", k, ctx->v2_qn, want, n);
+    if (!std::isfinite(cost_max)) return fail(SLAM_ERR_INVALID, "cost_max must be finite");
+    double w2max = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (!std::isfinite(weights[i])) return fail(SLAM_ERR_INVALID, "weights[%d] is not finite", i);
+        w2max = std::max(w2max, weights[i] * weights[i]);
+    }
+    if (!(w2max > 0.0)) return fail(SLAM_ERR_INVALID, "a cost constraint needs a non-zero weight");
+    HIP_TRY(ctx->v2_cons_w[k].reserve((size_t)n * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(ctx->v2_cons_w[k].p, weights, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the caller's buffer
+    ctx->v2_cons_n[k] = n;
+    ctx->v2_cons_max[k] = cost_max;
+    ctx->v2_cons_rho[k] = 30.0 / w2max;
     return SLAM_OK;
 }
 

@@ -61,7 +61,9 @@ struct CfgV2 {
     static constexpr int LDS_XCHG = kQuadsPerWave * XSTRIDE;
     static constexpr int LDS_FH = K * 4 * kRow * 2;              // h_0..h_{K-1}: [vector][row][lane + pad] double2
     static constexpr int LDS_BOUNDS = 2 * NA * 4;                // (lo, hi) per parameter, padded to 4 NA
-    static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH + LDS_BOUNDS + kSincosLdsDoubles;
+    static constexpr int LDS_CW = NA * 4 + kQuadsPerWave * 8;    // cost constraint (after the trig table): one weight per parameter, then per quad
+                                                                 // (mu, loss, c, multiplier updates) at x and (loss, c) at the trial point
+    static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH + LDS_BOUNDS + kSincosLdsDoubles + LDS_CW;
 };
 
 // ---- conversion-gain gate actions from the (cos, sin) table entries of the four raw angles -------------------------
@@ -631,10 +633,18 @@ struct MinimizeV2Args {
     double* trace_x;           // [M][trace_cap][n]
     int32_t trace_cap;
     int32_t bounded;           // 0: every bound is (-inf, +inf) -- plain BFGS (optimizer.py:255): no projection, no blocked components
+    // cost constraint of the template (CircuitTemplateV2.set_constraint, basisv2.py:192-200: circuit_cost(x) <= param_max_cost),
+    // for circuit costs that are affine in the parameters over the box: sum_i cons_w[i] x_i <= cons_max.  nullptr = none.
+    const double* cons_w;      // [n]
+    double cons_max;           // (lowered by the feasibility tolerance by the host side)
+    double cons_rho;           // penalty parameter of the augmented Lagrangian
+    double cons_tol;           // feasibility / complementarity tolerance of the multiplier loop
 };
 
 // FREE = true: instantiated for launches without any finite bound (plain BFGS): the projection code and the trial point kept
 // across the evaluation (2 NA registers) are compiled out; FREE = false handles both (args.bounded, wave-uniform)
+constexpr int kMaxMultiplierUpdates = 24;
+
 template <int K, int QN, int GQ = 0, bool FREE = false>
 __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimize_v2_kernel(MinimizeV2Args<K, QN> args) {
     using C = CfgV2<K, QN>;
@@ -649,6 +659,14 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
     load_sincos_table(tbl, lane);
     for (int i = lane; i < 4 * NA; i += kWave)
         bnd[i] = (i < C::N) ? make_double2(args.bound_lo[i], args.bound_hi[i]) : make_double2(0.0, 0.0);
+    // cost constraint (FREE = false only): weights staged next to the bounds
+    const bool cons = !FREE && args.cons_w != nullptr;  // wave-uniform
+    double* cw = lds + C::LDS_XCHG + C::LDS_FH + C::LDS_BOUNDS + kSincosLdsDoubles;
+    if (cons)
+        for (int i = lane; i < 4 * NA; i += kWave) cw[i] = (i < C::N) ? args.cons_w[i] : 0.0;
+    // the item's multiplier state lives in LDS (all four lanes of a quad write the same values): the kernels that handle bounds
+    // without a constraint keep their register budget
+    double* cst = cw + 4 * NA + quad * 8;  // [0] mu [1] loss(x) [2] c(x) [3] updates [4] loss(trial) [5] c(trial)
     lds_fence();
     const int theta_bits = theta_slot_bits_v2<K, QN>(q);
     // n_active < 0: the stage's target count is produced on the device by the previous stage's compaction (span loop enqueued
@@ -765,6 +783,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
                 alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0; hs1 = 0.0;
                 nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
                 scaled = false; fresh = true; live = true; taken = true;
+                if (!FREE) { cst[0] = 0.0; cst[3] = 0.0; }  // multiplier estimate; metric restarts + multiplier updates
             }
         }
         if (__any(taken)) H.set_identity_where(q, taken);
@@ -790,6 +809,24 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         }
         double ft, Wr[4], Wi[4];
         eval_quad_v2<K, QN, false, GQ>(xt, tcol, args.maps, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
+        // Cost constraint (set_constraint, basisv2.py:192-200; the reference hands it to SLSQP): augmented Lagrangian around this
+        // box-constrained loop.  The function minimised is  L(x) = loss(x) + rho / 2 max(0, c(x) + mu / rho)^2  with
+        // c(x) = w.x - cmax: smooth, same box -- one more quad reduction per evaluation.  When the loop below has converged on L
+        // the item's multiplier estimate moves, mu <- max(0, mu + rho c), and the loop goes on from the same point with the same
+        // metric until c <= tol and mu c = 0 within tol (first-order multiplier method; the violation shrinks by ~ rho / curvature
+        // per update: 5..7 updates to 1e-8 with rho w.w = 30).  cmax is handed in lowered by that tolerance: results are feasible.
+        if (cons) {
+            double ct = 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) ct = fma(cw[4 * a + q], xt[a], ct);
+            ct = quad_sum(ct) - args.cons_max;
+            cst[4] = ft;
+            cst[5] = ct;
+            const double tpen = args.cons_rho * fmax(0.0, fma(cst[0], 1.0 / args.cons_rho, ct));  // rho max(0, c + mu / rho)
+            ft = fma(0.5 * tpen, tpen * (1.0 / args.cons_rho), ft);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) gt[a] = fma(tpen, cw[4 * a + q], gt[a]);
+        }
         const bool active = live;
         const bool finite = isfinite(ft);
         // The quasi-Newton algebra lives in the subspace of the variables that can move: the gradient component of a
@@ -866,6 +903,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         if (acc) {
             nstall = (step && (f - ft) <= kStallDf) ? nstall + 1 : 0;
             f = ft;
+            if (cons) { cst[1] = cst[4]; cst[2] = cst[5]; }
             if (step) ++iters;
             nback = 0;
             grow = (step && too_short) ? fmin(grow * kGrowFactor, kGrowMax) : 1.0;
@@ -893,7 +931,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
             if (args.trace_loss) {  // wave-uniform: nothing when off
                 if (step && iters <= args.trace_cap) {
                     const int64_t row = (int64_t)item * args.trace_cap + (iters - 1);
-                    if (q == 0) args.trace_loss[row] = f;
+                    if (q == 0) args.trace_loss[row] = cons ? cst[1] : f;
 #pragma unroll
                     for (int a = 0; a < NA; ++a) {
                         const int i = 4 * a + q;
@@ -932,7 +970,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         const double pp = qdot<NA>(p, p);
         if (acc) {
             alpha = (pp > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(pp)) : grow;
-            if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) { status = ST_CONVERGED; done = true; }
+            if (f < args.stop_loss || gnorm < args.gtol || (!cons && gnorm < args.gtol_far && f > args.far_loss)) { status = ST_CONVERGED; done = true; }
             else if (nstall >= 2) { status = ST_STALLED; done = true; }
             else if (iters >= args.maxiter) { status = ST_MAXITER; done = true; }
         } else if (active && !fresh) {
@@ -960,6 +998,36 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
             alpha = periodic ? ((gg2 < -1e-300) ? fmin(grow, kStepMax * fast_rsqrt(-gg2)) : grow) : alpha;  // (-gg2 = |projected g|^2)
             // nothing left to move along: a KKT point of the box-constrained problem
             if (reset && !(gg2 < 0.0)) { status = ST_CONVERGED; done = true; }
+        }
+        if (bounded) {
+            // A failed line search is not a point of rest.  With bounds the projected step of a quasi-Newton direction need not
+            // be a descent direction (a variable about to reach its bound is clamped mid-step, and the metric couples it to the
+            // others); the projected step of the steepest-descent direction always is: the metric starts over from the identity
+            // and the loop goes on (the variable lands ON its bound and is left out from then on).  With a cost constraint: the
+            // loop has come to rest on L(.; mu) -- multiplier update, or the end of the item (no update from a failed search).
+            const double nouter = cst[3];  // metric restarts + multiplier updates of the item so far
+            const bool lsfail = active && done && status == ST_LINESEARCH && nouter < (double)kMaxMultiplierUpdates;
+            bool update = false;
+            double mu_next = 0.0;
+            if (cons) {
+                const bool rest = active && done && (status == ST_CONVERGED || status == ST_STALLED);
+                const double mu = cst[0], cc = cst[2];
+                mu_next = fmax(0.0, fma(args.cons_rho, cc, mu));
+                const bool kkt = cc <= args.cons_tol && (mu_next == 0.0 || fabs(cc) <= args.cons_tol);
+                update = rest && !kkt && nouter < (double)kMaxMultiplierUpdates;
+                mu_next = update ? mu_next : mu;
+            }
+            if (lsfail || update) {
+                if (cons) cst[0] = mu_next;
+                cst[3] = nouter + 1.0;
+                hs1 = lsfail ? 0.0 : hs1;
+                scaled = lsfail ? false : scaled;
+                done = false; fresh = true; alpha = 0.0; nstall = 0; nback = 0; status = ST_MAXITER;  // re-evaluated at x (with the new mu)
+            }
+            if (__any(lsfail)) H.set_identity_where(q, lsfail);
+            // with a constraint, what leaves the kernel is the plain loss -- of a feasible point: an item that ran out of multiplier
+            // updates with the constraint still violated reports +inf and never wins its target
+            if (cons) f = (active && done && status != ST_NONFINITE) ? ((cst[2] <= args.cons_tol) ? cst[1] : INFINITY) : f;
         }
         if (active && done) {
             if (early && f < args.exit_loss && q == 0)

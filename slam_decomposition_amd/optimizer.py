@@ -77,8 +77,6 @@ class TemplateOptimizer:
         if not isinstance(basis, (CircuitTemplate, CircuitTemplateV2)):
             raise NotImplementedError("the HIP optimizer needs a slam_decomposition_amd CircuitTemplate / CircuitTemplateV2")
         self._v2 = isinstance(basis, CircuitTemplateV2)
-        if self._v2 and basis.using_constraints:
-            raise NotImplementedError("cost constraints (SLSQP, optimizer.py:260-265) are not implemented on the HIP path")
         if isinstance(self.objective, SquareCost):
             self._cost_kind = _ffi.COST_SQUARE
         elif isinstance(self.objective, BasicCost):
@@ -88,7 +86,7 @@ class TemplateOptimizer:
             raise ValueError("Unrecognized Cost Function")
         if use_callback and not deterministic:
             raise ValueError("use_callback=True records the reference's sequential restart loop: it needs deterministic=True")
-        if override_method not in (None, "BFGS") and not (self._v2 and override_method == "L-BFGS-B"):
+        if override_method not in (None, "BFGS") and not (self._v2 and override_method in ("L-BFGS-B", "SLSQP")):
             raise NotImplementedError(f"override_method={override_method!r}: the HIP path implements BFGS only")
         if self.training_restarts <= 0:
             raise ValueError("training_restarts must be positive")
@@ -295,6 +293,8 @@ class TemplateOptimizer:
         for k in ks:
             basis.build(k)
             layouts[k] = (basis.gate_sequence(k),) + tuple(basis.device_layout(k))
+        # set_constraint (optimizer.py:260-265 switches SciPy to SLSQP): the half-space of every span, for the device
+        constraints = {k: basis.constraint_layout(k) for k in ks} if basis.using_constraints else {}
 
         def run_shard(device, first, count):
             single = len(self.devices) == 1
@@ -302,6 +302,8 @@ class TemplateOptimizer:
             try:
                 ctx.set_targets(targets[first : first + count])
                 ctx.v2_set_gates(basis._gate_maps)
+                for k, (w_dev, cost_max) in constraints.items():
+                    ctx.v2_set_constraint(k, w_dev, cost_max)
                 ctx.set_cost(self._cost_kind)
                 ctx.reset_stats()
                 sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
@@ -396,6 +398,9 @@ class TemplateOptimizer:
         ctx.set_targets(targets)
         if self._v2:
             ctx.v2_set_gates(self.basis._gate_maps)
+            if self.basis.using_constraints:
+                for k in sorted({int(k) for ks in spans_per_target for k in ks}):
+                    ctx.v2_set_constraint(k, *self.basis.constraint_layout(k))
         else:
             ctx.set_gates(self.basis.gate_matrices)
         ctx.set_cost(self._cost_kind)

@@ -399,3 +399,142 @@ def test_v2_device_span_loop_equals_the_host_driven_one(hip_ctx):
     # a window of the resident batch, and the optimizer path built on it
     wl, _, wc = hip_ctx.v2_decompose_range(16, 8, 1, 3, [[0] * k for k in (1, 2, 3)], [lay[k][2:6] for k in (1, 2, 3)], prm, thr)
     assert np.array_equal(wl, dl[16:24]) and np.array_equal(wc, dc[16:24])
+
+
+def _slsqp_best(fn, qn, k, target, bounds, w_user, cost_max, x0s, square=False):
+    """SciPy SLSQP on the oracle (analytic gradient), the method the reference switches to once the template has a
+    constraint (optimizer.py:260-265), with the constraint in SciPy's C(x) >= 0 form (basisv2.py:196-199).  Best feasible
+    result over the start points (a single start = a polish of that point)."""
+    best = np.inf
+    gm = gate_map(fn)[1:]
+    cons = {"type": "ineq", "fun": lambda xx: cost_max - w_user @ xx, "jac": lambda xx: -w_user}
+    for x0 in x0s:
+        res = opt.minimize(lambda xx: v.loss_and_grad(xx, [gm] * k, qn, k, target, False, square), x0, jac=True, method="SLSQP",
+                           bounds=bounds, constraints=cons, options={"maxiter": 2500, "ftol": 1e-13})
+        if res.success and w_user @ res.x <= cost_max + 1e-9:
+            best = min(best, res.fun)
+    return best
+
+
+def test_cost_constraint_matches_scipy_slsqp_riswap():
+    """set_constraint (basisv2.py:192-200): three RiSwap gates with 0 <= alpha_i <= 1 and alpha_1 + alpha_2 + alpha_3 <= 1.0 -- too
+    little total interaction for a generic target, so the optimum lies ON the constraint.  Best-of-restarts loss of the device's
+    multiplier method vs SciPy SLSQP on the oracle: SLSQP started AT the device's result does not get below it by 1e-6 (it is a
+    constrained minimum), SLSQP from as many random starts does not beat it by 1e-6 (the landscape has several minima per target:
+    best-of-restarts from different starts need not coincide); bounds and constraint hold exactly."""
+    cmax = 1.0
+    for seed in (31, 32, 33):
+        target = o.haar_unitary(seed)
+        basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=3)
+        basis.build(3)
+        basis.spanning_range = range(3, 4)
+        for name in basis.parameter_names():
+            if name.startswith("Q"):
+                basis.add_bound(name, 1.0, 0.0)
+        basis.set_constraint(cmax)
+        R = 32
+        optm = TemplateOptimizer(basis, BasicCost(), training_restarts=R, seed=7 + seed, override_fail=True)
+        td = optm.approximate_target_U(target)
+        x = np.asarray(td.Xk)
+        assert td.cycles == 3
+        assert np.all(x[-3:] >= 0.0) and np.all(x[-3:] <= 1.0)
+        basis.build(3)
+        assert basis.circuit_cost(x) <= cmax + 1e-12
+        assert abs(o.basic_cost(basis.eval(x), target) - td.loss_result) < 1e-12
+        bounds = [(-4 * np.pi, 4 * np.pi)] * 24 + [(0.0, 1.0)] * 3
+        w_user = np.concatenate([np.zeros(24), np.ones(3)])
+        rng = np.random.default_rng(seed)
+        x0s = [np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, 24), rng.uniform(0, 1.0 / 3, 3)]) for _ in range(R)]
+        ref = _slsqp_best(RiSwapGate, 1, 3, target, bounds, w_user, cmax, x0s)
+        polished = _slsqp_best(RiSwapGate, 1, 3, target, bounds, w_user, cmax, [x])
+        assert td.loss_result - polished < 1e-6, (seed, polished, td.loss_result)
+        assert td.loss_result < ref + 1e-6, (seed, ref, td.loss_result)
+        if td.loss_result > 1e-6:
+            assert basis.circuit_cost(x) > cmax - 1e-6  # the constraint binds
+
+
+def test_cost_constraint_conversion_gain_and_errors():
+    """ConversionGainGate(0, 0, gc, gg, 1): cost = (|gc| + |gg|) t / (pi / 2) (custom_gates.py:208-212) is affine once gc, gg >= 0
+    are bounds; without them the HIP path refuses; an unreachable cost raises; remove_constraint restores the plain run."""
+    fn = lambda gc, gg: ConversionGainGate(0.0, 0.0, gc, gg, 1.0)
+    target = o.haar_unitary(91)
+    basis = CircuitTemplateV2(base_gates=[fn], maximum_span_guess=2)
+    basis.build(2)
+    basis.spanning_range = range(2, 3)
+    basis.set_constraint(0.4)
+    with pytest.raises(NotImplementedError):
+        basis.constraint_layout(2)  # |gc|, |gg| with sign-indefinite parameters
+    for name in basis.parameter_names():
+        if name.startswith("Q"):
+            basis.add_bound(name, 1.5, 0.0)
+    w_dev, cm = basis.constraint_layout(2)
+    assert np.allclose(w_dev[18:], 2 / np.pi) and np.all(w_dev[:18] == 0.0) and abs(cm - 0.4) < 1e-12
+    R = 32
+    optm = TemplateOptimizer(basis, BasicCost(), training_restarts=R, seed=3, override_fail=True)
+    td = optm.approximate_target_U(target)
+    x = np.asarray(td.Xk)
+    basis.build(2)
+    assert basis.circuit_cost(x) <= 0.4 + 1e-12 and np.all(x[-4:] >= 0.0) and np.all(x[-4:] <= 1.5)
+    assert abs(o.basic_cost(basis.eval(x), target) - td.loss_result) < 1e-12
+    bounds = [(-4 * np.pi, 4 * np.pi)] * 18 + [(0.0, 1.5)] * 4
+    w_user = np.concatenate([np.zeros(18), np.full(4, 2 / np.pi)])
+    rng = np.random.default_rng(4)
+    x0s = [np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, 18), rng.uniform(0, 0.15, 4)]) for _ in range(R)]
+    ref = _slsqp_best(fn, 2, 2, target, bounds, w_user, 0.4, x0s)
+    polished = _slsqp_best(fn, 2, 2, target, bounds, w_user, 0.4, [x])
+    assert td.loss_result - polished < 1e-6, (polished, td.loss_result)
+    assert td.loss_result < ref + 1e-6, (ref, td.loss_result)
+    # without the constraint the same template does better (the constraint was binding)
+    basis.remove_constraint()
+    td_free = TemplateOptimizer(basis, BasicCost(), training_restarts=R, seed=3, override_fail=True).approximate_target_U(target)
+    assert td_free.loss_result < td.loss_result - 1e-6
+    basis.build(2)
+    basis.set_constraint(-0.1)
+    with pytest.raises(ValueError):
+        basis.constraint_layout(2)  # costs are >= 0 inside the bounds
+
+
+def test_cost_constraint_stage_matches_the_cpu_port_item_by_item(hip_ctx):
+    """slam_v2_set_constraint + slam_v2_minimize_stage from explicit start points against oracle/pqn_port.py (the same multiplier
+    method in NumPy, float64 metric) item by item: every device result is feasible; most items end in the port's minimum
+    (float32 metric: a few take another path to another minimum) and the best of each target's restarts agrees; the C ABI's
+    argument checks."""
+    from oracle import pqn_port
+
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate])
+    basis.build(3)
+    for name in basis.parameter_names():
+        if name.startswith("Q"):
+            basis.add_bound(name, 1.0, 0.0)
+    basis.set_constraint(1.0)
+    n_dev, idx, ilo, ihi, blo, bhi = basis.device_layout(3)
+    w_dev, cmax = basis.constraint_layout(3)
+    assert n_dev == 27 and np.array_equal(w_dev, np.r_[np.zeros(24), np.ones(3)]) and cmax == 1.0
+    T, R = 3, 10
+    targets = o.haar_batch(T, seed0=640)
+    hip_ctx.set_targets(targets)
+    hip_ctx.v2_set_gates(basis._gate_maps)
+    with pytest.raises(_ffi.SlamHipError):
+        hip_ctx.v2_set_constraint(3, w_dev[:-1], cmax)  # wrong parameter count
+    with pytest.raises(_ffi.SlamHipError):
+        hip_ctx.v2_set_constraint(3, np.zeros(27), cmax)  # no weight
+    hip_ctx.v2_set_constraint(3, w_dev, cmax)
+    rng = np.random.default_rng(8)
+    x0 = np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, (T, R, 24)), rng.uniform(0.0, 0.6, (T, R, 3))], axis=2)  # some starts infeasible
+    prm = _ffi.OptParams(restarts=R, seed=1)
+    out = hip_ctx.v2_minimize_stage([0, 0, 0], prm, 1e-10, ilo, ihi, blo, bhi, x0=x0)
+    gm = gate_map(RiSwapGate)[1:]
+    agree = 0
+    for t in range(T):
+        fun = lambda xx: v.loss_and_grad(xx, [gm] * 3, 1, 3, targets[t], False, False)
+        port = [pqn_port.minimize_port(fun, x0[t, r], blo, bhi, w_dev, cmax)[0] for r in range(R)]
+        agree += int(np.sum(np.abs(np.array(port) - out["item_loss"][t]) < 1e-6))
+        assert abs(min(port) - out["best_loss"][t]) < 1e-6, (t, min(port), out["best_loss"][t])
+        xb = out["best_x"][t]
+        assert xb[24:].sum() <= 1.0 and np.all(xb[24:] >= 0.0) and np.all(xb[24:] <= 1.0)
+        assert abs(fun(xb)[0] - out["best_loss"][t]) < 1e-12  # the plain loss, not the augmented Lagrangian
+    assert agree >= 0.7 * T * R, agree
+    # removing the constraint gives the bounded run again: lower losses, cost above the limit somewhere
+    hip_ctx.v2_set_constraint(3, None)
+    free = hip_ctx.v2_minimize_stage([0, 0, 0], prm, 1e-10, ilo, ihi, blo, bhi, x0=x0)
+    assert np.all(free["best_loss"] <= out["best_loss"] + 1e-9) and np.any(free["best_x"][:, 24:].sum(axis=1) > 1.0 + 1e-6)

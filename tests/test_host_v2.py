@@ -65,8 +65,9 @@ def test_bounds_follow_the_reference_semantics():
     # once one bound is set every parameter is bounded: explicit, or the default (-4 pi, 4 pi) (basisv2.py:160-169)
     assert blo[idx[0]] == DEFAULT_BOUND[0] and bhi[idx[0]] == DEFAULT_BOUND[1]
     assert (blo[idx[18]], bhi[idx[18]]) == (0.5, 0.5) and blo[idx[19]] == 0.0 and np.isinf(bhi[idx[19]])
-    with pytest.raises(NotImplementedError):
-        b.set_constraint(1.0)
+    b.set_constraint(1.0)  # (the HIP path runs cost constraints since round 3: test_constraint_layout_... below)
+    assert b.using_constraints
+    b.remove_constraint()
     for kw in (dict(param_vec_expand=[1, 2]), dict(use_polytopes=True), dict(n_qubits=3)):
         with pytest.raises(NotImplementedError):
             CircuitTemplateV2(**kw)
@@ -86,3 +87,54 @@ def test_v2_oracle_vz_only_template_is_the_rz_circuit():
     ref = np.kron(v.rz(x[3]), v.rz(x[2])) @ o.riswap_matrix(x[4]) @ np.kron(v.rz(x[1]), v.rz(x[0]))
     assert np.allclose(W, ref, atol=1e-15)
     assert np.allclose(o.u3(0, 0, 0.7), np.exp(0.35j) * v.rz(0.7), atol=1e-15)
+
+
+def test_constraint_layout_and_the_multiplier_method_port():
+    """set_constraint (basisv2.py:192-200) on the host: the probed half-space of the device, its refusals, and oracle/pqn_port.py
+    -- the NumPy restatement of the kernel's multiplier method -- against SciPy SLSQP on a small constrained problem."""
+    import scipy.optimize as opt
+
+    from oracle import pqn_port
+    from slam_decomposition_amd.basisv2 import CircuitTemplateV2
+    from slam_decomposition_amd.gates import ConversionGainGate, RiSwapGate
+
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate])
+    basis.build(2)
+    basis.set_constraint(0.7)
+    assert basis.using_constraints and basis.constraint_func["type"] == "ineq"
+    x = np.r_[np.zeros(18), 0.25, 0.35]
+    assert abs(basis.constraint_func["fun"](x) - 0.1) < 1e-12  # C(x) = param_max_cost - circuit_cost(x) >= 0
+    w, cm = basis.constraint_layout(2)
+    assert np.array_equal(w, np.r_[np.zeros(18), 1.0, 1.0]) and cm == 0.7  # RiSwapGate.cost() = alpha, no bounds needed
+    basis.remove_constraint()
+    assert not basis.using_constraints and basis.constraint_func is None
+    cg = CircuitTemplateV2(base_gates=[lambda gc, gg: ConversionGainGate(0.0, 0.0, gc, gg, 2.0)])
+    cg.build(1)
+    cg.set_constraint(1.0)
+    with pytest.raises(NotImplementedError):
+        cg.constraint_layout(1)  # |gc| + |gg| is not affine around 0
+    cg.add_bound("Q0", 1.0, 0.0)
+    cg.add_bound("Q1", 0.0, -1.0)  # a negative drive strength: cost falls with the parameter
+    w, cm = cg.constraint_layout(1)
+    assert np.allclose(w[12:], [4 / np.pi, -4 / np.pi]) and abs(cm - 1.0) < 1e-12
+    cg.set_constraint(-1.0)
+    with pytest.raises(ValueError):
+        cg.constraint_layout(1)
+
+    # the port on a convex quadratic with one active bound and an active constraint: SLSQP's solution
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(6, 6))
+    Q = A @ A.T + 0.5 * np.eye(6)
+    b = rng.normal(size=6) * 3
+    fun = lambda xx: (0.5 * xx @ Q @ xx - b @ xx, Q @ xx - b)
+    lo, hi = np.full(6, -0.4), np.full(6, 2.0)
+    wv = np.array([1.0, 2.0, 0.0, 0.5, 0.0, 1.0])
+    free = opt.minimize(fun, np.zeros(6), jac=True, method="L-BFGS-B", bounds=list(zip(lo, hi)))
+    cmax = wv @ free.x - 0.8  # cuts the bounded optimum off
+    ref = opt.minimize(fun, np.zeros(6), jac=True, method="SLSQP", bounds=list(zip(lo, hi)), options={"ftol": 1e-14},
+                       constraints={"type": "ineq", "fun": lambda xx: cmax - wv @ xx, "jac": lambda xx: -wv})
+    f, xs, iters, status, nev, mu = pqn_port.minimize_port(fun, np.zeros(6), lo, hi, wv, cmax, stop_loss=-np.inf)
+    assert status in (0, 4) and mu > 0 and wv @ xs <= cmax and wv @ xs > cmax - 1e-7
+    assert abs(f - ref.fun) < 1e-6 and np.allclose(xs, ref.x, atol=1e-4)
+    f2, x2, *_ = pqn_port.minimize_port(fun, np.zeros(6), lo, hi, None, 0.0, stop_loss=-np.inf)
+    assert abs(f2 - free.fun) < 1e-7  # without the constraint: the L-BFGS-B optimum
