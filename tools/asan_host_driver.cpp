@@ -58,6 +58,7 @@ int main() {
     slam_v2_gate vg{};
     vg.n_params = 1;
     EXPECT(slam_v2_set_gates(nullptr, &vg, 1) == SLAM_ERR_INVALID);
+    EXPECT(slam_v2_set_constraint(nullptr, 1, d, 13, 1.0) == SLAM_ERR_INVALID);
     EXPECT(slam_v2_eval_loss_grad(nullptr, 1, i32, d, i32, 1, d, d, d) == SLAM_ERR_INVALID);
     EXPECT(slam_v2_minimize_stage(nullptr, 1, i32, nullptr, 1, nullptr, d, d, nullptr, nullptr, &prm, 1e-10, d, d, i32, d, i32, i32, i32) == SLAM_ERR_INVALID);
     EXPECT(slam_v2_decompose_range(nullptr, 0, 1, 1, 1, i32, d, d, nullptr, nullptr, &prm, 1e-10, d, d, i32) == SLAM_ERR_INVALID);
