@@ -302,7 +302,8 @@ def make_comm(rank: int, world: int, local_rank: int):
     return comm
 
 
-def run_v2(rank: int, local_rank: int, steps: int = 64, warmup: int = 8, n_targets: int = 4096, restarts: int = 16, n_streams: int = 4, group: int = 8):
+def run_v2(rank: int, local_rank: int, steps: int = 64, warmup: int = 8, n_targets: int = 4096, restarts: int = 16, n_streams: int = 4, group: int = 8,
+           base_gate=None, gate_desc: str = "RiSwapGate"):
     """secondary.v2: CircuitTemplateV2(base_gates=[RiSwapGate]) -- every gate instance with its own free alpha -- SquareCost,
     spans 1..3, `n_targets` Haar targets x `restarts` restarts per step.  The span loop is the one TemplateOptimizer runs for a
     V2 template (optimizer.py:_run_batch_v2 -> slam_v2_decompose_range): enqueued on the device as one chain of kernels per
@@ -313,7 +314,7 @@ def run_v2(rank: int, local_rank: int, steps: int = 64, warmup: int = 8, n_targe
     from slam_decomposition_amd.basisv2 import CircuitTemplateV2
     from slam_decomposition_amd.gates import RiSwapGate
 
-    basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=3)
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate if base_gate is None else base_gate], maximum_span_guess=3)
     total = steps + warmup
     group = max(1, min(group, steps))
     n_streams = max(1, min(n_streams, (steps + group - 1) // group))
@@ -382,7 +383,7 @@ def run_v2(rank: int, local_rank: int, steps: int = 64, warmup: int = 8, n_targe
     kms_span = {k: sum(x["kernel_ms_span"][k] for x in sts) for k in (1, 2, 3)}
     flops = sum(ev[k] * f_eval_v2(k) for k in (1, 2, 3))
     return {
-        "workload": f"CircuitTemplateV2(base_gates=[RiSwapGate]) (one free alpha per gate), SquareCost, spans 1..3, {n_targets} Haar targets x {restarts} restarts per step",
+        "workload": f"CircuitTemplateV2(base_gates=[{gate_desc}]) (free gate parameters per gate instance), SquareCost, spans 1..3, {n_targets} Haar targets x {restarts} restarts per step",
         "value": solved / elapsed, "unit": "decompositions/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
         "batches_in_flight_per_gpu": n_streams, "steps_per_library_call": group,
         "solved_fraction": solved / (steps * n_targets), "best_cycles_hist": {str(k): int(hist[k]) for k in range(4)},
