@@ -682,9 +682,12 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
     int nev = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
     double f = 0.0, alpha = 0.0, gp = 0.0, gnorm = 0.0, grow = 1.0, hs1 = 0.0;
     const double* tcol = args.targets + q * 2;
-    double x[NA], g[NA], p[NA], hg[NA];  // hg = (H + hs1 I) g: the unprojected direction, negated
+    // hg = (H + hs1 I) g: the unprojected direction, negated.  Without bounds (FREE) the direction is never masked, p = -hg
+    // throughout, and hg is not kept (HG(a) reads -p[a]): 2 NA registers
+    double x[NA], g[NA], p[NA], hg[FREE ? 1 : NA];
+#define HG(a) (FREE ? -p[a] : hg[FREE ? 0 : (a)])
 #pragma unroll
-    for (int a = 0; a < NA; ++a) { x[a] = 0.0; g[a] = 0.0; p[a] = 0.0; hg[a] = 0.0; }
+    for (int a = 0; a < NA; ++a) { x[a] = 0.0; g[a] = 0.0; p[a] = 0.0; if constexpr (!FREE) hg[a] = 0.0; }
     HStore<NA, v2_h_in_memory<K, QN>()> H;
     H.bind(args.hmem + (size_t)blockIdx.x * v2_h_floats_per_wave<K, QN>(), lane);
     H.set_identity_where(q, true);
@@ -778,7 +781,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
                         const double2 b = bnd[i];
                         xv = fmin(fmax(xv, b.x), b.y);
                     }
-                    x[a] = xv; g[a] = 0.0; p[a] = 0.0; hg[a] = 0.0;
+                    x[a] = xv; g[a] = 0.0; p[a] = 0.0; if constexpr (!FREE) hg[a] = 0.0;
                 }
                 alpha = 0.0; gp = 0.0; f = 0.0; grow = 1.0; hs1 = 0.0;
                 nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
@@ -876,7 +879,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             qv[a] = fma(hs1, gt[a], qv[a]);              // (H + hs1 I) g'
-            const double ua = fma(-fac, hg[a], qv[a]);   // (H + hs1 I) y
+            const double ua = fma(-fac, HG(a), qv[a]);   // (H + hs1 I) y
             yu = fma(gt[a] - g[a], ua, yu);
         }
         yu = quad_sum(yu);
@@ -888,7 +891,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const double sa = FREE ? (step ? alpha : 0.0) * p[a] : (step ? xt[a] - x[a] : 0.0);
-                const double ua = fma(-fac, hg[a], qv[a]);
+                const double ua = fma(-fac, HG(a), qv[a]);
                 const double wa = cf * sa - rho * ua;  // rho = cf = 0 unless curv: w = v = 0, H unchanged
                 const double va = -rho * ua;
                 s32[a] = (float)sa; w32[a] = (float)wa; v32[a] = (float)va;
@@ -910,21 +913,21 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const double sa = FREE ? (step ? alpha : 0.0) * p[a] : (step ? xt[a] - x[a] : 0.0);
-                const double ua = fma(-fac, hg[a], qv[a]);
+                const double ua = fma(-fac, HG(a), qv[a]);
                 const double va = -rho * ua;
                 x[a] = FREE ? fma(step ? alpha : 0.0, p[a], x[a]) : xt[a];  // (FREE: the same fma that formed the trial point)
                 g[a] = gt[a];
                 // H' g' = (H + hs1 I) g' + s (w.g') + v (s.g'); the direction is its negative, projected: no component may
                 // point out of the box
                 const double hn = qv[a] + sa * wg + va * sg;
-                hg[a] = hn;
+                if constexpr (!FREE) hg[a] = hn;
                 p[a] = -hn;
             }
             if (bounded) {
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
                     const double2 b = bnd[4 * a + q];
-                    const bool out = (x[a] <= b.x && hg[a] > 0.0) || (x[a] >= b.y && hg[a] < 0.0);
+                    const bool out = (x[a] <= b.x && HG(a) > 0.0) || (x[a] >= b.y && HG(a) < 0.0);
                     p[a] = out ? 0.0 : p[a];
                 }
             }
@@ -990,7 +993,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
                 double pn = -g[a];
                 if ((x[a] <= b.x && pn < 0.0) || (x[a] >= b.y && pn > 0.0)) pn = 0.0;
                 p[a] = reset ? pn : p[a];
-                hg[a] = reset ? g[a] : hg[a];
+                if constexpr (!FREE) hg[a] = reset ? g[a] : hg[a];
                 gg2 = fma(g[a], pn, gg2);
             }
             gg2 = quad_sum(gg2);
@@ -1052,5 +1055,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
     }
     if (lane == 0 && rounds) atomicAdd(&args.ctl->rounds, (unsigned long long)rounds);
 }
+
+#undef HG
 
 }  // namespace slamdev
