@@ -25,6 +25,9 @@ constexpr double kGrowMax = 1048576.0;  // happening).  Covers negative curvatur
 // evaluations where SciPy's BFGS needs 50..170 from the same start, and ONE such item sets the duration of its whole stage
 // (CNOT k = 2, 1 M items: pct 99.99 of the evaluation counts 197, maximum 1309).  Restarted, it is through in ~40 more.  128 is
 // past the 99th percentile of the iteration counts at every span: the mean does not notice.  (oracle/bfgs_port.py: RESTART_PERIOD)
+#ifndef SLAM_REMAT_Q_COND
+#define SLAM_REMAT_Q_COND (K == 2)
+#endif
 #ifndef SLAM_RESTART_PERIOD
 #define SLAM_RESTART_PERIOD 128
 #endif
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
         // q is re-materialised every iteration: otherwise the lane-dependent LDS addresses derived from it
         // (gradient gather, stash slots) are hoisted out of the loop, kept live across it, spilled to scratch
         // and reloaded -- one exposed memory latency each -- in every round
-        if constexpr (K == 2) {
+        if constexpr (SLAM_REMAT_Q_COND) {
             asm volatile("" : "+v"(q));  // (measured: pays at k = 2 only)
             __builtin_assume((unsigned)q < 4u);  // keeps the slot-validity tests 4 a + q < N compile-time for a < NA - 1
         }

@@ -596,6 +596,12 @@ struct HStore<NA, true> {
 // ---------------------------------------------------------------------------------------------------------------
 // projected quasi-Newton minimisation, persistent wavefronts over the stage's restart-major work queue
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef SLAM_V2_REMAT_Q
+#define SLAM_V2_REMAT_Q 1
+#endif
+#ifndef SLAM_V2_REMAT_Q_COND
+#define SLAM_V2_REMAT_Q_COND (K >= 2)
+#endif
 #ifndef SLAM_V2_WAVES
 #define SLAM_V2_WAVES(K, QN, GQ, FREE) (((K) == 1 && (GQ) == 1 && (FREE)) ? 2 : 1)
 #endif
@@ -650,7 +656,8 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
     using C = CfgV2<K, QN>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int lane = threadIdx.x, q = lane & 3, quad = lane >> 2;
+    const int lane = threadIdx.x, quad = lane >> 2;
+    int q = lane & 3;
     double* xq = lds + quad * C::XSTRIDE;
     float* xq32 = reinterpret_cast<float*>(xq);
     double2* fh = reinterpret_cast<double2*>(lds + C::LDS_XCHG) + lane;
@@ -701,6 +708,14 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
     if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
 
     while (true) {
+#if SLAM_V2_REMAT_Q
+        // q re-materialised every iteration (as minimize_kernel at k = 2): keeps the lane-dependent LDS addresses derived from it
+        // from being hoisted out of the loop and held in registers across it
+        if constexpr (SLAM_V2_REMAT_Q_COND) {
+            asm volatile("" : "+v"(q));
+            __builtin_assume((unsigned)q < 4u);
+        }
+#endif
         // ---- 1. idle quads pull the next queue positions (restart-major: position = restart * n_active + slot).
         // As in minimize_kernel: positions come in wave-private chunks (one atomicAdd per chunk, the next one requested
         // while the current one is consumed) and are scanned 64 at a time, so that the positions a successful sibling
