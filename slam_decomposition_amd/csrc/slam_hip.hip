@@ -1267,6 +1267,7 @@ int v2_launch_minimize(slam_ctx* c, const V2Stage& sgt) {
         if (sgt.riswap_like && !sgt.bounded && c->v2_cons_n[K] == 0) return v2_launch_minimize_gq<K, QN, 1, true>(c, sgt);  // RiSwapGate class, plain BFGS
         if (sgt.riswap_like) return v2_launch_minimize_gq<K, QN, 1, false>(c, sgt);
     }
+    if (!sgt.bounded && c->v2_cons_n[K] == 0) return v2_launch_minimize_gq<K, QN, 0, true>(c, sgt);  // general gates, plain BFGS
     return v2_launch_minimize_gq<K, QN, 0, false>(c, sgt);
 }
 

@@ -600,10 +600,10 @@ struct HStore<NA, true> {
 #define SLAM_V2_REMAT_Q 1
 #endif
 #ifndef SLAM_V2_REMAT_Q_COND
-#define SLAM_V2_REMAT_Q_COND (K >= 2)
+#define SLAM_V2_REMAT_Q_COND (K >= 2 || GQ == 0)
 #endif
 #ifndef SLAM_V2_WAVES
-#define SLAM_V2_WAVES(K, QN, GQ, FREE) (((K) == 1 && (GQ) == 1 && (FREE)) ? 2 : 1)
+#define SLAM_V2_WAVES(K, QN, GQ, FREE) (((K) == 1 && (FREE)) ? 2 : 1)
 #endif
 template <int K, int QN>
 struct MinimizeV2Args {
