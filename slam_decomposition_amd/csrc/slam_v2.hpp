@@ -600,7 +600,7 @@ struct HStore<NA, true> {
 #define SLAM_V2_REMAT_Q 1
 #endif
 #ifndef SLAM_V2_REMAT_Q_COND
-#define SLAM_V2_REMAT_Q_COND (K >= 2 || GQ == 0)
+#define SLAM_V2_REMAT_Q_COND (K >= 2 || GQ == 0 || !FREE)
 #endif
 #ifndef SLAM_V2_WAVES
 #define SLAM_V2_WAVES(K, QN, GQ, FREE) (((K) == 1 && (FREE)) ? 2 : 1)
