@@ -596,6 +596,9 @@ struct HStore<NA, true> {
 // ---------------------------------------------------------------------------------------------------------------
 // projected quasi-Newton minimisation, persistent wavefronts over the stage's restart-major work queue
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef SLAM_V2_REFILL_BATCH
+#define SLAM_V2_REFILL_BATCH ((K == 1) ? 2 : 1)
+#endif
 #ifndef SLAM_V2_REMAT_Q
 #define SLAM_V2_REMAT_Q 1
 #endif
@@ -723,7 +726,12 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         // one atomic round trip each (first version: 0.5 G evaluations/s at k = 2 against 3.8 at k = 1: the stage was
         // bound by its single counter).
         bool taken = false;
-        while (!exhausted && __any(!live)) {
+        // (the refill code is wave-wide: at span 1, where items last ~ 30 rounds, it pays to let two quads go idle before running
+        // it, as in minimize_kernel)
+        constexpr int kRefillBatch = SLAM_V2_REFILL_BATCH;
+        const int n_idle0 = __popcll(__ballot(!live && q == 0));
+        const bool go = n_idle0 >= kRefillBatch || n_idle0 == kQuadsPerWave;
+        while (go && !exhausted && __any(!live)) {
             if (cur_next >= cur_end) {
                 const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)pre_base);
                 if (b >= n_items) { exhausted = true; break; }
