@@ -25,8 +25,15 @@
 //     sequential break, optimizer.py:287-295);
 //   * ONE symmetric mat-vec per iteration: H g is carried from the previous iteration, so H y = H g' - H g needs H g' only
 //     (the projected direction is no longer -H g, which is why the first version formed both);
-//   * the one-off scaling of the initial inverse Hessian as the scalar hs1 (metric H + hs1 I), as in minimize_kernel.
-// plus the gradient with respect to the gate angles and the projected quasi-Newton step for the box bounds.
+//   * the one-off scaling of the initial inverse Hessian as the scalar hs1 (metric H + hs1 I), as in minimize_kernel;
+//   * the queue taken in wave-private chunks and scanned 64 positions per flag load (as minimize_kernel: one atomic per
+//     pulled position bound the stages in which most positions are void);
+//   * the quad-lane index re-materialised every round for spans >= 2, the general gate class and the bounded kernels: LDS
+//     addresses derived from it are not hoisted and held across the loop (no scratch, fewer AGPRs, span 2 of the RiSwap
+//     class at two wavefronts per SIMD).
+// plus the gradient with respect to the gate angles, the projected quasi-Newton step for the box bounds (a failed line
+// search restarts the metric instead of ending the item) and the cost constraint of set_constraint (basisv2.py:192-200)
+// as a multiplier method around that loop (slam_v2_set_constraint).
 #pragma once
 #include "slam_device.hpp"
 #include "slam_kernels.hpp"
