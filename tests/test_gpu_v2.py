@@ -538,3 +538,45 @@ def test_cost_constraint_stage_matches_the_cpu_port_item_by_item(hip_ctx):
     hip_ctx.v2_set_constraint(3, None)
     free = hip_ctx.v2_minimize_stage([0, 0, 0], prm, 1e-10, ilo, ihi, blo, bhi, x0=x0)
     assert np.all(free["best_loss"] <= out["best_loss"] + 1e-9) and np.any(free["best_x"][:, 24:].sum(axis=1) > 1.0 + 1e-6)
+
+
+def test_cost_constraint_with_callback_and_sharded_devices():
+    """set_constraint through the other two host paths: use_callback=True (slam_v2_minimize_stage_trace: the recorded losses are
+    plain losses, the last one of the winning restart is the result) and devices=[0, 0] (every shard's context gets the
+    constraint; the sharded job returns the single-device results bit for bit)."""
+    def make():
+        b = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=2)
+        b.build(2)
+        b.spanning_range = range(2, 3)
+        for name in b.parameter_names():
+            if name.startswith("Q"):
+                b.add_bound(name, 1.0, 0.0)
+        b.set_constraint(0.6)
+        return b
+
+    targets = [o.haar_unitary(s) for s in (411, 412, 413, 414)]
+    one = TemplateOptimizer(make(), BasicCost(), training_restarts=6, seed=21, override_fail=True)
+    one.approximate_from_distribution(GateSample(targets[0]))  # warm path
+    res1 = [TemplateOptimizer(make(), BasicCost(), training_restarts=6, seed=21, override_fail=True).approximate_target_U(t) for t in targets[:1]]
+    basis = make()
+    both = TemplateOptimizer(basis, BasicCost(), training_restarts=6, seed=21, override_fail=True, devices=[0, 0])
+    single = TemplateOptimizer(make(), BasicCost(), training_restarts=6, seed=21, override_fail=True)
+
+    class Batch:
+        def __iter__(self):
+            return iter(targets)
+
+    _, _, d2 = both.approximate_from_distribution(Batch())
+    _, _, d1 = single.approximate_from_distribution(Batch())
+    for a, b in zip(d1, d2):
+        assert a.loss_result == b.loss_result and np.array_equal(np.asarray(a.Xk), np.asarray(b.Xk))
+        basis.build(2)
+        assert basis.circuit_cost(a.Xk) <= 0.6 + 1e-12 and a.loss_result > 1e-6  # too little interaction: the constraint binds
+    assert res1[0].loss_result == d1[0].loss_result  # seeds keyed on the target index: the same decomposition alone or in a batch
+    cb = TemplateOptimizer(make(), BasicCost(), training_restarts=6, seed=21, override_fail=True, use_callback=True)
+    loss, coords, data = cb.approximate_from_distribution(GateSample(targets[0]))
+    assert abs(data[0].loss_result - d1[0].loss_result) < 1e-9
+    rec = [v for v in loss[0] if v >= 0]  # (-1, k) markers removed: [k, losses..., ...]
+    # the record holds PLAIN losses (iterates of the multiplier method may be infeasible and lie below the feasible optimum);
+    # the winning restart's last one is the result
+    assert any(abs(v - data[0].loss_result) < 1e-9 for v in rec)
