@@ -432,7 +432,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     # device-side work queue per span over all their (target, restart) items, and come back as per-step slices.  With
     # the ordered early exit every step's results are bit for bit those of its own call (tests/test_gpu_round2.py).
     group = 1
-    if small and not (gname == "cgsweep") and not (main and args.span_rules):
+    if (small or (main and args.group)) and not (gname == "cgsweep") and not (main and args.span_rules):
         group = args.group if (main and args.group) else 20  # measured (320 steps, 4 streams): 10 -> 0.40, 16 -> 0.44, 20 -> 0.445, 32 -> 0.44 of peak
     group = max(1, min(group, steps))
     # (the basis sweep cannot group its steps -- every step has its own gate -- so it keeps more of them in flight; measured on
