@@ -11,4 +11,8 @@ monodromy are absent -- ordinary ``ModuleNotFoundError``; no permission was
 denied).  The oracle is therefore a NumPy/SciPy restatement pinned by the
 reference's recorded notebook outputs; see
 ``tests/test_oracle_kat.py``.
+
+Files: ``slam_oracle.py`` (template, loss, gradient, Haar sampler, ``c1c2c3``, the reference's restart loop on SciPy),
+``v2_oracle.py`` (templates with parametrised gates), ``bfgs_port.py`` (the kernel's quasi-Newton loop in NumPy),
+``pqn_port.py`` (its projected variant for box bounds and the multiplier method for a cost constraint).
 """
