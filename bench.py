@@ -119,11 +119,14 @@ def _cpu_one(args):
         gates = {"cx": [o.cx_matrix()], "sqiswap": [o.riswap_matrix(0.5)], "iswap+b": [o.riswap_matrix(1.0), o.berkeley_matrix()]}[gname]
     target = o.haar_unitary(seed0 + idx) if host_targets else o.haar_philox_port(seed0, idx)
     t0 = time.perf_counter()
-    best, _, k, stats = o.run_reference(
+    best, xk, k, stats = o.run_reference(
         target, gates, range(1, 4), restarts, SUCCESS_LOSS, x0_fn=lambda kk, r: o.x0_philox(seed, idx, r, kk),
         analytic_jac=analytic,
     )
-    return best, k, time.perf_counter() - t0, stats["nfev"]
+    dt = time.perf_counter() - t0
+    # (outside the clock) Weyl coordinates of the circuit the reference path found: compared with the GPU's for the same target
+    coords = o.c1c2c3_raw(o.template_eval(xk, o.gate_sequence(gates, k)))
+    return best, k, dt, stats["nfev"], [float(c) for c in coords]
 
 
 def usable_cores():
@@ -147,7 +150,52 @@ def usable_cores():
     return min(n, 64), quota  # (64: beyond that the sample below would exceed the bench's time budget)
 
 
-def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool):
+def parity_sample_size(n_sample: int) -> int:
+    return n_sample if n_sample > 0 else 12 * usable_cores()[0]
+
+
+def weyl_distance(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Max-norm distance of Weyl coordinates (units of pi), modulo the identification (c1, c2, 0) ~ (1 - c1, c2, 0) on the c3 = 0 face."""
+    d = np.abs(a - b).max(axis=-1)
+    am = a.copy()
+    am[..., 0] = 1.0 - am[..., 0]
+    am[..., 2] = -am[..., 2]
+    return np.minimum(d, np.abs(am - b).max(axis=-1))
+
+
+def parity_sample(res, gpu):
+    """north_star: "match the reference path's converged loss and recovered Weyl coordinates to 1e-6 on identical Haar targets".
+    `res` = the CPU baseline's per-target results (SciPy BFGS + finite differences on the oracle: the reference's path,
+    optimizer.py:270-278), `gpu` = (best_loss, best_cycles, found coordinates) of the HIP path for the SAME target indices and
+    Philox start points.  A target counts as solved below SUCCESS_LOSS on either side."""
+    g_loss, g_cyc, g_coords, t_coords = gpu
+    n = min(len(res), len(g_loss))
+    c_loss = np.array([r[0] for r in res[:n]])
+    c_cyc = np.array([r[1] for r in res[:n]])
+    c_coords = np.array([r[4] for r in res[:n]])
+    c_ok, g_ok = c_loss < SUCCESS_LOSS, g_loss[:n] < SUCCESS_LOSS
+    both = c_ok & g_ok
+    neither = ~c_ok & ~g_ok  # out of the template's reach for both (basis sweep): different local minima are not a mismatch
+    cycles_equal = int((both & (c_cyc == g_cyc[:n])).sum() + neither.sum())
+    dl = float(np.abs(c_loss - g_loss[:n])[both].max()) if both.any() else 0.0
+    # coordinates of the found circuits against the TARGET's: the HIP path must recover them to 1e-6; the reference path's own circuits
+    # sit ~ sqrt(loss) ~ 3e-5 off (its finite-difference floor: loss ~ 1e-9), so path against path the bound is 1e-6 + 4 sqrt(CPU loss)
+    d_gt = weyl_distance(g_coords[:n][both], t_coords[:n][both]) if both.any() else np.zeros(0)
+    d_ct = weyl_distance(c_coords[both], t_coords[:n][both]) if both.any() else np.zeros(0)
+    d_gc = weyl_distance(c_coords[both], g_coords[:n][both]) if both.any() else np.zeros(0)
+    coords_ok = bool(np.all(d_gt <= 1e-6) and np.all(d_gc <= 1e-6 + 4.0 * np.sqrt(c_loss[both])))
+    ok = cycles_equal >= n - 2 and dl <= 1e-6 and coords_ok
+    mx = lambda v: float(v.max()) if len(v) else 0.0
+    return {"n": n, "cycles_equal": cycles_equal, "solved_cpu": int(c_ok.sum()), "solved_gpu": int(g_ok.sum()), "both_unsolved": int(neither.sum()),
+            "max_abs_loss_diff": dl, "max_coord_diff_gpu_vs_target": mx(d_gt), "max_coord_diff_cpu_vs_target": mx(d_ct),
+            "max_coord_diff_gpu_vs_cpu": mx(d_gc), "tolerance": 1e-6, "pass": bool(ok),
+            "what": "reference path (SciPy BFGS, finite differences, sequential restarts on the NumPy oracle) vs the HIP path on the same target "
+                    "indices and the same Philox start points; coordinates = c1c2c3 of the found circuits, units of pi; required: equal cycles "
+                    "(n - 2 at least), |loss difference| <= 1e-6, HIP coordinates within 1e-6 of the target's, path against path within "
+                    "1e-6 + 4 sqrt(reference loss) (the reference path's own accuracy)"}
+
+
+def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool, gpu_sample=None):
     import multiprocessing as mp
 
     # every core the box GIVES this process: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box of
@@ -156,8 +204,7 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
     cores, quota = usable_cores()
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ.setdefault(var, "1")  # one target per worker process: no BLAS thread pools on top
-    if n_sample <= 0:
-        n_sample = 12 * cores  # every core busy for a dozen targets: ~15-25 s of wall time for the two passes
+    n_sample = parity_sample_size(n_sample)  # every core busy for a dozen targets: ~15-25 s of wall time for the two passes
     with mp.get_context("spawn").Pool(cores) as pool:
         pool.map(abs, range(cores))  # workers up (interpreter + NumPy/SciPy import) before the clock starts
         t0 = time.perf_counter()
@@ -171,7 +218,8 @@ def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int
     cpu_s = sum(r[2] for r in res)
     ok_j = sum(1 for r in res_j if r[0] < SUCCESS_LOSS)
     cpu_sj = sum(r[2] for r in res_j)
-    return {
+    parity = parity_sample(res, gpu_sample) if gpu_sample is not None else None
+    return parity, {
         "value": ok / wall,
         "unit": "decompositions/s",
         "cores": cores,
@@ -402,6 +450,38 @@ def run_v2(rank: int, local_rank: int, steps: int = 64, warmup: int = 8, n_targe
     }
 
 
+def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: int = 3):
+    """secondary.api: the drop-in method north_star names, end to end --
+    ``TemplateOptimizer(CircuitTemplate([RiSwapGate(1/2)], maximum_span_guess=3), BasicCost(), training_restarts=32)
+    .approximate_from_distribution(DeviceHaarBatch(n_samples=65536))`` (src/slam/optimizer.py:180-186): targets generated on the
+    device, ONE blocking call, results back as the reference's 3-tuple (training_loss, coordinate_list, [DataDictEntry]).  Wall
+    time of the whole Python call, median of `reps` after one untimed call; a fresh sampler seed per call."""
+    from slam_decomposition_amd import _ffi
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.gates import RiSwapGate
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    from slam_decomposition_amd.sampler import DeviceHaarBatch
+
+    device = local_rank % max(1, _ffi.device_count())
+    basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3, device=device)
+    times, solved = [], 0
+    for r in range(reps + 1):
+        opt = TemplateOptimizer(basis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True)
+        t0 = time.perf_counter()
+        loss, _, data = opt.approximate_from_distribution(DeviceHaarBatch(seed=TARGET_SEED0 + 9_000_000 + r, n_samples=n_targets, device=device))
+        dt = time.perf_counter() - t0
+        if r:
+            times.append(dt)
+            solved = int((np.asarray(loss) < SUCCESS_LOSS).sum())
+            assert len(data) == n_targets and data[n_targets - 1].cycles in (2, 3)
+    times.sort()
+    med = times[(len(times) - 1) // 2]
+    return {"workload": f"TemplateOptimizer.approximate_from_distribution(DeviceHaarBatch(n_samples={n_targets})), sqrt(iSWAP) span<=3, {restarts} restarts, one blocking call",
+            "value": solved / med, "unit": "decompositions/s", "wall_ms": 1e3 * med, "wall_ms_all": [round(1e3 * t, 3) for t in times],
+            "solved_fraction": solved / n_targets, "kernel_ms": opt.last_stats["kernel_ms"]}
+
+
 # ------------------------------------------------------------------------------------------------
 def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool):
     """Run `warmup` untimed + `steps` timed steps of one workload; returns the dict of measurements."""
@@ -445,6 +525,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     sweep = gname == "cgsweep"
     host_targets = main and args.host_targets
     span_rules_mode = main and args.span_rules
+    stub_mode = bool(os.environ.get("SLAM_BENCH_TEST_STUB"))
     # every batch resident in HBM before the timed region: Haar targets generated in place by the device
     # sampler (slam_sample_haar; --host-targets: SciPy's sampler on the host, ~55 us per target, then uploaded)
     n_resident = n_per_step if sweep else total_steps * n_per_step  # the sweep's targets are shared by all bases
@@ -576,11 +657,15 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
                     for g in groups[w::n_streams]:
                         for s in g:
                             comm.raw.merge_add(ctxs[w], s * n_per_step, n_per_step, rank * n_loc + (s - first_step) * n_per_step)
+                t_c = time.perf_counter()
                 results["merged_solved"], _ = comm.raw.allreduce_min_merged(SUCCESS_LOSS)
+                results["collective_ms"] = 1e3 * (time.perf_counter() - t_c)
             else:
                 merged = np.full(world * n_loc, np.inf)
                 merged[rank * n_loc : (rank + 1) * n_loc] = np.concatenate([results[s][0] for s in step_ids])
+                t_c = time.perf_counter()
                 comm.allreduce_min(merged)
+                results["collective_ms"] = 1e3 * (time.perf_counter() - t_c)
                 results["merged_solved"] = int((merged < SUCCESS_LOSS).sum())
 
     # set-up, not a step: every context runs one batch once so that its device buffers exist and its
@@ -621,6 +706,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         res = {}
         t0 = time.perf_counter()
         run_steps(list(range(warmup, total_steps)), res, warmup)
+        res["own_ms"] = 1e3 * (time.perf_counter() - t0)  # this rank's own steps + the collective, before the closing barrier
         sync()
         tt = np.array([time.perf_counter() - t0])
         comm.allreduce_max(tt)  # max over ranks of the time
@@ -651,42 +737,87 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
             per_basis[b] = {"solved_fraction": float(ok.mean()), "mean_cycles": float(bc[ok].mean()) if ok.any() else None}
 
     # solved targets counted on the all-reduced vector (same on every rank)
+    rank_diag = None
     if world > 1:
         solved_all = res["merged_solved"]
         cnt = np.array([float(solved)])
         comm.allreduce_sum(cnt)
         assert int(cnt[0]) == solved_all, "merged best-loss vector disagrees with the per-rank counts"
+        # what a first N > 1 run needs to diagnose itself: every rank's own time for the median repetition's timed region
+        # (steps + collective, before the closing barrier), its solved count, the collective's duration, its evaluations
+        flat = np.zeros(world * 4)
+        flat[4 * rank : 4 * rank + 4] = [res["own_ms"], float(solved), res.get("collective_ms", 0.0), float(sum(st["evals"][k] for k in (1, 2, 3)))]
+        comm.allreduce_sum(flat)
+        diag = flat.reshape(world, 4)
+        rank_diag = {"own_ms": [round(float(v), 3) for v in diag[:, 0]], "solved": [int(v) for v in diag[:, 1]],
+                     "collective_ms": [round(float(v), 3) for v in diag[:, 2]], "evals": [int(v) for v in diag[:, 3]],
+                     "note": "per rank, median repetition: wall time of its own steps + the final collective (before the closing barrier), "
+                             "targets it solved, duration of the collective as it saw it, loss+gradient evaluations"}
     else:
         solved_all = solved
 
     # per-span pass, ONE batch in flight: launches do not overlap, so every frac below is evals x F_eval(k) / the HIP
     # events around that launch -- the figure `rocprofv3 --kernel-trace --stats` reports for the same launches
-    # (profiles/r2_*_single_stream_kernel_stats.csv).  Not part of `value`.
+    # (tools/r4_trace_summary.py picks them out of the driver command's trace).  Not part of `value`.
+    # The steps are enqueued BACK TO BACK on one stream (no result fetch in between: the 13 MB copy into pageable memory
+    # leaves the chip idle for ~1 ms, and the launch after an idle gap runs 2-10 % slower while the clock ramps:
+    # profiles/r4_solo_probe.txt), after one untimed step of the same kind.
     per_span = None
     if main and rank == 0 and not span_rules_mode and args.per_span_steps > 0:
         c = ctxs[0]
-        c.reset_stats()
-        for s in range(min(args.per_span_steps, total_steps)):
-            one_step(s, c)
-        ps = c.stats()
+
+        def solo_step(s):
+            if sweep:
+                c.set_gates(np.stack([sweep_gate(basis_of(s))]))
+                c.decompose_range(0, n_per_step, 1, 3, gate_seqs, prm, threshold, fetch=False)
+            else:
+                c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm, threshold, fetch=False)
+
+        solo_step(0)
+        rows = []
+        for s in range(args.per_span_steps):
+            c.reset_stats()
+            solo_step(s % total_steps)
+            rows.append(c.stats())
         per_span = {}
         for k in (1, 2, 3):
-            ms = ps["kernel_ms_span"][k]
-            n_launch = args.per_span_steps if ps["items"][k] else 0
-            if not n_launch or ms <= 0:
+            rk = [r for r in rows if r["items"][k] and r["kernel_ms_span"][k] > 0]
+            if not rk:
                 continue
+            ms = sum(r["kernel_ms_span"][k] for r in rk)
+            ev = sum(r["evals"][k] for r in rk)
             per_span[str(k)] = {
-                "launches": n_launch,
-                "evals_per_launch": ps["evals"][k] / n_launch,
-                "hip_event_ms": ms / n_launch,
-                "achieved": ps["evals"][k] * f_eval(k) / (ms * 1e-3) / 1e12,
-                "frac": ps["evals"][k] * f_eval(k) / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                "quad_occupancy": ps["evals"][k] / 16 / max(1, ps["wave_rounds"][k]),
+                "launches": len(rk),
+                "evals_per_launch": ev / len(rk),
+                "hip_event_ms": ms / len(rk),
+                "hip_event_ms_all": [round(r["kernel_ms_span"][k], 4) for r in rk],
+                "achieved": ev * f_eval(k) / (ms * 1e-3) / 1e12,
+                "frac": ev * f_eval(k) / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "quad_occupancy": ev / 16 / max(1, sum(r["wave_rounds"][k] for r in rk)),
             }
-        tot_ms = sum(ps["kernel_ms_span"][k] for k in (1, 2, 3))
-        tot_fl = sum(ps["evals"][k] * f_eval(k) for k in (1, 2, 3))
-        per_span["all"] = {"hip_event_ms_per_step": tot_ms / args.per_span_steps,
-                           "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if tot_ms > 0 else None}
+        tot_ms = sum(r["kernel_ms_span"][k] for r in rows for k in (1, 2, 3))
+        tot_fl = sum(r["evals"][k] * f_eval(k) for r in rows for k in (1, 2, 3))
+        per_span["all"] = {"hip_event_ms_per_step": tot_ms / len(rows),
+                           "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if tot_ms > 0 else None,
+                           "mode": "one batch in flight, steps enqueued back to back on one stream, no result fetch in between"}
+
+    # parity sample: the HIP path's answers for the targets the CPU baseline solves (same indices of the resident array, same
+    # Philox start points); with the ordered early exit a window's results do not depend on what else is in the call
+    gpu_sample = None
+    if main and rank == 0 and world == 1 and not args.no_cpu_baseline and not span_rules_mode and not host_targets and not stub_mode:
+        n_s = min(parity_sample_size(args.cpu_sample), n_per_step)
+        c = ctxs[0]
+        if sweep:
+            c.set_gates(np.stack([sweep_gate(SWEEP_CPU_BASIS)]))
+        g_loss, g_x, g_cyc = c.decompose_range(0, n_s, 1, 3, gate_seqs, prm, threshold)
+        g_coords = np.full((n_s, 3), np.nan)
+        for k in np.unique(g_cyc):
+            k = int(k)
+            if k < 1:
+                continue
+            sel = np.nonzero(g_cyc == k)[0]
+            g_coords[sel] = c.eval_c1c2c3(gate_seqs[k - 1], np.ascontiguousarray(g_x[sel, : 6 * (k + 1)]), ndigits=-1)
+        gpu_sample = (g_loss, g_cyc, g_coords, c.targets_c1c2c3(0, n_s, ndigits=-1))
 
     for c in ctxs:
         c.close()
@@ -705,7 +836,8 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         "n_streams": n_streams, "ipq": ipq, "dev_name": dev_name, "cus": cus, "elapsed": elapsed, "solved_all": solved_all,
         "cyc_hist": cyc_hist, "worst": worst, "per_basis": per_basis, "st": st, "achieved": achieved, "kernel_s": kernel_s,
         "rejected": rejected, "flops_accepted": flops_accepted, "flops_strict": flops_strict, "per_span": per_span,
-        "resident_merge": resident_merge, "rep_ms": rep_ms, "strong": strong, "group": group,
+        "resident_merge": resident_merge, "rep_ms": rep_ms, "strong": strong, "group": group, "gpu_sample": gpu_sample,
+        "rank_diag": rank_diag,
     }
 
 
@@ -744,6 +876,7 @@ def main():
     ap.add_argument("--per-span-steps", type=int, default=3, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 / v2 measurements")
     ap.add_argument("--v2-only", action="store_true", help="dev: run only the secondary.v2 measurement (CircuitTemplateV2) and print it")
+    ap.add_argument("--api-only", action="store_true", help="dev: run only the secondary.api measurement (TemplateOptimizer.approximate_from_distribution) and print it")
     args = ap.parse_args()
 
     stub = os.environ.get("SLAM_BENCH_TEST_STUB")
@@ -760,6 +893,9 @@ def main():
 
     if args.v2_only:
         print(json.dumps(run_v2(0, 0)), flush=True)
+        return
+    if args.api_only:
+        print(json.dumps(run_api(0)), flush=True)
         return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):
@@ -792,6 +928,7 @@ def main():
         }}
         if rank == 0 and not os.environ.get("SLAM_BENCH_TEST_STUB"):
             secondary["v2"] = run_v2(rank, local_rank)
+            secondary["api"] = run_api(local_rank)
 
     rank_devices = gather_strings(comm, rank, world, f"{m['dev_name'].strip()} cu={m['cus']} dev={local_rank}")
     if rank == 0:
@@ -854,6 +991,11 @@ def main():
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": m["achieved"] / PEAK_FP64_VALU_TFLOPS,
+                # the DOMINANT kernel alone on the chip (minimize_kernel<1>: 64 % of the flops): algorithmic flops of a launch / the
+                # HIP events around it, mean over the back-to-back single-stream launches of `per_span` (= rocprofv3's average for
+                # those launches, profiles/r4_trace_summary.json).  `frac` above is the whole job on the wall clock.
+                "frac_kernel": (m["per_span"] or {}).get("1", {}).get("frac"),
+                "kernel_dominant": "minimize_kernel<1, *>",
                 "traffic": traffic_per_launch(args.workload),
                 # north_star's two evidence figures, per span, from the committed PMC passes of this workload
                 "valu_busy": pmc["valu_busy"] if pmc else None,
@@ -863,6 +1005,7 @@ def main():
                 "scope": "rank 0's GPU",
                 "time_basis": "hip_events" if m["n_streams"] == 1 else "wall_clock_of_timed_region",
                 "kernel_ms_total": st["kernel_ms"],
+                "kernel_ms_span": {str(k): st["kernel_ms_span"][k] for k in (1, 2, 3)},
                 "kernel_launches": st["kernel_launches"],
                 "avg_launch_ms": st["kernel_ms"] / n_launch,
                 "evals_per_span": {str(k): st["evals"][k] for k in (1, 2, 3)},
@@ -884,9 +1027,19 @@ def main():
         }
         if secondary:
             out["secondary"] = secondary
+        if m["rank_diag"]:
+            out["rank_diag"] = m["rank_diag"]
+        parity = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m["gname"], m["restarts"], TARGET_SEED0, OPT_SEED, args.cpu_sample, args.host_targets)
+            parity, out["cpu_baseline"] = cpu_baseline(m["gname"], m["restarts"], TARGET_SEED0, OPT_SEED, args.cpu_sample, args.host_targets,
+                                                       gpu_sample=m["gpu_sample"])
+            if parity is not None:
+                out["parity_sample"] = parity
         print(json.dumps(out), flush=True)
+        if parity is not None and not parity["pass"]:
+            print(f"[bench] parity sample FAILED: {parity}", file=sys.stderr, flush=True)
+            comm.close()
+            raise SystemExit(4)
     comm.close()
 
 

@@ -236,6 +236,17 @@ int slam_decompose_range_fetch(slam_ctx* ctx, int64_t first, int64_t count, int 
                                const slam_opt_params* params, double success_threshold, double* best_loss, double* best_x,
                                int32_t* best_cycles);
 
+/* The span loops of SEVERAL contexts in one chain of kernels (round 4): n_ctx contexts on one device, each holding the target
+ * window [first, first + count) and ITS OWN gate table (slam_set_gates) -- the bases of a basis-gate sweep
+ * (src/slam/utils/gates/bare_candidates.py:47-69 builds such a family; the reference then runs one TemplateOptimizer per gate).
+ * Per span ONE optimizer launch serves all of them -- a wavefront works on one context's queue at a time, so the gates stay scalar
+ * operands -- and one bookkeeping launch.  Every context ends with exactly the resident results its own slam_decompose_range
+ * call would have left (needs SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED: results independent of scheduling); fetch them per
+ * context with slam_fetch_results_range.  Spans 1..3; the work is enqueued on ctxs[0]'s stream, whose statistics get the kernel
+ * times (evaluation counts go to each context's own statistics).  The contexts must be idle and distinct. */
+int slam_decompose_multi(slam_ctx** ctxs, int32_t n_ctx, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                         const slam_opt_params* params, double success_threshold);
+
 /* The same for an explicit list of resident-target indices (e.g. the targets a span predictor assigns to one
  * template size: CircuitTemplate.get_spanning_range with use_polytopes, src/slam/basis.py:95-100).  Results land
  * in the per-target resident arrays like those of slam_decompose_range; fetch them with
@@ -418,6 +429,13 @@ int slam_allreduce_min(slam_comm* comm, double threshold, int64_t* n_below, doub
 
 /* Library version string. */
 const char* slam_version(void);
+
+/* Binary interface revision: bumped whenever an exported function changes its signature or a structure its layout (round 4: 4 --
+ * slam_allreduce_min took its fifth argument, merged_capacity, in round 3 without a new symbol; a caller built against an older
+ * header must check this before calling).  The Python binding refuses a library whose revision differs from the one it was
+ * written for. */
+#define SLAM_ABI_VERSION 4
+int slam_abi_version(void);
 
 #ifdef __cplusplus
 }

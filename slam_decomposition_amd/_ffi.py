@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLAM_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslamhip.so")
 
+ABI_VERSION = 4  # include/slam_hip.h: SLAM_ABI_VERSION
 MAX_SPAN_EVAL = 5
 MAX_SPAN_MINIMIZE = 5
 
@@ -32,6 +33,7 @@ COST_BASIC, COST_SQUARE = 0, 1
 EXPORTED_SYMBOLS = (
     "slam_last_error",
     "slam_version",
+    "slam_abi_version",
     "slam_device_count",
     "slam_ctx_create",
     "slam_ctx_destroy",
@@ -51,6 +53,7 @@ EXPORTED_SYMBOLS = (
     "slam_fetch_results",
     "slam_decompose_range",
     "slam_decompose_list",
+    "slam_decompose_multi",
     "slam_decompose_range_fetch",
     "slam_fetch_results_range",
     "slam_fetch_span_losses",
@@ -150,6 +153,15 @@ def load_library() -> C.CDLL:
     dp = np.ctypeslib.ndpointer
     lib.slam_last_error.restype = C.c_char_p
     lib.slam_version.restype = C.c_char_p
+    variant = "SLAM_HIP_LIB" in os.environ  # an A/B build selected by a dev tool: older entry points are tolerated
+    if hasattr(lib, "slam_abi_version"):
+        lib.slam_abi_version.restype = C.c_int
+        abi = int(lib.slam_abi_version())
+    else:
+        abi = 0
+    if abi != ABI_VERSION and not variant:
+        raise ImportError(f"{LIB_PATH}: binary interface revision {abi}, this binding is written for {ABI_VERSION} (include/slam_hip.h: "
+                          "SLAM_ABI_VERSION): rebuild the library with `make`")
     lib.slam_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.slam_ctx_create.argtypes = [C.c_int, C.POINTER(P)]
     lib.slam_ctx_destroy.argtypes = [P]
@@ -171,6 +183,8 @@ def load_library() -> C.CDLL:
     if hasattr(lib, "slam_decompose_range_fetch"):  # (absent from older A/B builds selected with SLAM_HIP_LIB)
         lib.slam_decompose_range_fetch.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P, P]
     lib.slam_decompose_list.argtypes = [P, P, C.c_int64, C.c_int, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
+    if hasattr(lib, "slam_decompose_multi"):
+        lib.slam_decompose_multi.argtypes = [C.POINTER(P), C.c_int32, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results_range.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, P, P]
     if hasattr(lib, "slam_minimize_stage_trace"):
         lib.slam_fetch_span_losses.argtypes = [P, C.c_int64, C.c_int64, P]
@@ -190,8 +204,9 @@ def load_library() -> C.CDLL:
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.slam_reset_stats.argtypes = [P]
     lib.slam_best_loss_device_ptr.argtypes = [P, C.POINTER(P), C.POINTER(C.c_int64)]
-    lib.slam_ctx_device.argtypes = [P, C.POINTER(C.c_int)]
-    if hasattr(lib, "slam_comm_init"):
+    if hasattr(lib, "slam_ctx_device"):
+        lib.slam_ctx_device.argtypes = [P, C.POINTER(C.c_int)]
+    if hasattr(lib, "slam_comm_init") and (abi >= 4 or not variant):  # (older variants: slam_allreduce_min had four arguments)
         lib.slam_comm_get_unique_id.argtypes = [P]
         lib.slam_comm_init.argtypes = [C.c_int, C.c_int, C.c_int, P, C.POINTER(P)]
         lib.slam_comm_destroy.argtypes = [P]
@@ -206,7 +221,7 @@ def load_library() -> C.CDLL:
         if "SLAM_HIP_LIB" in os.environ and not hasattr(lib, name):
             continue  # an older A/B build: newer entry points are simply not used
         fn = getattr(lib, name)
-        if name not in ("slam_last_error", "slam_version"):
+        if name not in ("slam_last_error", "slam_version", "slam_abi_version"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -646,6 +661,17 @@ class Context:
         p, n = C.c_void_p(), C.c_int64(0)
         _check(self._lib.slam_best_loss_device_ptr(self._h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
+
+
+def decompose_multi(ctxs: Sequence["Context"], first: int, count: int, k_min: int, k_max: int, gate_seqs, params: OptParams,
+                    success_threshold: float) -> None:
+    """The span loops of several contexts (same device, same target window, each its own gate table) as ONE chain of kernels
+    (``slam_decompose_multi``): per span one multi-queue optimizer launch and one bookkeeping launch for all of them.  Results
+    stay resident in each context: ``ctx.fetch_results_range(k_max, first, count)``."""
+    lib = load_library()
+    flat = Context._flat_gate_seqs(gate_seqs, k_min, k_max)
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib.slam_decompose_multi(arr, len(ctxs), int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params), float(success_threshold)))
 
 
 class Comm:

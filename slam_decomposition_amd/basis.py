@@ -65,12 +65,19 @@ class CircuitTemplate(VariationalTemplate):
 
             self._gate_coords_all = [c1c2c3(m) for m in self.gate_matrices]
             self._gate_coords = self._gate_coords_all[0]
+            self._span_sequence = False
             if len(self.base_gates) == 1:
                 try:
                     span_rules.family_of(self._gate_coords)
                     self._span_exact = True
                 except NotImplementedError:
                     pass
+            if not self._span_exact:
+                # a sequence of different gates (or a gate outside the single-gate classes) whose one-, two- and three-gate
+                # coverage is known exactly (span_rules.sequence_minimal_span: e.g. [iSWAP, B])
+                seq = [self._gate_coords_all[i % len(self.base_gates)] for i in range(int(maximum_span_guess))]
+                if span_rules.sequence_is_exact(seq, int(maximum_span_guess)):
+                    self._span_exact = self._span_sequence = True
         super().__init__(preseed=preseed, use_polytopes=use_polytopes)
         self._reset()
         self.trotter = False
@@ -121,10 +128,15 @@ class CircuitTemplate(VariationalTemplate):
         (polytope_wrap.py:91-93)."""
         if not self.use_polytopes:
             raise ValueError("minimal_spans needs use_polytopes=True")
-        if self._span_exact:
-            return span_rules.minimal_span(target_coords, self._gate_coords)
         kmax = int(self.maximum_span_guess)
         seq = [self._gate_coords_all[i] for i in self.gate_sequence(kmax)]
+        if self._span_exact and self._span_sequence:
+            k = span_rules.sequence_minimal_span(target_coords, seq, kmax)
+            if np.any(k > kmax):
+                raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
+            return k
+        if self._span_exact:
+            return span_rules.minimal_span(target_coords, self._gate_coords)
         lb = span_rules.span_lower_bound(target_coords, seq, kmax)
         if np.any(lb > kmax):
             raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 from abc import ABC
+from collections.abc import Sequence
 from dataclasses import dataclass
 
 import numpy as np
@@ -53,3 +54,63 @@ class DataDictEntry:
     loss_result: float
     Xk: list
     cycles: int
+
+
+class TargetDataList(Sequence):
+    """``target_data`` of a big batch: the list of ``DataDictEntry`` that ``approximate_from_distribution`` returns
+    (optimizer.py:180-186), materialised on access.  Holds the batch's result arrays -- labels, losses, the padded
+    parameter block, cycles -- and builds an entry (whose ``Xk`` is the first ``6 (cycles + 1)`` parameters of the target's
+    row) when it is indexed or iterated over; building 65 536 dataclass objects up front cost more than the span loop on
+    the GPU.  List semantics for readers: ``len``, integer / slice indexing, iteration, ``==`` against any sequence of
+    entries, ``list(...)`` for a real list.  Entries are cached, so ``data[i] is data[i]``."""
+
+    def __init__(self, labels, losses, x_rows, cycles, width_of):
+        self._labels = labels
+        self._losses = losses
+        self._x = x_rows          # ndarray [n, nmax] (padded rows) or a list of per-target vectors
+        self._cycles = cycles
+        self._width_of = width_of  # cycles -> number of parameters of the entry's Xk (None: rows are final already)
+        self._cache = {}
+
+    def __len__(self):
+        return len(self._losses)
+
+    def _entry(self, i: int) -> "DataDictEntry":
+        e = self._cache.get(i)
+        if e is None:
+            c = int(self._cycles[i])
+            row = self._x[i]
+            if self._width_of is not None:
+                row = row[: self._width_of(c)]
+            e = DataDictEntry(int(self._labels[i]), float(self._losses[i]), row, c)
+            self._cache[i] = e
+        return e
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._entry(j) for j in range(*i.indices(len(self)))]
+        n = len(self)
+        j = int(i)
+        if j < 0:
+            j += n
+        if not 0 <= j < n:
+            raise IndexError("target_data index out of range")
+        return self._entry(j)
+
+    def __eq__(self, other):
+        try:
+            if len(other) != len(self):
+                return False
+        except TypeError:
+            return NotImplemented
+        return all(_entries_equal(a, b) for a, b in zip(self, other))
+
+    def __repr__(self):
+        return f"TargetDataList(n={len(self)})"
+
+
+def _entries_equal(a, b) -> bool:
+    if not isinstance(a, DataDictEntry) or not isinstance(b, DataDictEntry):
+        return a == b
+    return (a.success_label == b.success_label and a.loss_result == b.loss_result and a.cycles == b.cycles
+            and np.array_equal(np.asarray(a.Xk), np.asarray(b.Xk)))

@@ -28,14 +28,6 @@
 
 #include "slam_sincos.hpp"
 
-// build-time experiment switches (tools/ab_build.sh)
-#ifndef SLAM_L0OUT
-#define SLAM_L0OUT 1
-#endif
-#ifndef SLAM_K1_LOWREG
-#define SLAM_K1_LOWREG 0
-#endif
-
 namespace slamdev {
 
 constexpr int kQuadsPerWave = 16;
@@ -156,26 +148,10 @@ __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 // quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2), [0,0,0,0] = 0x00 (broadcast lane 0)
-#ifndef SLAM_SWZ
-#define SLAM_SWZ 0
-#endif
-// The same quad permutation executed by the LDS unit (ds_swizzle_b32, quad-perm mode: bit 15 + the four lane selects):
-// no vector-ALU slot -- a fp64 shuffle is two v_mov_b32_dpp, 8 issue cycles of a kernel that is bound by exactly those --
-// at the price of an LDS round trip per stage, which the SIMD's other wavefront covers.
+// (the same permutation through the LDS unit -- ds_swizzle_b32 in quad-perm mode, no vector-ALU slot -- was measured in
+// round 3: -40 vector instructions per round, +3 % time: HISTORY.md)
 template <int CTRL>
-__device__ __forceinline__ double swz_f64(double v) {
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x8000 | CTRL);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x8000 | CTRL);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ double quad_shuffle(double v) {
-#if SLAM_SWZ
-    return swz_f64<CTRL>(v);
-#else
-    return dpp_f64<CTRL>(v);
-#endif
-}
+__device__ __forceinline__ double quad_shuffle(double v) { return dpp_f64<CTRL>(v); }
 __device__ __forceinline__ double quad_sum(double v) {
     v += quad_shuffle<0xB1>(v);
     v += quad_shuffle<0x4E>(v);
@@ -677,21 +653,16 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     constexpr bool PSQ = psq_layout<K, GC>();
     using C = Cfg<K, PSQ>;
     asm volatile("" : "+v"(theta_bits));  // one register, not NA hoisted lane masks
-    // K = 1 at three wavefronts per SIMD (168 registers): the latency-hiding prefetches that cost registers are dropped --
-    // the third wavefront covers what they covered
-    constexpr bool kLowReg = (K == 1) && (SLAM_K1_LOWREG != 0);
     // this quad's trig table (Cfg::TOFF): offsets (0, 4, 2, 6) doubles for quad mod 4 = 0..3
     double* const xt = xq + (PSQ ? (int)((threadIdx.x & 4) + ((threadIdx.x >> 2) & 2)) : 0);
     auto HS = [](int j) constexpr { return LEAN ? j : 2 * j + 1; };  // fh slot of the layer output h_j
-    // the target column is requested first and consumed after the forward pass (kLowReg: requested after it)
+    // the target column is requested first and consumed after the forward pass
     double tre[4], tim[4];
-    if constexpr (!kLowReg) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
-            tre[r] = t.x;
-            tim[r] = t.y;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
+        tre[r] = t.x;
+        tim[r] = t.y;
     }
     // ---- 1. trig table: each lane handles its own parameter slots
     {
@@ -809,14 +780,6 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
     for (int r = 0; r < 4; ++r) { Wr[r] = Fr[r]; Wi[r] = Fi[r]; }
 
     // ---- 3. t = Tr(T^+ W), loss, z = -conj(t) / (4|t|)
-    if constexpr (kLowReg) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
-            tre[r] = t.x;
-            tim[r] = t.y;
-        }
-    }
     double pr = 0.0, pi = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -848,8 +811,8 @@ __device__ __forceinline__ void eval_quad(const double (&xd)[Cfg<K>::NA], const 
         Ur[r] = zr * tre[r] + zi * tim[r];
         Ui[r] = zi * tre[r] - zr * tim[r];
     }
-    constexpr bool kL0Out = SLAM_L0OUT != 0;  // layer 0's partials from its output side (l0_gate_partials)
-    constexpr bool kBwdTrigAhead = (K == 1) && !kLowReg;
+    constexpr bool kL0Out = true;  // layer 0's partials from its output side (l0_gate_partials)
+    constexpr bool kBwdTrigAhead = (K == 1);
     constexpr bool kEarlyP = (K <= 4);
     constexpr bool kKeepTopTrig = (K <= 3);  // layer K's trig entries stay in registers from the forward pass
     static_assert(!PSQ || kKeepTopTrig, "the partial-sum planes start over the top layer's trig entries: nobody may read those in the backward pass");

@@ -97,7 +97,7 @@ struct slam_ctx {
     DevBuf targets, gates;
     // stage work buffers
     DevBuf active, active2, x0;
-    DevBuf item_loss, item_x, item_iters, item_status, item_evals, item_acc;
+    DevBuf item_rec, item_x;  // per work item: one 32-byte result record (slam_kernels.hpp: ItemRec), the parameter row
     DevBuf stage_loss, stage_x, stage_restart;
     // decompose results
     DevBuf best_loss, best_x, best_cycles, span_loss;
@@ -109,7 +109,7 @@ struct slam_ctx {
     DevBuf v2_cons_w[SLAM_V2_MAX_SPAN + 1];
     int v2_cons_n[SLAM_V2_MAX_SPAN + 1] = {0};
     double v2_cons_max[SLAM_V2_MAX_SPAN + 1] = {0};
-    double v2_cons_rho[SLAM_V2_MAX_SPAN + 1] = {0};  // penalty parameter of the multiplier method: 30 / max w^2
+    double v2_cons_rho[SLAM_V2_MAX_SPAN + 1] = {0};  // penalty parameter of the multiplier method: 30 / max_i w_i^2
     DevBuf trace_loss, trace_x;  // slam_minimize_stage_trace
     int32_t trace_cap = 0;       // > 0 only inside slam_minimize_stage_trace
     double stage_exit_loss = -1.0;  // single-stage calls: >= 0 overrides stop_loss as the ordered early-exit level
@@ -128,11 +128,17 @@ struct slam_ctx {
     // eval buffers
     DevBuf ev_x, ev_tof, ev_loss, ev_grad, ev_unitary, ev_weyl;
     slam_stats stats{};
-    bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][kGateClasses][2] = {};
+    bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][kGateClasses][3] = {};  // [.][.][0] eval kernel, [1] optimizer kernel, [2] its multi-queue form
+    int64_t resident_waves_mq[SLAM_MAX_SPAN_EVAL + 1][kGateClasses] = {};
+    // slam_decompose_multi (this context leads the call): the sub-problems' argument blocks / epilogue arguments per span, staged
+    // through pinned memory
+    DevBuf mq_args;
+    void* h_mq_args = nullptr;
+    size_t h_mq_cap = 0;
+    int v2_per_cu[SLAM_V2_MAX_SPAN + 1][3][2][2] = {};  // resident workgroups per CU of minimize_v2_kernel<K, QN, GQ, FREE> (0 = not asked yet)
 
     ~slam_ctx() {
-        DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_loss, &item_x, &item_iters,
-                         &item_status, &item_evals, &item_acc, &stage_loss, &stage_x, &stage_restart, &best_loss,
+        DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_rec, &item_x, &stage_loss, &stage_x, &stage_restart, &best_loss,
                          &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &v2_cons_w[0], &v2_cons_w[1], &v2_cons_w[2], &v2_cons_w[3], &v2_cons_w[4], &v2_cons_w[5], &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
@@ -143,6 +149,8 @@ struct slam_ctx {
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_stage) (void)hipHostFree(h_stage);
         if (h_gates) (void)hipHostFree(h_gates);
+        if (h_mq_args) (void)hipHostFree(h_mq_args);
+        mq_args.release();
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -264,21 +272,11 @@ struct StageLaunch {
     StageCtl* ctl;
 };
 
-template <int K, int GC>
-int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
-    const size_t lds = lds_bytes<K, GC>();
-    if (!c->max_lds_set[K][GC][1]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_kernel<K, GC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_kernel<K, GC>),
-                                                             kWave, lds));
-        if (per_cu < 1) per_cu = 1;
-        c->resident_waves[K][GC] = (int64_t)per_cu * c->compute_units;
-        c->max_lds_set[K][GC][1] = true;
-    }
+// the optimizer kernel's argument block for one stage of one context
+template <int K>
+int build_minimize_args(slam_ctx* c, const StageLaunch& sl, MinimizeArgs<K>& a) {
     const slam_opt_params* prm = sl.prm;
-    MinimizeArgs<K> a{};
+    a = MinimizeArgs<K>{};
     a.targets = sl.d_stage_targets;
     a.orig = sl.d_active;
     a.first_target = sl.first_target;
@@ -297,17 +295,39 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     a.items_per_quad = prm->items_per_quad;
     a.cost_kind = c->cost_kind;
     a.solved = c->solved.as<int32_t>();
-    a.item_loss = c->item_loss.as<double>();
+    a.item_rec = c->item_rec.as<ItemRec>();
     a.item_x = c->item_x.as<double>();
-    a.item_iters = c->item_iters.as<int32_t>();
-    a.item_status = c->item_status.as<int32_t>();
-    a.item_evals = c->item_evals.as<int32_t>();
-    a.item_acc = c->item_acc.as<int32_t>();
     a.trace_cap = c->trace_cap;
     a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
     if (a.trace_loss) a.flags |= kFlagTrace;
     a.trace_x = c->trace_cap > 0 ? c->trace_x.as<double>() : nullptr;
     { int rc = stage_gates(c, K, sl.gate_seq, &a.gates); if (rc) return rc; }
+    return SLAM_OK;
+}
+
+template <int K, int GC, bool MQ = false>
+int prepare_minimize_kernel(slam_ctx* c) {
+    const size_t lds = lds_bytes<K, GC>();
+    if (!c->max_lds_set[K][GC][MQ ? 2 : 1]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_kernel<K, GC, MQ>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_kernel<K, GC, MQ>),
+                                                             kWave, lds));
+        if (per_cu < 1) per_cu = 1;
+        (MQ ? c->resident_waves_mq : c->resident_waves)[K][GC] = (int64_t)per_cu * c->compute_units;
+        c->max_lds_set[K][GC][MQ ? 2 : 1] = true;
+    }
+    return SLAM_OK;
+}
+
+template <int K, int GC>
+int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
+    const size_t lds = lds_bytes<K, GC>();
+    { int rc = prepare_minimize_kernel<K, GC>(c); if (rc) return rc; }
+    const slam_opt_params* prm = sl.prm;
+    MinimizeArgs<K> a;
+    { int rc = build_minimize_args<K>(c, sl, a); if (rc) return rc; }
     // persistent wavefronts: never more blocks than can be resident, every quad pulls items.  The grid is
     // sized for the upper bound of the item count; the kernel derives the real launch shape (waves that
     // take part, chunk size) from the device-side target count and surplus waves exit at once.
@@ -321,7 +341,7 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     const int64_t cap = c->resident_waves[K][GC] - c->reserve_waves > 0 ? c->resident_waves[K][GC] - c->reserve_waves : 1;
     if (blocks > cap) blocks = cap;
     HIP_TRY(hipEventRecord(c->ev_a[K], c->stream));
-    hipLaunchKernelGGL((minimize_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
+    hipLaunchKernelGGL((minimize_kernel<K, GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a, (const MinimizeArgs<K>*)nullptr, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_b[K], c->stream));
     return SLAM_OK;
@@ -352,12 +372,8 @@ int reserve_stage_buffers(slam_ctx* c, int64_t n_upper, int k_max, const slam_op
     const int n = 6 * (k_max + 1);
     const int64_t M = n_upper * (int64_t)prm->restarts;
     if (M > 0x7fff0000LL) return fail(SLAM_ERR_INVALID, "too many work items in one stage (%lld)", (long long)M);
-    HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
+    HIP_TRY(c->item_rec.reserve(M * sizeof(ItemRec)));
     HIP_TRY(c->item_x.reserve(M * n * sizeof(double)));
-    HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
-    HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
-    HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
-    HIP_TRY(c->item_acc.reserve(M * sizeof(int32_t)));
     HIP_TRY(c->stage_loss.reserve(n_upper * sizeof(double)));
     HIP_TRY(c->stage_x.reserve(n_upper * n * sizeof(double)));
     HIP_TRY(c->stage_restart.reserve(n_upper * sizeof(int32_t)));
@@ -379,6 +395,43 @@ struct SpanLoopStep {
     double threshold;
     int32_t* active_out;
 };
+
+ReduceArgs build_reduce_args(slam_ctx* c, int k, const int32_t* d_active, const slam_opt_params* prm, double exit_loss, bool merge) {
+    ReduceArgs r{};
+    r.item_rec = c->item_rec.as<ItemRec>();
+    r.item_x = c->item_x.as<double>();
+    r.exit_loss = exit_loss;
+    r.ordered = ((prm->flags & SLAM_FLAG_EARLY_EXIT) && (prm->flags & SLAM_FLAG_ORDERED)) ? 1 : 0;
+    r.ctl = stage_ctl(c, k);
+    r.restarts = prm->restarts;
+    r.n = 6 * (k + 1);
+    r.stage_loss = c->stage_loss.as<double>();
+    r.stage_x = c->stage_x.as<double>();
+    r.stage_restart = c->stage_restart.as<int32_t>();
+    if (merge) {
+        r.active = d_active;
+        r.nmax = c->result_nmax;
+        r.k = k;
+        r.best_loss = c->best_loss.as<double>();
+        r.best_x = c->best_x.as<double>();
+        r.best_cycles = c->best_cycles.as<int32_t>();
+        r.span_loss = c->span_loss.as<double>();
+    }
+    return r;
+}
+
+EpilogueArgs build_epilogue_args(slam_ctx* c, int k, const ReduceArgs& r, const SpanLoopStep& loop) {
+    EpilogueArgs e{};
+    e.r = r;
+    e.has_next = loop.has_next ? 1 : 0;
+    e.threshold = loop.threshold;
+    e.active_out = loop.active_out;
+    e.next = stage_ctl(c, k + 1);
+    e.targets = c->targets.as<double>();
+    e.stage_targets = c->stage_targets.as<double>();
+    e.solved = c->solved.as<int32_t>();
+    return e;
+}
 
 int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_active, int64_t n_upper,
                   const double* d_x0, const slam_opt_params* prm, const SpanLoopStep* loop) {
@@ -419,41 +472,11 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
     }
     if (rc != SLAM_OK) return rc;
 
-    ReduceArgs r{};
-    r.item_loss = c->item_loss.as<double>();
-    r.item_x = c->item_x.as<double>();
-    r.item_evals = c->item_evals.as<int32_t>();
-    r.item_acc = c->item_acc.as<int32_t>();
-    r.item_status = c->item_status.as<int32_t>();
-    r.exit_loss = exit_loss;
-    r.ordered = ((prm->flags & SLAM_FLAG_EARLY_EXIT) && (prm->flags & SLAM_FLAG_ORDERED)) ? 1 : 0;
-    r.ctl = ctl;
-    r.restarts = prm->restarts;
-    r.n = n;
-    r.stage_loss = c->stage_loss.as<double>();
-    r.stage_x = c->stage_x.as<double>();
-    r.stage_restart = c->stage_restart.as<int32_t>();
-    if (merge) {
-        r.active = d_active;
-        r.nmax = c->result_nmax;
-        r.k = k;
-        r.best_loss = c->best_loss.as<double>();
-        r.best_x = c->best_x.as<double>();
-        r.best_cycles = c->best_cycles.as<int32_t>();
-        r.span_loss = c->span_loss.as<double>();
-    }
+    const ReduceArgs r = build_reduce_args(c, k, d_active, prm, exit_loss, merge);
     if (loop) {
         // reduction, bookkeeping, compaction and the next stage's inputs in ONE launch: a single workgroup for small
         // batches (ordered compaction without atomics), a grid of 256-thread workgroups beyond
-        EpilogueArgs e{};
-        e.r = r;
-        e.has_next = loop->has_next ? 1 : 0;
-        e.threshold = loop->threshold;
-        e.active_out = loop->active_out;
-        e.next = stage_ctl(c, k + 1);
-        e.targets = c->targets.as<double>();
-        e.stage_targets = c->stage_targets.as<double>();
-        e.solved = c->solved.as<int32_t>();
+        const EpilogueArgs e = build_epilogue_args(c, k, r, *loop);
         if (n_upper <= 2048) hipLaunchKernelGGL(stage_epilogue_kernel<256>, dim3(1), dim3(256), 0, c->stream, e);
         else if (n_upper <= kEpilogueMaxTargets) hipLaunchKernelGGL(stage_epilogue_kernel<1024>, dim3(1), dim3(1024), 0, c->stream, e);
         else hipLaunchKernelGGL(stage_epilogue_grid_kernel, dim3((unsigned)((n_upper + 255) / 256)), dim3(256), 0, c->stream, e);
@@ -653,13 +676,214 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     return drained(c, decompose_body(c, first, count, k_min, k_max, gate_seqs, prm, success_threshold, h_list, k_layout, fetch));
 }
 
+
+// -----------------------------------------------------------------------------------------------------------------------
+// slam_decompose_multi: the span loops of SEVERAL contexts -- same device, same target window, each with its own gate table
+// (e.g. the bases of a parametric-Hamiltonian sweep, BASELINE configs[4]) -- enqueued as ONE chain of kernels on the first
+// context's stream: per span ONE multi-queue optimizer launch (minimize_kernel<K, GC, true>: a wavefront works on one
+// sub-problem at a time, so gates stay scalar operands) and ONE epilogue launch for all of them.  Every context ends with the
+// results its own slam_decompose_range call would have left (ordered early exit: bit for bit).
+// -----------------------------------------------------------------------------------------------------------------------
+int join_gate_class(int a, int b) {
+    if (a == b) return a;
+    auto xri_like = [](int g) { return g == GC_XRI1 || g == GC_XRI; };
+    if (xri_like(a) && xri_like(b)) return GC_XRI;
+    auto x_like = [&](int g) { return xri_like(g) || g == GC_XGEN; };
+    if (x_like(a) && x_like(b)) return GC_XGEN;
+    return GC_DENSE;
+}
+
+template <int K, int GC>
+int launch_minimize_multi(slam_ctx* lead, const MinimizeArgs<K>& common, const MinimizeArgs<K>* d_subs, int n, int64_t items_max_total) {
+    const size_t lds = lds_bytes<K, GC>();
+    { int rc = prepare_minimize_kernel<K, GC, true>(lead); if (rc) return rc; }
+    int64_t blocks = (items_max_total + kQuadsPerWave - 1) / kQuadsPerWave;
+    const int64_t cap = lead->resident_waves_mq[K][GC] > 0 ? lead->resident_waves_mq[K][GC] : 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks < n) blocks = n;  // every sub-problem has a wavefront that starts on it
+    HIP_TRY(hipEventRecord(lead->ev_a[K], lead->stream));
+    hipLaunchKernelGGL((minimize_kernel<K, GC, true>), dim3((unsigned)blocks), dim3(kWave), lds, lead->stream, common, d_subs, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(lead->ev_b[K], lead->stream));
+    return SLAM_OK;
+}
+
+int decompose_multi_body(slam_ctx** cs, int n, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                         const slam_opt_params* prm, double success_threshold) {
+    if (!cs || n <= 0) return fail(SLAM_ERR_INVALID, "no contexts");
+    slam_ctx* lead = cs[0];
+    for (int i = 0; i < n; ++i) {
+        if (!cs[i]) return fail(SLAM_ERR_INVALID, "ctxs[%d] is NULL", i);
+        if (cs[i]->device != lead->device) return fail(SLAM_ERR_INVALID, "ctxs[%d] lives on device %d, ctxs[0] on %d", i, cs[i]->device, lead->device);
+        for (int j = 0; j < i; ++j)
+            if (cs[j] == cs[i]) return fail(SLAM_ERR_INVALID, "ctxs[%d] and ctxs[%d] are the same context", j, i);
+        if (cs[i]->n_targets <= 0) return fail(SLAM_ERR_STATE, "ctxs[%d]: no targets", i);
+        if (cs[i]->n_gates <= 0) return fail(SLAM_ERR_STATE, "ctxs[%d]: no gates", i);
+        if (first < 0 || count <= 0 || first + count > cs[i]->n_targets)
+            return fail(SLAM_ERR_INVALID, "ctxs[%d]: target window [%lld, %lld) outside [0, %lld)", i, (long long)first, (long long)(first + count), (long long)cs[i]->n_targets);
+        if (cs[i]->cost_kind != lead->cost_kind) return fail(SLAM_ERR_INVALID, "ctxs[%d]: another cost function than ctxs[0]", i);
+    }
+    HIP_TRY(hipSetDevice(lead->device));
+    if (k_min < 1 || k_max < k_min) return fail(SLAM_ERR_INVALID, "bad span range [%d, %d]", k_min, k_max);
+    if (k_max > 3) return fail(SLAM_ERR_UNSUPPORTED, "slam_decompose_multi runs spans 1..3 (got k_max = %d)", k_max);
+    int rc = check_params(prm);
+    if (rc) return rc;
+    if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED))
+        return fail(SLAM_ERR_INVALID, "slam_decompose_multi needs SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED (results independent of scheduling)");
+    const int64_t N = count;
+    for (int i = 0; i < n; ++i) {
+        slam_ctx* c = cs[i];
+        const int32_t* gs = gate_seqs;
+        for (int k = k_min; k <= k_max; ++k) {
+            rc = check_gate_seq(c, k, gs);
+            if (rc) return rc;
+            gs += k;
+        }
+        if (c->result_nmax != 0 && c->result_nmax != 6 * (k_max + 1) && !(first == 0 && count == c->n_targets))
+            return fail(SLAM_ERR_STATE, "ctxs[%d]: resident results were produced with a different k_max", i);
+        // (allocation and the first fill run on the context's own, idle stream; the lead's stream waits for them below)
+        rc = ensure_results(c, k_max);
+        if (rc) return rc;
+        HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
+        HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));
+        rc = reserve_stage_buffers(c, N, k_max, prm);
+        if (rc) return rc;
+        if (c != lead) HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    // staging: per span n optimizer argument blocks + n epilogue argument blocks
+    const size_t sz_ma = sizeof(MinimizeArgs<1>), sz_ep = sizeof(EpilogueArgs);
+    static_assert(sizeof(MinimizeArgs<1>) == sizeof(MinimizeArgs<3>), "argument blocks of all spans have one layout");
+    const size_t slot = (size_t)n * (sz_ma + sz_ep);
+    const size_t need = slot * (size_t)(k_max + 1);
+    HIP_TRY(lead->mq_args.reserve(need));
+    if (need > lead->h_mq_cap) {
+        if (lead->h_mq_args) (void)hipHostFree(lead->h_mq_args);
+        lead->h_mq_args = nullptr;
+        lead->h_mq_cap = 0;
+        HIP_TRY(hipHostMalloc(&lead->h_mq_args, need, hipHostMallocDefault));
+        lead->h_mq_cap = need;
+    }
+    HIP_TRY(hipEventRecord(lead->ev_t0, lead->stream));
+    for (int i = 0; i < n; ++i) {
+        slam_ctx* c = cs[i];
+        const bool whole = (first == 0 && count == c->n_targets);
+        hipLaunchKernelGGL(init_results_kernel, dim3((unsigned)(((whole ? N : N * 16) + 255) / 256)), dim3(256), 0, lead->stream,
+                           c->best_loss.as<double>(), c->best_cycles.as<int32_t>(), c->span_loss.as<double>(),
+                           whole ? (int32_t*)nullptr : c->active.as<int32_t>(), first, N, stage_ctl(c, k_min), c->targets.as<double>(),
+                           c->stage_targets.as<double>(), c->solved.as<int32_t>(), c->counters.as<StageCtl>(),
+                           (int32_t)(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2) / 8), 0);
+        HIP_TRY(hipGetLastError());
+    }
+    std::vector<const int32_t*> d_active((size_t)n);
+    std::vector<DevBuf*> cur((size_t)n), nxt((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const bool whole = (first == 0 && count == cs[i]->n_targets);
+        d_active[(size_t)i] = whole ? nullptr : cs[i]->active.as<int32_t>();
+        cur[(size_t)i] = &cs[i]->active;
+        nxt[(size_t)i] = &cs[i]->active2;
+    }
+    const int32_t* gs = gate_seqs;
+    for (int k = k_min; k <= k_max; ++k) {
+        char* h = static_cast<char*>(lead->h_mq_args) + slot * (size_t)k;
+        char* d = static_cast<char*>(lead->mq_args.p) + slot * (size_t)k;
+        int gc = -1;
+        MinimizeArgs<1>* h_ma = reinterpret_cast<MinimizeArgs<1>*>(h);  // (one layout for every span)
+        EpilogueArgs* h_ep = reinterpret_cast<EpilogueArgs*>(h + (size_t)n * sz_ma);
+        for (int i = 0; i < n; ++i) {
+            slam_ctx* c = cs[i];
+            const int g = classify_gates(c, k, gs);
+            gc = gc < 0 ? g : join_gate_class(gc, g);
+            const double* d_stage_targets = d_active[(size_t)i] ? c->stage_targets.as<double>() : c->targets.as<double>();
+            StageLaunch sl{success_threshold, gs, d_stage_targets, d_active[(size_t)i], 0, nullptr, N * (int64_t)prm->restarts, prm, stage_ctl(c, k)};
+            switch (k) {
+                case 1: rc = build_minimize_args<1>(c, sl, *reinterpret_cast<MinimizeArgs<1>*>(&h_ma[i])); break;
+                case 2: rc = build_minimize_args<2>(c, sl, *reinterpret_cast<MinimizeArgs<2>*>(&h_ma[i])); break;
+                default: rc = build_minimize_args<3>(c, sl, *reinterpret_cast<MinimizeArgs<3>*>(&h_ma[i])); break;
+            }
+            if (rc) return rc;
+            if (c != lead) HIP_TRY(hipStreamSynchronize(c->stream));  // (its gate slot may just have been staged on its own stream)
+            SpanLoopStep step{success_threshold, true, k < k_max, success_threshold, nxt[(size_t)i]->as<int32_t>()};
+            const ReduceArgs r = build_reduce_args(c, k, d_active[(size_t)i], prm, success_threshold, true);
+            h_ep[i] = build_epilogue_args(c, k, r, step);
+        }
+        HIP_TRY(hipMemcpyAsync(d, h, slot, hipMemcpyHostToDevice, lead->stream));
+        const int64_t items_total = (int64_t)n * N * prm->restarts;
+#define SLAM_MQ_CASE(KK)                                                                                                                         \
+    case KK: {                                                                                                                                   \
+        const MinimizeArgs<KK>& a0 = *reinterpret_cast<const MinimizeArgs<KK>*>(&h_ma[0]);                                                       \
+        const MinimizeArgs<KK>* dsub = reinterpret_cast<const MinimizeArgs<KK>*>(d);                                                             \
+        if (gc == GC_CX) rc = launch_minimize_multi<KK, GC_CX>(lead, a0, dsub, n, items_total);                                                  \
+        else if (gc == GC_XRI1) rc = launch_minimize_multi<KK, GC_XRI1>(lead, a0, dsub, n, items_total);                                         \
+        else if (gc == GC_XRI) rc = launch_minimize_multi<KK, GC_XRI>(lead, a0, dsub, n, items_total);                                           \
+        else if (gc == GC_XGEN) rc = launch_minimize_multi<KK, GC_XGEN>(lead, a0, dsub, n, items_total);                                         \
+        else rc = launch_minimize_multi<KK, GC_DENSE>(lead, a0, dsub, n, items_total);                                                           \
+    } break;
+        switch (k) {
+            SLAM_MQ_CASE(1)
+            SLAM_MQ_CASE(2)
+            SLAM_MQ_CASE(3)
+            default: return fail(SLAM_ERR_UNSUPPORTED, "slam_decompose_multi runs spans 1..3");
+        }
+#undef SLAM_MQ_CASE
+        if (rc) return rc;
+        hipLaunchKernelGGL(stage_epilogue_multi_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), 0, lead->stream,
+                           reinterpret_cast<const EpilogueArgs*>(d + (size_t)n * sz_ma));
+        HIP_TRY(hipGetLastError());
+        gs += k;
+        if (k < k_max)
+            for (int i = 0; i < n; ++i) {
+                d_active[(size_t)i] = nxt[(size_t)i]->as<int32_t>();
+                DevBuf* t = cur[(size_t)i]; cur[(size_t)i] = nxt[(size_t)i]; nxt[(size_t)i] = t;
+            }
+    }
+    HIP_TRY(hipEventRecord(lead->ev_t1, lead->stream));
+    for (int i = 0; i < n; ++i)
+        HIP_TRY(hipMemcpyAsync(cs[i]->h_ctl, cs[i]->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, lead->stream));
+    HIP_TRY(hipEventRecord(lead->ev_done, lead->stream));
+    HIP_TRY(hipEventSynchronize(lead->ev_done));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, lead->ev_t0, lead->ev_t1));
+    lead->stats.total_ms = ms;
+    // statistics: every context gets the evaluations / items of its own queues; the kernels' time goes to the leading context
+    for (int i = 0; i < n; ++i) {
+        slam_ctx* c = cs[i];
+        for (int k = k_min; k <= k_max; ++k) {
+            if (c->h_ctl[k].n_active <= 0) continue;
+            c->stats.evals[k] += (int64_t)c->h_ctl[k].evals;
+            c->stats.evals_accepted[k] += (int64_t)c->h_ctl[k].evals_accepted;
+            c->stats.evals_preempted[k] += (int64_t)c->h_ctl[k].evals_preempted;
+            c->stats.wave_rounds[k] += (int64_t)c->h_ctl[k].rounds;
+            c->stats.items[k] += (int64_t)c->h_ctl[k].n_active * prm->restarts;
+        }
+    }
+    for (int k = k_min; k <= k_max; ++k) {
+        float kms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&kms, lead->ev_a[k], lead->ev_b[k]));
+        lead->stats.kernel_ms += kms;
+        lead->stats.kernel_ms_span[k] += kms;
+        lead->stats.kernel_launches += 1;
+    }
+    return SLAM_OK;
+}
+
+int decompose_multi_impl(slam_ctx** cs, int n, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                         const slam_opt_params* prm, double success_threshold) {
+    const int rc = decompose_multi_body(cs, n, first, count, k_min, k_max, gate_seqs, prm, success_threshold);
+    if (rc != SLAM_OK && cs)
+        for (int i = 0; i < n; ++i)
+            if (cs[i]) (void)drained(cs[i], rc);  // (the work sits on ctxs[0]'s stream; every context forgets its cached gate slots)
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* slam_last_error(void) { return g_err.c_str(); }
 
-const char* slam_version(void) { return "slamhip 0.1.0 (gfx950)"; }
+const char* slam_version(void) { return "slamhip 0.4.0 (gfx950)"; }
+
+int slam_abi_version(void) { return SLAM_ABI_VERSION; }
 
 int slam_device_count(int* count) {
     if (!count) return fail(SLAM_ERR_INVALID, "count is NULL");
@@ -863,6 +1087,22 @@ int slam_eval_unitary(slam_ctx* ctx, int k, const int32_t* gate_seq, const doubl
     return eval_impl(ctx, k, gate_seq, x, target_of, M, loss, nullptr, unitary);
 }
 
+// Per-item results of a single-stage call for the host: the records come over as they are and are unpacked into the
+// caller's arrays (any of which may be NULL).  The stream is idle (the caller has waited for the stage).
+static int fetch_item_records(slam_ctx* c, int64_t M, double* item_loss, int32_t* item_iters, int32_t* item_status, int32_t* item_evals) {
+    if (!(item_loss || item_iters || item_status || item_evals) || M <= 0) return SLAM_OK;
+    std::vector<ItemRec> rec((size_t)M);
+    HIP_TRY(hipMemcpyAsync(rec.data(), c->item_rec.p, (size_t)M * sizeof(ItemRec), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < M; ++i) {
+        if (item_loss) item_loss[i] = rec[(size_t)i].loss;
+        if (item_iters) item_iters[i] = rec[(size_t)i].iters;
+        if (item_status) item_status[i] = rec[(size_t)i].status;
+        if (item_evals) item_evals[i] = rec[(size_t)i].evals;
+    }
+    return SLAM_OK;
+}
+
 static int minimize_stage_body(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
                         const double* x0, const slam_opt_params* params, double* best_loss, double* best_x,
                         int32_t* best_restart, double* item_loss, int32_t* item_iters, int32_t* item_status,
@@ -917,11 +1157,9 @@ static int minimize_stage_body(slam_ctx* ctx, int k, const int32_t* gate_seq, co
     HIP_TRY(hipMemcpyAsync(best_loss, ctx->stage_loss.p, (size_t)n_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(best_x, ctx->stage_x.p, (size_t)n_active * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (best_restart) HIP_TRY(hipMemcpyAsync(best_restart, ctx->stage_restart.p, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (item_loss) HIP_TRY(hipMemcpyAsync(item_loss, ctx->item_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (item_iters) HIP_TRY(hipMemcpyAsync(item_iters, ctx->item_iters.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (item_status) HIP_TRY(hipMemcpyAsync(item_status, ctx->item_status.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (item_evals) HIP_TRY(hipMemcpyAsync(item_evals, ctx->item_evals.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    rc = fetch_item_records(ctx, M, item_loss, item_iters, item_status, item_evals);
+    if (rc) return rc;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
     ctx->stats.total_ms = ms;
@@ -974,6 +1212,11 @@ int slam_decompose_range_fetch(slam_ctx* ctx, int64_t first, int64_t count, int 
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     FetchReq fr{best_loss, best_x, best_cycles};
     return decompose_impl(ctx, first, count, k_min, k_max, gate_seqs, params, success_threshold, nullptr, 0, &fr);
+}
+
+int slam_decompose_multi(slam_ctx** ctxs, int32_t n_ctx, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
+                         const slam_opt_params* params, double success_threshold) {
+    return decompose_multi_impl(ctxs, n_ctx, first, count, k_min, k_max, gate_seqs, params, success_threshold);
 }
 
 int slam_fetch_results(slam_ctx* ctx, int k_max, double* best_loss, double* best_x, int32_t* best_cycles) {
@@ -1196,10 +1439,15 @@ struct V2Stage {
 template <int K, int QN, int GQ, bool FREE>
 int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
     const size_t lds = v2_lds_bytes<K, QN>();
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN, GQ, FREE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN, GQ, FREE>), kWave, lds));
-    if (per_cu < 1) per_cu = 1;
+    // attribute + occupancy once per context and instantiation (both were runtime calls inside every stage launch of the
+    // span loop's chain)
+    int& per_cu = c->v2_per_cu[K][QN == 1 ? 0 : (QN == 2 ? 1 : 2)][GQ][FREE ? 1 : 0];
+    if (per_cu == 0) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN, GQ, FREE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int v = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(&minimize_v2_kernel<K, QN, GQ, FREE>), kWave, lds));
+        per_cu = v < 1 ? 1 : v;
+    }
     constexpr int n = CfgV2<K, QN>::N;
     MinimizeV2Args<K, QN> a{};
     a.targets = c->targets.as<double>();
@@ -1223,12 +1471,8 @@ int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
     a.cost_kind = c->cost_kind;
     a.maps = sgt.d_maps;
     a.solved = c->solved.as<int32_t>();
-    a.item_loss = c->item_loss.as<double>();
+    a.item_rec = c->item_rec.as<ItemRec>();
     a.item_x = c->item_x.as<double>();
-    a.item_iters = c->item_iters.as<int32_t>();
-    a.item_status = c->item_status.as<int32_t>();
-    a.item_evals = c->item_evals.as<int32_t>();
-    a.item_acc = c->item_acc.as<int32_t>();
     a.ctl = stage_ctl(c, K);
     a.trace_cap = c->trace_cap;
     a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
@@ -1377,12 +1621,8 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     HIP_TRY(hipStreamSynchronize(c->stream));  // b is a local buffer
     {
         // stage buffers sized for n parameters per item (reserve_stage_buffers sizes for 6 (k + 1))
-        HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
+        HIP_TRY(c->item_rec.reserve(M * sizeof(ItemRec)));
         HIP_TRY(c->item_x.reserve(M * n * sizeof(double)));
-        HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
-        HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
-        HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
-        HIP_TRY(c->item_acc.reserve(M * sizeof(int32_t)));
         HIP_TRY(c->stage_loss.reserve(n_active * sizeof(double)));
         HIP_TRY(c->stage_x.reserve(n_active * n * sizeof(double)));
         HIP_TRY(c->stage_restart.reserve(n_active * sizeof(int32_t)));
@@ -1403,11 +1643,8 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     SLAM_V2_DISPATCH(v2_launch_minimize, c, sgt);
     if (rc) return rc;
     ReduceArgs r{};
-    r.item_loss = c->item_loss.as<double>();
+    r.item_rec = c->item_rec.as<ItemRec>();
     r.item_x = c->item_x.as<double>();
-    r.item_evals = c->item_evals.as<int32_t>();
-    r.item_acc = c->item_acc.as<int32_t>();
-    r.item_status = c->item_status.as<int32_t>();
     r.exit_loss = exit_loss;
     r.ordered = 1;  // the winner is the restart the reference's sequential loop breaks at (restarts below it always run to their end)
     r.ctl = stage_ctl(c, k);
@@ -1421,12 +1658,10 @@ int v2_minimize_body(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t*
     HIP_TRY(hipMemcpyAsync(best_loss, c->stage_loss.p, (size_t)n_active * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(best_x, c->stage_x.p, (size_t)n_active * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (best_restart) HIP_TRY(hipMemcpyAsync(best_restart, c->stage_restart.p, (size_t)n_active * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (item_loss) HIP_TRY(hipMemcpyAsync(item_loss, c->item_loss.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (item_iters) HIP_TRY(hipMemcpyAsync(item_iters, c->item_iters.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (item_status) HIP_TRY(hipMemcpyAsync(item_status, c->item_status.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (item_evals) HIP_TRY(hipMemcpyAsync(item_evals, c->item_evals.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_ctl, c->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = fetch_item_records(c, M, item_loss, item_iters, item_status, item_evals);
+    if (rc) return rc;
     return collect_stats(c, k, k, c->h_ctl, prm->restarts);
 }
 
@@ -1499,12 +1734,24 @@ int v2_decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int 
     if (rc) return rc;
     HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
     HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));
-    HIP_TRY(c->item_loss.reserve(M * sizeof(double)));
+    HIP_TRY(c->item_rec.reserve(M * sizeof(ItemRec)));
     HIP_TRY(c->item_x.reserve(M * nmax * sizeof(double)));
-    HIP_TRY(c->item_iters.reserve(M * sizeof(int32_t)));
-    HIP_TRY(c->item_status.reserve(M * sizeof(int32_t)));
-    HIP_TRY(c->item_evals.reserve(M * sizeof(int32_t)));
-    HIP_TRY(c->item_acc.reserve(M * sizeof(int32_t)));
+    {
+        // inverse Hessians of the long templates (v2_h_in_memory: more than 8 parameter slots per lane) live in device memory, one slice
+        // per resident wavefront: sized HERE for the longest span of the loop -- growing the buffer between two stages of the chain
+        // would free it under the stage in flight (hipFree synchronises the device: ADVICE r3)
+        size_t need = 0;
+        for (int k = k_min; k <= k_max; ++k) {
+            const int na = (6 * (k + 1) + c->v2_qn * k + 3) / 4;
+            if (na <= 8) continue;
+            int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
+            const int64_t cap = (int64_t)8 * c->compute_units;  // never more wavefronts than a CU can hold
+            if (blocks > cap) blocks = cap;
+            const size_t bytes = (size_t)blocks * (size_t)(na * (na + 1) / 2 * 4 * kWave) * sizeof(float);
+            need = bytes > need ? bytes : need;
+        }
+        if (need) HIP_TRY(c->v2_hmem.reserve(need));
+    }
     HIP_TRY(c->stage_loss.reserve(N * sizeof(double)));
     HIP_TRY(c->stage_x.reserve(N * nmax * sizeof(double)));
     HIP_TRY(c->stage_restart.reserve(N * sizeof(int32_t)));
@@ -1525,11 +1772,8 @@ int v2_decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int 
         SLAM_V2_DISPATCH(v2_launch_minimize, c, sgt);
         if (rc) return rc;
         EpilogueArgs e{};
-        e.r.item_loss = c->item_loss.as<double>();
+        e.r.item_rec = c->item_rec.as<ItemRec>();
         e.r.item_x = c->item_x.as<double>();
-        e.r.item_evals = c->item_evals.as<int32_t>();
-        e.r.item_acc = c->item_acc.as<int32_t>();
-        e.r.item_status = c->item_status.as<int32_t>();
         e.r.exit_loss = success_threshold;
         e.r.ordered = 1;
         e.r.ctl = stage_ctl(c, k);

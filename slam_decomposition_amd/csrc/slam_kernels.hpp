@@ -6,10 +6,7 @@ namespace slamdev {
 
 constexpr double kArmijoC1 = 1e-4;
 constexpr int kMaxBacktrack = 20;
-#ifndef SLAM_STEP_MAX
-#define SLAM_STEP_MAX 2.0
-#endif
-constexpr double kStepMax = SLAM_STEP_MAX;  // cap on |alpha p|_2 of the first trial step (parameters are angles)
+constexpr double kStepMax = 2.0;  // cap on |alpha p|_2 of the first trial step (parameters are angles)
 constexpr double kCurvEps = 1e-10;
 constexpr double kStallDf = 1e-15;
 constexpr double kStallGnorm = 1e-5;
@@ -25,13 +22,38 @@ constexpr double kGrowMax = 1048576.0;  // happening).  Covers negative curvatur
 // evaluations where SciPy's BFGS needs 50..170 from the same start, and ONE such item sets the duration of its whole stage
 // (CNOT k = 2, 1 M items: pct 99.99 of the evaluation counts 197, maximum 1309).  Restarted, it is through in ~40 more.  128 is
 // past the 99th percentile of the iteration counts at every span: the mean does not notice.  (oracle/bfgs_port.py: RESTART_PERIOD)
-#ifndef SLAM_REMAT_Q_COND
-#define SLAM_REMAT_Q_COND (K == 2)
-#endif
-#ifndef SLAM_RESTART_PERIOD
-#define SLAM_RESTART_PERIOD 128
-#endif
-constexpr int kRestartPeriod = SLAM_RESTART_PERIOD;
+constexpr int kRestartPeriod = 128;
+static_assert((kRestartPeriod & (kRestartPeriod - 1)) == 0, "the periodic restart tests iters & (period - 1)");
+
+// One finished (or dropped) work item: the five scalars of its result as ONE 32-byte record = one sector, written by one lane as two
+// 16-byte stores (round 3 wrote them into five arrays: five partial-sector stores per item, WRITE_SIZE 2.2x the payload)
+struct __attribute__((aligned(32))) ItemRec {
+    double loss;
+    int32_t iters;
+    int32_t status;
+    int32_t evals;   // all loss+gradient evaluations of the item
+    int32_t acc;     // those whose point was accepted
+    int32_t pad[2];
+};
+static_assert(sizeof(ItemRec) == 32, "ItemRec layout");
+__device__ __forceinline__ unsigned long long pack2(int lo, int hi) { return (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32); }
+__device__ __forceinline__ void item_rec_store(ItemRec* r, double loss, int iters, int status, int evals, int acc) {
+    // (field by field, all into the one sector: paired into 8- or 16-byte stores the operands need aligned register pairs / quads, and
+    // the k = 2 kernel -- at its 256-register limit -- spilled two registers for them)
+    r->loss = loss;
+    asm volatile("" ::: "memory");  // (keeps the store vectoriser from pairing them again)
+    r->iters = iters;
+    asm volatile("" ::: "memory");
+    r->status = status;
+    asm volatile("" ::: "memory");
+    r->evals = evals;
+    asm volatile("" ::: "memory");
+    r->acc = acc;
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<int2*>(&r->pad[0]) = make_int2(0, 0);
+}
+// positions dropped at a refill: a sibling restart has already succeeded
+__device__ __forceinline__ void item_rec_store_dropped(ItemRec* r, int status) { item_rec_store(r, (double)INFINITY, 0, status, 0, 0); }
 
 enum : int { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_NONFINITE = 3, ST_STALLED = 4, ST_PREEMPTED = 5 };
 
@@ -75,12 +97,8 @@ struct MinimizeArgs {
     // else restarts - r for the lowest-index successful restart r so far (atomic max)
     int32_t* solved;
     // per-item outputs
-    double* item_loss;        // [M]
+    ItemRec* item_rec;        // [M]
     double* item_x;           // [M][n]
-    int32_t* item_iters;      // [M]
-    int32_t* item_status;     // [M]
-    int32_t* item_evals;      // [M]
-    int32_t* item_acc;        // [M] evaluations whose point was accepted
     const double* gates;      // [K][32]: G_1..G_K of this span
     // optional per-iteration trace (use_callback, optimizer.py:217-224): after accepted quasi-Newton step number
     // it >= 1 of item m, trace_loss[m][it - 1] = loss and trace_x[m][it - 1][:] = parameters; nullptr = off
@@ -160,6 +178,21 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MinimizeArgs<
     asm volatile("" : "+s"(a));
     return (const __attribute__((address_space(4))) MinimizeArgs<K>*)a;
 }
+// Multi-queue launches (MQ: several independent sub-problems -- their own targets, gates, work queue, outputs -- behind ONE
+// launch, slam_decompose_multi): the argument block of the sub-problem the wavefront is working on lives in device memory
+// (MinimizeArgs<K>[n_sub]); `cur` is its address, wave-uniform.
+template <int K, bool MQ>
+__device__ __forceinline__ const __attribute__((address_space(4))) MinimizeArgs<K>* cold_args(unsigned long long cur) {
+    if constexpr (MQ) {
+        // (wave-uniform by construction; the compiler cannot see it through the loop: two v_readfirstlane per use)
+        unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32));
+        unsigned long long u = ((unsigned long long)hi << 32) | lo;
+        asm volatile("" : "+s"(u));
+        return (const __attribute__((address_space(4))) MinimizeArgs<K>*)u;
+    } else {
+        return cold_args<K>();
+    }
+}
 
 // ---------------------------------------------------------------------------------
 // batched quasi-Newton minimisation.  Persistent wavefronts: each of the 16 quads of a wave
@@ -167,11 +200,8 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MinimizeArgs<
 // it finishes, so lanes stay busy although items need very different iteration counts.
 // All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
-#ifndef SLAM_K1_WAVES
-#define SLAM_K1_WAVES 2
-#endif
-template <int K, int GC>
-__global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 : 1))) minimize_kernel(MinimizeArgs<K> args) {
+template <int K, int GC, bool MQ = false>
+__global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args, const MinimizeArgs<K>* subs, int n_sub) {
     using C = Cfg<K, psq_layout<K, GC>()>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -193,15 +223,25 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
     }
     lds_fence();
     // ---- launch shape from the device-side target count (the grid is sized for the host's upper bound)
-    const unsigned n_act = (unsigned)args.ctl->n_active;
-    const unsigned n_items = n_act * (unsigned)args.restarts;
+    // MQ: the wavefront starts on sub-problem blockIdx.x mod n_sub and moves on to the next one (cyclically) when that one's queue
+    // is exhausted AND its own quads have drained -- gates, targets and outputs are wave-uniform, so a wavefront never holds items of
+    // two sub-problems at once; it leaves after n_sub exhausted queues in a row
+    unsigned sub_idx = MQ ? (unsigned)blockIdx.x % (unsigned)n_sub : 0u;
+    unsigned long long cur = MQ ? (unsigned long long)(subs + sub_idx) : 0ull;  // wave-uniform
+    int sub_tries = 0;
+    unsigned n_act = (unsigned)(MQ ? cold_args<K, MQ>(cur)->ctl->n_active : args.ctl->n_active);
+    unsigned n_items = n_act * (unsigned)args.restarts;
     unsigned n_waves = (n_items + kQuadsPerWave - 1) / kQuadsPerWave;
-    if (args.items_per_quad > 1) {
-        n_waves = (n_items + kQuadsPerWave * args.items_per_quad - 1) / (kQuadsPerWave * args.items_per_quad);
-        if (n_waves < 1 && n_items) n_waves = 1;
+    if constexpr (!MQ) {
+        if (args.items_per_quad > 1) {
+            n_waves = (n_items + kQuadsPerWave * args.items_per_quad - 1) / (kQuadsPerWave * args.items_per_quad);
+            if (n_waves < 1 && n_items) n_waves = 1;
+        }
+        if (n_waves > gridDim.x) n_waves = gridDim.x;
+        if (blockIdx.x >= n_waves) return;
+    } else {
+        n_waves = gridDim.x / (unsigned)n_sub + 1u;  // the sub-problems share the grid (chunk size: from the first one a wavefront sees)
     }
-    if (n_waves > gridDim.x) n_waves = gridDim.x;
-    if (blockIdx.x >= n_waves) return;
     // The work queue is RESTART-MAJOR: position idx holds restart idx / n_active of stage slot idx % n_active, so every
     // target's restart 0 is handed out before any restart 1, and so on -- the order of the reference's sequential
     // loop (optimizer.py:253).  By the time a target's restart r + 1 comes up, its restart r has usually finished:
@@ -226,7 +266,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
     // metric is H + hs1 I, so the one-off scaling of the initial inverse Hessian (Nocedal & Wright eq. 6.20) is a scalar
     // update instead of a multiplication of every stored block
     double pp = 0.0, hs1 = 0.0;
-    const double* tcol = args.targets + q * 2;  // this lane's column of the quad's target
+    const double* tcol = cold_args<K, MQ>(cur)->targets + q * 2;  // this lane's column of the quad's target
     double x[NA], g[NA], p[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) { x[a] = 0.0; g[a] = 0.0; p[a] = 0.0; }
@@ -237,13 +277,29 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
     unsigned cur_next = 0, cur_end = 0;  // wave-uniform
     unsigned pre_base = 0;               // lane 0: base of the prefetched chunk
     unsigned rounds = 0;                 // wave-uniform
-    if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
+    if (lane == 0) pre_base = atomicAdd(&cold_args<K, MQ>(cur)->ctl->work_counter, kChunk);
 
     while (true) {
+        if constexpr (MQ) {
+            // this sub-problem's queue is exhausted and the wavefront's quads have drained: on to the next one
+            if (exhausted && !__any(live)) {
+                if (lane == 0 && rounds) atomicAdd(&cold_args<K, MQ>(cur)->ctl->rounds, (unsigned long long)rounds);
+                rounds = 0;
+                if (++sub_tries >= n_sub) break;
+                sub_idx = (sub_idx + 1u == (unsigned)n_sub) ? 0u : sub_idx + 1u;
+                cur = (unsigned long long)(subs + sub_idx);
+                n_act = (unsigned)cold_args<K, MQ>(cur)->ctl->n_active;
+                n_items = n_act * (unsigned)args.restarts;
+                exhausted = false;
+                cur_next = 0;
+                cur_end = 0;
+                if (lane == 0) pre_base = atomicAdd(&cold_args<K, MQ>(cur)->ctl->work_counter, kChunk);
+            }
+        }
         // q is re-materialised every iteration: otherwise the lane-dependent LDS addresses derived from it
         // (gradient gather, stash slots) are hoisted out of the loop, kept live across it, spilled to scratch
         // and reloaded -- one exposed memory latency each -- in every round
-        if constexpr (SLAM_REMAT_Q_COND) {
+        if constexpr (K == 2) {
             asm volatile("" : "+v"(q));  // (measured: pays at k = 2 only)
             __builtin_assume((unsigned)q < 4u);  // keeps the slot-validity tests 4 a + q < N compile-time for a < NA - 1
         }
@@ -266,7 +322,8 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
                     cur_next = b;
                     cur_end = (b + kChunk < n_items) ? b + kChunk : n_items;
                     if (b >= n_items) { exhausted = true; break; }
-                    if (lane == 0) pre_base = atomicAdd(&cold_args<K>()->ctl->work_counter, kChunk);
+                    if constexpr (MQ) sub_tries = 0;  // this queue still had work
+                    if (lane == 0) pre_base = atomicAdd(&cold_args<K, MQ>(cur)->ctl->work_counter, kChunk);
                 }
                 // ---- scan up to 64 queue positions at once: lane l looks at position cur_next + l.  Positions whose
                 // target already has a successful restart are dropped here (one flag load for the whole window, their
@@ -282,7 +339,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
                     // (SLAM_FLAG_ORDERED): only restarts with a HIGHER index than a successful one are dropped, so the
                     // winner is the lowest-index successful restart whatever the scheduling -- the restart the
                     // reference's sequential loop stops at (optimizer.py:287-295).
-                    const int fl = __hip_atomic_load(&args.solved[psl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int fl = __hip_atomic_load(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[psl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int mine = args.restarts - (int)prs;
                     skipv = (args.flags & 2u) ? (fl > mine) : (fl != 0);
                 }
@@ -301,11 +358,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
                     // a sibling restart already succeeded: nothing to do for this item
                     // (outputs and explicit seeds keep the [slot][restart] layout whatever the processing order)
                     const unsigned o = psl * (unsigned)args.restarts + prs;
-                    cold_args<K>()->item_loss[o] = INFINITY;
-                    cold_args<K>()->item_iters[o] = 0;
-                    cold_args<K>()->item_status[o] = ST_PREEMPTED;
-                    cold_args<K>()->item_evals[o] = 0;
-                    cold_args<K>()->item_acc[o] = 0;
+                    item_rec_store_dropped(cold_args<K, MQ>(cur)->item_rec + o, ST_PREEMPTED);
                 }
                 int* wp = reinterpret_cast<int*>(xchg);  // wave-private, dead between rounds: [16] slots, [16] restarts
                 if (handed) {
@@ -326,15 +379,15 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
                     // over the 64 lanes instead -- n_take N / 2 blocks, one pass for up to 10 / 7 / 5 quads at k = 1 / 2 / 3 --
                     // and handed to their owners through LDS: the same numbers, a third to a sixth of the instructions.
                     constexpr bool kSharedSeeds = psq_layout<K, GC>();
-                    const bool shared = kSharedSeeds && cold_args<K>()->x0 == nullptr;  // wave-uniform
+                    const bool shared = kSharedSeeds && cold_args<K, MQ>(cur)->x0 == nullptr;  // wave-uniform
                     if (get) {
                         const unsigned oidx = sl * (unsigned)args.restarts + rs;
                         item = oidx;
                         slot = (int)sl;
                         const unsigned restart = rs;
                         // three independent loads (no load feeds another's address)
-                        tgt = cold_args<K>()->orig ? cold_args<K>()->orig[sl] : cold_args<K>()->first_target + (int)sl;
-                        tcol = cold_args<K>()->targets + (int64_t)sl * 32 + q * 2;
+                        tgt = cold_args<K, MQ>(cur)->orig ? cold_args<K, MQ>(cur)->orig[sl] : cold_args<K, MQ>(cur)->first_target + (int)sl;
+                        tcol = cold_args<K, MQ>(cur)->targets + (int64_t)sl * 32 + q * 2;
                         if (!shared) {
 #pragma unroll
                             for (int a = 0; a < NA; ++a) {
@@ -342,10 +395,10 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
                                 double xv = 0.0;
                                 if (i < C::N) {
                                     if constexpr (kSharedSeeds)  // (not shared: explicit start points)
-                                        xv = cold_args<K>()->x0[(int64_t)oidx * C::N + i];
+                                        xv = cold_args<K, MQ>(cur)->x0[(int64_t)oidx * C::N + i];
                                     else
-                                        xv = cold_args<K>()->x0 ? cold_args<K>()->x0[(int64_t)oidx * C::N + i]
-                                                     : x0_philox(cold_args<K>()->seed, (uint32_t)(tgt + (int)cold_args<K>()->target_base), restart, (uint32_t)K, (uint32_t)i);
+                                        xv = cold_args<K, MQ>(cur)->x0 ? cold_args<K, MQ>(cur)->x0[(int64_t)oidx * C::N + i]
+                                                     : x0_philox(cold_args<K, MQ>(cur)->seed, (uint32_t)(tgt + (int)cold_args<K, MQ>(cur)->target_base), restart, (uint32_t)K, (uint32_t)i);
                                 }
                                 x[a] = xv;
                             }
@@ -365,11 +418,11 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
                             static_assert(5 * C::N <= C::XSTRIDE && 4 * C::N * 8 >= 64 * 4, "staging area [4N, 5N) inside the quad's exchange area and clear of wp");
                             // wp[32 + r]: Philox target word of the r-th taking quad, wp[48 + r]: its quad index
                             if (get && q == 0) {
-                                wp[32 + qrank] = tgt + (int)cold_args<K>()->target_base;
+                                wp[32 + qrank] = tgt + (int)cold_args<K, MQ>(cur)->target_base;
                                 wp[48 + qrank] = quad;
                             }
                             lds_fence();
-                            const uint64_t seed = cold_args<K>()->seed;
+                            const uint64_t seed = cold_args<K, MQ>(cur)->seed;
                             const int jobs = n_take * kPairs;
                             for (int j0 = 0; j0 < jobs; j0 += kWave) {
                                 const int jb = j0 + lane;
@@ -396,7 +449,10 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
             }
             if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
         }
-        if (!__any(live)) break;
+        if (!__any(live)) {
+            if constexpr (MQ) continue;  // (nothing is live, hence nothing loop-carried to copy: the next sub-problem, or out)
+            else break;
+        }
         ++rounds;
 
         // early-exit flag of this quad's target (consumed at the end of the round)
@@ -404,7 +460,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
         // the round does not start with a wait for global memory)
         int sflag = 0;
         if (args.flags & 1u)
-            sflag = __hip_atomic_load(&args.solved[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sflag = __hip_atomic_load(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         // ---- 2. one fused loss + gradient evaluation at the trial point x + alpha p (x itself when
         //         fresh: alpha = 0, p = 0)
@@ -414,7 +470,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K, false, GC>(xt, tcol, args.gates, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
+            eval_quad<K, false, GC>(xt, tcol, MQ ? cold_args<K, MQ>(cur)->gates : args.gates, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
         }
         const bool active = live;
         const bool finite = isfinite(ft);
@@ -512,7 +568,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
                 p[a] = -(qv[a] + sa * wg + va * sg);
             }
             if (args.flags & kFlagTrace) {  // wave-uniform flag test: nothing when off
-                const auto* ca = cold_args<K>();
+                const auto* ca = cold_args<K, MQ>(cur);
                 const int t_cap = ca->trace_cap;
                 double* const t_loss = ca->trace_loss;
                 double* const t_x = ca->trace_x;
@@ -559,7 +615,7 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
         }
         fresh = false;
         // not a descent direction (H lost positive definiteness numerically), or the periodic restart: steepest descent again
-        const bool periodic = step && !done && ((kRestartPeriod & (kRestartPeriod - 1)) == 0 ? ((iters & (kRestartPeriod - 1)) == 0) : (iters % kRestartPeriod == 0));
+        const bool periodic = step && !done && ((iters & (kRestartPeriod - 1)) == 0);
         const bool reset = active && !done && (!(gp < 0.0) || periodic);
         if (__any(reset)) {
             h_set_identity_where<NA>(H, q, reset);
@@ -579,27 +635,23 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
             const bool beaten = (args.flags & 2u) ? (sflag > mine) : (sflag != 0);
             if (active && !done && beaten) { status = ST_PREEMPTED; done = true; }
             if (active && done && status != ST_PREEMPTED && f < args.exit_loss && q == 0)
-                __hip_atomic_fetch_max(&args.solved[slot], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[slot], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- 6. finished items leave; their quads pull new work next round
         if (active && done) {
-            if (q == 0) {
-                cold_args<K>()->item_loss[item] = f;
-                cold_args<K>()->item_iters[item] = iters;
-                cold_args<K>()->item_status[item] = status;
-                cold_args<K>()->item_evals[item] = nev & 0xFFFFF;
-                cold_args<K>()->item_acc[item] = (int)((unsigned)nev >> 20);
-            }
+            if (q == 0) item_rec_store(cold_args<K, MQ>(cur)->item_rec + item, f, iters, status, nev & 0xFFFFF, (int)((unsigned)nev >> 20));
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const int i = 4 * a + q;
-                if (i < C::N) cold_args<K>()->item_x[(int64_t)item * C::N + i] = x[a];
+                if (i < C::N) cold_args<K, MQ>(cur)->item_x[(int64_t)item * C::N + i] = x[a];
             }
             live = false;
             alpha = 0.0;  // an idle quad keeps evaluating x + 0 p (its direction is reset when it takes the next item)
         }
     }
-    if (lane == 0 && rounds) atomicAdd(&cold_args<K>()->ctl->rounds, (unsigned long long)rounds);
+    if constexpr (!MQ) {
+        if (lane == 0 && rounds) atomicAdd(&cold_args<K>()->ctl->rounds, (unsigned long long)rounds);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -608,11 +660,8 @@ __global__ void __launch_bounds__(kWave, (K == 1 ? SLAM_K1_WAVES : (K <= 2 ? 2 :
 // best_result" the stage result replaces the target's best (loss, parameters, cycles).
 // ---------------------------------------------------------------------------------
 struct ReduceArgs {
-    const double* item_loss;   // [n_active * R]
+    const ItemRec* item_rec;   // [n_active * R]
     const double* item_x;      // [n_active * R][n]
-    const int32_t* item_evals; // [n_active * R]
-    const int32_t* item_acc;   // [n_active * R]
-    const int32_t* item_status;// [n_active * R]
     double exit_loss;          // ordered == 1: the winner is the lowest-index restart below exit_loss (else the argmin)
     int32_t ordered;
     StageCtl* ctl;             // n_active; evals += sum of item_evals
@@ -645,10 +694,13 @@ __device__ __forceinline__ void reduce_merge_slot(const ReduceArgs& a, int64_t s
         // targets one after the other: the single-workgroup epilogue of a small batch is a chain of memory latencies)
 #pragma unroll 4
         for (int r = 0; r < a.restarts; ++r) {
-            const double l = a.item_loss[s * a.restarts + r];
-            const unsigned long long e = (unsigned long long)a.item_evals[s * a.restarts + r];
-            const bool pre = a.item_status[s * a.restarts + r] == ST_PREEMPTED;
-            const unsigned long long ac = (unsigned long long)a.item_acc[s * a.restarts + r];
+            // one 32-byte record per restart: two 16-byte loads
+            const ulonglong2* rw = reinterpret_cast<const ulonglong2*>(a.item_rec + (s * a.restarts + r));
+            const ulonglong2 w0 = rw[0], w1 = rw[1];
+            const double l = __longlong_as_double((long long)w0.x);
+            const bool pre = (int)(w0.y >> 32) == ST_PREEMPTED;
+            const unsigned long long e = w1.x & 0xffffffffull;
+            const unsigned long long ac = w1.x >> 32;
             ev.all += e;
             ev.preempted += pre ? e : 0ull;
             ev.accepted += pre ? 0ull : ac;
@@ -849,7 +901,7 @@ __global__ void __launch_bounds__(NT) stage_epilogue_kernel(EpilogueArgs a) {
 // order only decides which wavefront works on what, never a result), then the next stage's inputs for the kept targets.
 // Round 2 ran three kernels here (reduce_merge, a single-workgroup compact_active, stage_prepare): with several batches in
 // flight each of them waited its turn behind other batches' persistent wavefronts.
-__global__ void __launch_bounds__(256) stage_epilogue_grid_kernel(EpilogueArgs a) {
+__device__ __forceinline__ void stage_epilogue_grid_body(const EpilogueArgs& a) {
     __shared__ int32_t wave_counts[4];
     __shared__ int32_t s_base;
     __shared__ int32_t kept_t[256];  // the workgroup's kept targets, in order
@@ -887,6 +939,12 @@ __global__ void __launch_bounds__(256) stage_epilogue_grid_kernel(EpilogueArgs a
     const double2* src = reinterpret_cast<const double2*>(a.targets);
     double2* dst = reinterpret_cast<double2*>(a.stage_targets) + (int64_t)base * 16;
     for (int e = tid; e < tot * 16; e += 256) dst[e] = src[(int64_t)kept_t[e >> 4] * 16 + (e & 15)];
+}
+__global__ void __launch_bounds__(256) stage_epilogue_grid_kernel(EpilogueArgs a) { stage_epilogue_grid_body(a); }
+// slam_decompose_multi: the same for n_sub sub-problems in one launch (blockIdx.y = sub-problem, its arguments in device memory)
+__global__ void __launch_bounds__(256) stage_epilogue_multi_kernel(const EpilogueArgs* arr) {
+    const EpilogueArgs a = arr[blockIdx.y];
+    stage_epilogue_grid_body(a);
 }
 
 }  // namespace slamdev

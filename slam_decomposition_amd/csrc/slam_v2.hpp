@@ -635,12 +635,8 @@ struct MinimizeV2Args {
     int32_t cost_kind;
     const V2GateMap* maps;
     int32_t* solved;           // [n_active], zeroed before launch: restarts - r of the lowest-index successful restart r, 0 = none
-    double* item_loss;         // [M] outputs, [slot][restart]
+    ItemRec* item_rec;         // [M] outputs, [slot][restart]
     double* item_x;            // [M][n]
-    int32_t* item_iters;
-    int32_t* item_status;
-    int32_t* item_evals;
-    int32_t* item_acc;
     StageCtl* ctl;             // work queue head, round counter
     float* hmem;               // v2_h_in_memory<K, QN>(): [gridDim.x][v2_h_floats_per_wave] inverse Hessians; else unused
     // optional per-iteration trace (use_callback, optimizer.py:217-224), as MinimizeArgs: after accepted step number it >= 1 of
@@ -769,11 +765,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
             const unsigned consumed = (n_take == n_av) ? wlen : (unsigned)(64 - __builtin_clzll(handed_mask));
             if (valid && skipv && (unsigned)lane < consumed) {
                 const unsigned o = psl * (unsigned)args.restarts + prs;
-                args.item_loss[o] = INFINITY;
-                args.item_iters[o] = 0;
-                args.item_status[o] = ST_PREEMPTED;
-                args.item_evals[o] = 0;
-                args.item_acc[o] = 0;
+                item_rec_store_dropped(args.item_rec + o, ST_PREEMPTED);
             }
             int* wp = reinterpret_cast<int*>(lds);  // quad 0's exchange area, dead between rounds: [16] slots, [16] restarts
             if (handed) {
@@ -847,7 +839,8 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         // c(x) = w.x - cmax: smooth, same box -- one more quad reduction per evaluation.  When the loop below has converged on L
         // the item's multiplier estimate moves, mu <- max(0, mu + rho c), and the loop goes on from the same point with the same
         // metric until c <= tol and mu c = 0 within tol (first-order multiplier method; the violation shrinks by ~ rho / curvature
-        // per update: 5..7 updates to 1e-8 with rho w.w = 30).  cmax is handed in lowered by that tolerance: results are feasible.
+        // per update: 5..7 updates to 1e-8 with rho = 30 / max_i w_i^2 -- i.e. rho w.w = 30 for ONE weighted parameter, k times that for k
+        // gates of equal weight: the penalty is stiffer, never softer, than that figure).  cmax is handed in lowered by that tolerance: results are feasible.
         if (cons) {
             double ct = 0.0;
 #pragma unroll
@@ -1065,13 +1058,7 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
         if (active && done) {
             if (early && f < args.exit_loss && q == 0)
                 __hip_atomic_fetch_max(&args.solved[slot], args.restarts - restart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (q == 0) {
-                args.item_loss[item] = f;
-                args.item_iters[item] = iters;
-                args.item_status[item] = status;
-                args.item_evals[item] = nev & 0xFFFFF;
-                args.item_acc[item] = (int)((unsigned)nev >> 20);
-            }
+            if (q == 0) item_rec_store(args.item_rec + item, f, iters, status, nev & 0xFFFFF, (int)((unsigned)nev >> 20));
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const int i = 4 * a + q;

@@ -27,7 +27,7 @@ import numpy as np
 from . import _ffi, runtime
 from .basis import CircuitTemplate
 from .basisv2 import CircuitTemplateV2
-from .basis_abc import DataDictEntry, VariationalTemplate
+from .basis_abc import DataDictEntry, TargetDataList, VariationalTemplate
 from .cost_function import BasicCost, SquareCost, UnitaryCostFunction
 from .sampler import SampleFunction
 
@@ -106,6 +106,23 @@ class TemplateOptimizer:
 
     # ------------------------------------------------------------------------------------------
     _device_sampler = None
+    _want_span_losses = True
+    last_stats_per_device = None
+
+    def _set_stats(self, per_device) -> None:
+        """``last_stats`` is ONE dict whatever the number of devices (sums over the shards; ``total_ms`` = the slowest
+        shard's); the shards' own dicts are in ``last_stats_per_device``."""
+        self.last_stats_per_device = list(per_device)
+        tot = {}
+        for st in per_device:
+            for key, v in st.items():
+                if isinstance(v, list):
+                    tot[key] = [a + b for a, b in zip(tot[key], v)] if key in tot else list(v)
+                elif key == "total_ms":
+                    tot[key] = max(tot.get(key, 0.0), v)
+                else:
+                    tot[key] = tot.get(key, 0) + v
+        self.last_stats = tot
 
     def _opt_params(self) -> "_ffi.OptParams":
         seed = self.seed
@@ -162,13 +179,16 @@ class TemplateOptimizer:
                                     flags=prm.flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
                                     target_base=first)
                 out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
-                return out + (ctx.fetch_span_losses(0, count),), ctx.stats()
+                # the running best loss per span feeds the "Cycle (k =...)" log lines only (optimizer.py:297)
+                sl = ctx.fetch_span_losses(0, count) if self._want_span_losses else None
+                return out + (sl,), ctx.stats()
             finally:
                 if len(self.devices) > 1:
                     ctx.close()
 
         if len(self.devices) == 1 or n < len(self.devices):
-            (best_loss, best_x, best_cycles, self._span_losses), self.last_stats = run_shard(self.devices[0], 0, n)
+            (best_loss, best_x, best_cycles, self._span_losses), st = run_shard(self.devices[0], 0, n)
+            self._set_stats([st])
         else:
             import threading
 
@@ -194,18 +214,11 @@ class TemplateOptimizer:
             best_loss = np.concatenate([p[0][0] for p in parts])
             best_x = np.concatenate([p[0][1] for p in parts])
             best_cycles = np.concatenate([p[0][2] for p in parts])
-            self._span_losses = np.concatenate([p[0][3] for p in parts])
-            self.last_stats = [p[1] for p in parts]
-        # per target the first 6 (cycles + 1) parameters: one contiguous block per template size, rows handed out as views
-        # (65 536 per-row slices + copies cost more than the span loop on the GPU)
-        xs = [None] * n
-        cyc = np.asarray(best_cycles)
-        for c in np.unique(cyc):
-            idx = np.nonzero(cyc == c)[0]
-            block = np.ascontiguousarray(best_x[idx, : 6 * (int(c) + 1)])
-            for i, row in zip(idx.tolist(), block):
-                xs[i] = row
-        return best_loss, xs, best_cycles
+            self._span_losses = np.concatenate([p[0][3] for p in parts]) if self._want_span_losses else None
+            self._set_stats([p[1] for p in parts])
+        # per target the first 6 (cycles + 1) parameters of its row: the padded block goes back as it is (rows are cut when an
+        # entry is looked at: 65 536 per-row slices cost more than the span loop on the GPU)
+        return best_loss, best_x, best_cycles
 
     def _run_batch_any_order(self, targets: np.ndarray, ks):
         """A spanning range that is not a run k0, k0 + 1, ... (e.g. ``basis.spanning_range = [1, 3]``): the sizes are
@@ -238,7 +251,7 @@ class TemplateOptimizer:
             better[todo] = (best_cycles[todo] < 0) | (loss[todo] < best_loss[todo])  # optimizer.py:281-284
             best_loss[better], best_x[better], best_cycles[better] = loss[better], x[better], k
             self._span_losses[todo, k - 1] = best_loss[todo]
-        self.last_stats = ctx.stats()
+        self._set_stats([ctx.stats()])
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
         return best_loss, xs, best_cycles
 
@@ -247,9 +260,11 @@ class TemplateOptimizer:
         resident once; each size is one ``slam_decompose_list`` call over the list of its targets."""
         if np.any(spans <= 0):
             raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
-        k_top = int(spans.max())
+        exact = getattr(self.basis, "span_rules_exact", True)
+        # exact rules: every target runs at its own size only; lower bounds: the span loop runs from the bound to the template's maximum
+        k_top = int(spans.max()) if exact else max(int(spans.max()), int(self.basis.maximum_span_guess))
         if k_top > _ffi.MAX_SPAN_MINIMIZE:
-            raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path")
+            raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path (got {k_top})")
         prm = self._opt_params()
         ctx = runtime.get_context(self.devices[0])
         if self._device_sampler is not None:
@@ -259,9 +274,6 @@ class TemplateOptimizer:
         ctx.set_gates(self.basis.gate_matrices)
         ctx.set_cost(self._cost_kind)
         ctx.reset_stats()
-        exact = getattr(self.basis, "span_rules_exact", True)
-        if not exact:
-            k_top = int(self.basis.maximum_span_guess)  # lower bounds: the span loop runs from the bound to the template's maximum
         for k in np.unique(spans):
             k = int(k)
             k_hi = k if exact else k_top
@@ -269,7 +281,7 @@ class TemplateOptimizer:
                                self.success_threshold, k_layout=k_top)
         best_loss, best_x, best_cycles = ctx.fetch_results_range(k_top, 0, len(targets))
         self._span_losses = ctx.fetch_span_losses(0, len(targets))
-        self.last_stats = ctx.stats()
+        self._set_stats([ctx.stats()])
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(len(targets))]
         return best_loss, xs, best_cycles
 
@@ -351,7 +363,8 @@ class TemplateOptimizer:
                     ctx.close()
 
         if len(self.devices) == 1 or n < len(self.devices):
-            (best, best_x, best_k, self._span_losses), self.last_stats = run_shard(self.devices[0], 0, n)
+            (best, best_x, best_k, self._span_losses), st = run_shard(self.devices[0], 0, n)
+            self._set_stats([st])
         else:
             import threading
 
@@ -378,7 +391,7 @@ class TemplateOptimizer:
             best_x = [x for p in parts for x in p[0][1]]
             best_k = np.concatenate([p[0][2] for p in parts])
             self._span_losses = np.concatenate([p[0][3] for p in parts])
-            self.last_stats = [p[1] for p in parts]
+            self._set_stats([p[1] for p in parts])
         if np.any(best_k < 0):
             raise ValueError("empty spanning range")
         return best, best_x, best_k
@@ -416,8 +429,9 @@ class TemplateOptimizer:
         for k in all_ks:
             if k <= 0:
                 raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
-            if k > (_ffi.V2_MAX_SPAN if self._v2 else _ffi.MAX_SPAN_MINIMIZE):
-                raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path")
+            k_lim = _ffi.V2_MAX_SPAN if self._v2 else _ffi.MAX_SPAN_MINIMIZE
+            if k > k_lim:
+                raise NotImplementedError(f"template spans up to {k_lim} are implemented on the HIP path (got {k})")
             act = np.array([t for t in range(n) if k in spans_per_target[t] and not (best[t] is not None and best[t] < self.success_threshold)],
                            dtype=np.int32)
             if len(act) == 0:
@@ -472,7 +486,7 @@ class TemplateOptimizer:
                     assert best[t] == float(out["best_loss"][j])
                     best_x[t] = out["best_x"][j][v2_idx].copy() if self._v2 else out["best_x"][j].copy()
                 self._span_losses[t, k - 1] = best[t]
-        self.last_stats = ctx.stats()
+        self._set_stats([ctx.stats()])
         if any(b is None for b in best):
             raise ValueError("empty spanning range")
         return np.array(best), best_x, np.array(best_k, dtype=np.int32)
@@ -551,7 +565,9 @@ class TemplateOptimizer:
         self._device_sampler = sampler if hasattr(sampler, "fill") else None  # sampler.DeviceHaarBatch
         try:
             if self._device_sampler is not None:
-                stacked = np.asarray(sampler.as_array(), dtype=np.complex128)  # one array, no per-target Python objects
+                # the targets stay where they were generated; they come over (one array) only if something on the host
+                # looks at them: log lines, polytope mode, callbacks, several devices' shards, V2 templates
+                stacked = _ResidentTargets(sampler)
             else:
                 targets = [np.asarray(t, dtype=np.complex128) for t in sampler]
                 for t in targets:
@@ -563,14 +579,18 @@ class TemplateOptimizer:
             self._device_sampler = None
         return self.training_loss, self.coordinate_list, target_data
 
-    def _approximate_batch(self, stacked: np.ndarray, log_index: bool) -> List[DataDictEntry]:
+    def _approximate_batch(self, stacked, log_index: bool):
         n = len(stacked)
         # The reference logs per target (optimizer.py:77-106,183,234,297-305).  Formatting ~10 lines for each of 1e5
         # targets costs 50x the GPU time of the batch, so the log lines -- and the coordinates that only they show -- are
         # produced only when INFO logging is enabled.
         log_on = logging.getLogger().isEnabledFor(logging.INFO)
+        self._want_span_losses = log_on
         ctx0 = runtime.get_context(self.devices[0])
         need_coords = log_on or (self.basis.use_polytopes and not self._v2)
+        fast = (not need_coords and not self.use_callback and not self._v2 and not self.basis.use_polytopes)
+        if not fast and isinstance(stacked, _ResidentTargets):
+            stacked = stacked.as_array()
         # target_invariant (basis_abc.py:80-84) for the whole batch, on the device
         coords_arr = ctx0.c1c2c3(stacked) if need_coords else None
         self.basis.assign_seed(None)  # optimizer.py:150-152
@@ -596,12 +616,14 @@ class TemplateOptimizer:
                 spans_of = [list(range(int(k), int(self.basis.maximum_span_guess) + 1)) for k in spans]
             best_loss, best_xs, best_cycles = self._run_batch_by_span(stacked, spans)
         else:
-            spanning_range = self.basis.get_spanning_range(stacked[0])
-            spans_of = [list(spanning_range)] * n
+            spanning_range = self.basis.spanning_range  # (get_spanning_range without polytopes: the brute-force range, basis.py:95-100)
+            if not fast:
+                spans_of = [list(spanning_range)] * n
             best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)
         best_loss = np.asarray(best_loss, dtype=np.float64)
         best_cycles = np.asarray(best_cycles)
         self.basis.build(n_repetitions=int(best_cycles[-1]))  # the reference leaves the template at the last size
+        padded = isinstance(best_xs, np.ndarray) and best_xs.ndim == 2  # [n, 6 (k_max + 1)] rows, cut at 6 (cycles + 1) on access
         if not log_on and not self.use_callback:
             # same bookkeeping as the per-target path below, without the log lines: every target up to (and including)
             # the first one that fails without override_fail is recorded, then the reference's ValueError (optimizer.py:89-93)
@@ -609,10 +631,13 @@ class TemplateOptimizer:
             fail = (not self.override_fail) and (not bool(ok.all()))
             stop = int(np.argmin(ok)) + 1 if fail else n
             self.training_loss.extend(best_loss[:stop].tolist())  # optimizer.py:307-309 (no callback)
-            self.best_cycle_list.extend(int(c) for c in best_cycles[:stop])
+            self.best_cycle_list.extend(best_cycles[:stop].tolist())
             if fail:
                 raise ValueError(_FAIL_MSG)
-            return [DataDictEntry(a, b, c, d) for a, b, c, d in zip(ok.astype(int).tolist(), best_loss.tolist(), best_xs, best_cycles.tolist())]
+            # list of DataDictEntry (optimizer.py:113), entries built when they are looked at
+            return TargetDataList(ok, best_loss, best_xs, best_cycles, (lambda c: 6 * (c + 1)) if padded else None)
+        if padded:
+            best_xs = [best_xs[i, : 6 * (int(best_cycles[i]) + 1)] for i in range(n)]
         found = self._found_coordinates(best_xs, best_cycles) if log_on else np.zeros((n, 3))
         coords = coords_arr if coords_arr is not None else np.zeros((n, 3))
         out = []
@@ -625,3 +650,20 @@ class TemplateOptimizer:
             fc = tuple(float(v) for v in found[i])
             out.append(self._finish_target(tc, float(best_loss[i]), best_xs[i], int(best_cycles[i]), fc, index=i))
         return out
+
+
+class _ResidentTargets:
+    """The targets of a device sampler (sampler.DeviceHaarBatch) as the optimizer sees them: a length, and the array only
+    when somebody asks for it (``as_array`` copies the batch back once and caches it in the sampler)."""
+
+    def __init__(self, sampler):
+        self._sampler = sampler
+
+    def __len__(self):
+        return int(self._sampler.n_samples)
+
+    def as_array(self) -> np.ndarray:
+        return np.asarray(self._sampler.as_array(), dtype=np.complex128)
+
+    def __getitem__(self, i):
+        return self.as_array()[i]

@@ -68,68 +68,116 @@ def rendezvous_path(env=os.environ) -> str:
 
     ``SLAM_COMM_FILE`` if set (bench.py's own launcher sets it); otherwise derived from what all ranks
     of one ``torch.distributed.run`` job share and no other job does: the launcher's pid (the workers'
-    parent), MASTER_PORT and the run id."""
+    parent), MASTER_PORT, the run id and the elastic restart count (a restarted worker group is a new attempt)."""
     path = env.get("SLAM_COMM_FILE")
     if path:
         return path
-    key = f"{os.getppid()}_{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'none')}"
+    key = (f"{os.getppid()}_{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'none')}"
+           f"_{env.get('TORCHELASTIC_RESTART_COUNT', '0')}")
     key = "".join(ch if ch.isalnum() or ch in "_-" else "_" for ch in key)
     return os.path.join(tempfile.gettempdir(), f"slam_comm_{os.getuid()}_{key}.id")
 
 
-_ID_MAGIC = b"SLAMID01"
-_JOB_START = time.time()  # wall clock at import: no id file of THIS job can be older
+_ID_MAGIC = b"SLAMID02"
 
 
 def _generation_path(path: str, generation: int) -> str:
     return path if generation == 0 else f"{path}.g{generation}"
 
 
-def exchange_unique_id(rank: int, world: int, path: str, make_id: Callable[[], bytes], timeout: float = 300.0,
-                       nbytes: int = 128, generation: int = 0, not_before: Optional[float] = None) -> bytes:
-    """Rank 0 writes ``make_id()`` to the generation's file atomically (temp file + rename); the others wait for it.
+def _write_atomic(path: str, blob: bytes) -> None:
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        f.write(blob)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
 
-    Generation-safe: every communicator a process builds on one ``path`` has its own sequence number (``generation``,
-    counted per path by :class:`RcclComm` -- all ranks of a job build their communicators in the same order), which is in
-    the file's name and in its header (magic, generation, world size, rank 0's write time).  Rank 0 removes a
-    pre-existing file of that name before it creates the id; readers reject a file with the wrong header or one written
-    before ``not_before`` (default: 10 min before this process imported the module -- a leftover of a crashed job with a
-    repeated ``SLAM_COMM_FILE`` / torchrun key is older than any rank of this job)."""
+
+def _read_words(path: str, n: int) -> Optional[tuple]:
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    return struct.unpack(f"<{n}Q", blob) if len(blob) == 8 * n else None
+
+
+def exchange_unique_id(rank: int, world: int, path: str, make_id: Callable[[], bytes], timeout: float = 300.0,
+                       nbytes: int = 128, generation: int = 0) -> bytes:
+    """Rank 0 hands ``make_id()`` to the other ranks through files, with a handshake that does not depend on any clock.
+
+    Every communicator a process builds on one ``path`` has its own sequence number (``generation``, counted per path by
+    :class:`RcclComm` -- all ranks of a job build their communicators in the same order), which is in the files' names and
+    in the id file's header.  Protocol (files next to ``path``; every write is temp file + rename):
+
+      1. every rank draws a random 64-bit NONCE; a rank r > 0 publishes its in ``<path>.ready.<r>``;
+      2. rank 0 waits until it has a nonce of every other rank, creates the id and writes the id file: magic, generation,
+         world size, its own nonce, the world - 1 nonces it saw, the id;
+      3. rank r accepts an id file only if it carries ITS nonce, and then answers with ``<path>.ack.<r>``: its nonce and rank 0's;
+      4. rank 0 waits for every rank's ack (both nonces must match).  While it waits it keeps re-reading the ready files: if one
+         shows another nonce than the id file carries (it had picked up the leftover of a crashed attempt before the live rank
+         overwrote it), it rewrites the id file with the nonces it sees now (same id).  With all acks in, it removes the files.
+
+    A leftover of an earlier attempt with the same key -- id, ready or ack files of a job that died at start-up, a torchrun
+    elastic restart within seconds -- can therefore never be joined or mistaken for an answer: it does not carry the nonces the
+    live ranks drew for this attempt (the previous version trusted a 10-minute window of wall-clock freshness)."""
     if world == 1:
         return make_id()
     gpath = _generation_path(path, generation)
-    if not_before is None:
-        not_before = _JOB_START - 600.0
-    if rank == 0:
+    hdr = len(_ID_MAGIC) + 24 + 8 * (world - 1)
+    t0 = time.monotonic()
+
+    def expired(what: str):
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}: {what} (generation {generation}, {gpath}) after {timeout:.0f} s")
+
+    nonce = int.from_bytes(os.urandom(8), "little") | 1
+    if rank != 0:
+        _write_atomic(f"{gpath}.ready.{rank}", struct.pack("<Q", nonce))
+        while True:
+            try:
+                with open(gpath, "rb") as f:
+                    blob = f.read()
+            except OSError:
+                blob = b""
+            if len(blob) == hdr + nbytes and blob[: len(_ID_MAGIC)] == _ID_MAGIC:
+                gen, w, n0 = struct.unpack("<qqQ", blob[len(_ID_MAGIC) : len(_ID_MAGIC) + 24])
+                mine = struct.unpack("<Q", blob[len(_ID_MAGIC) + 24 + 8 * (rank - 1) : len(_ID_MAGIC) + 32 + 8 * (rank - 1)])[0]
+                if gen == generation and w == world and mine == nonce:
+                    _write_atomic(f"{gpath}.ack.{rank}", struct.pack("<QQ", nonce, n0))
+                    return blob[hdr:]
+            expired("no communicator id carrying this rank's nonce (is rank 0 running?)")
+            time.sleep(0.01)
+
+    # rank 0
+    try:
+        os.remove(gpath)  # a leftover id file carries nobody's live nonce; removed all the same
+    except OSError:
+        pass
+    uid = None
+    written: Optional[list] = None
+    while True:
+        seen = [(_read_words(f"{gpath}.ready.{r}", 1) or (None,))[0] for r in range(1, world)]
+        if all(v is not None for v in seen):
+            if uid is None:
+                uid = make_id()
+                if len(uid) != nbytes:
+                    raise ValueError(f"unique id must be {nbytes} bytes")
+            if seen != written:
+                _write_atomic(gpath, _ID_MAGIC + struct.pack("<qqQ", int(generation), int(world), nonce) + struct.pack(f"<{world - 1}Q", *seen) + uid)
+                written = list(seen)
+            acks = [_read_words(f"{gpath}.ack.{r}", 2) for r in range(1, world)]
+            if acks == [(v, nonce) for v in written]:
+                break
+        expired("not every rank published its nonce and acknowledged the id")
+        time.sleep(0.01)
+    for name in [gpath] + [f"{gpath}.{kind}.{r}" for kind in ("ready", "ack") for r in range(1, world)]:
         try:
-            os.remove(gpath)  # a stale file of an earlier job: nobody may pick it up while the new id is being made
+            os.remove(name)
         except OSError:
             pass
-        uid = make_id()
-        if len(uid) != nbytes:
-            raise ValueError(f"unique id must be {nbytes} bytes")
-        tmp = f"{gpath}.tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(_ID_MAGIC + struct.pack("<qqd", int(generation), int(world), time.time()) + uid)
-            f.flush()
-            os.fsync(f.fileno())
-        os.replace(tmp, gpath)
-        return uid
-    t0 = time.monotonic()
-    hdr = len(_ID_MAGIC) + 24
-    while True:
-        try:
-            with open(gpath, "rb") as f:
-                blob = f.read()
-            if len(blob) == hdr + nbytes and blob[: len(_ID_MAGIC)] == _ID_MAGIC:
-                gen, w, stamp = struct.unpack("<qqd", blob[len(_ID_MAGIC) : hdr])
-                if gen == generation and w == world and stamp >= not_before:
-                    return blob[hdr:]
-        except FileNotFoundError:
-            pass
-        if time.monotonic() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no communicator id (generation {generation}) at {gpath} after {timeout:.0f} s (is rank 0 running?)")
-        time.sleep(0.02)
+    return uid
 
 
 class RcclComm:
@@ -150,11 +198,6 @@ class RcclComm:
         self.raw = _ffi.Comm(device, rank, world, uid)  # collective: returns once every rank has joined
         # what RCCL itself says about the communicator; SLAM_ERR_STATE if it is not the job we asked for
         self.rccl_rank, self.rccl_world = self.raw.rccl_rank_world()
-        if self.rank == 0 and self.world > 1:
-            try:
-                os.remove(_generation_path(self.path, gen))  # every rank holds the id by now
-            except OSError:
-                pass
 
     @classmethod
     def from_env(cls, device: Optional[int] = None, env=os.environ) -> "RcclComm":

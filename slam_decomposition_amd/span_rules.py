@@ -28,6 +28,17 @@ the exact coverage polytopes are not available here, but a LOWER bound on the te
   canonical parameters s-majorised by t lambda(H); the folded representative minimises both expressions), and a
   simulation time is subadditive under composition with local gates in between ("chaining").
 
+Round 4 -- exact coverage of TWO-gate products beyond the single-gate classes (``sequence_minimal_span``).  The set of Weyl
+coordinates of ``g_2 L g_1`` over all local unitaries L is what monodromy's polytope for the pair describes; for the pairs below it
+was obtained here by sampling L over SU(2) x SU(2) (4e5 draws, ``tools/fit_two_gate_region.py``), reading off the supporting
+half-spaces in the folded coordinates (x >= y >= |z|, x <= 1/2) and checking that the polytope they cut out is FILLED (no empty cell
+of a 0.02 grid inside, no sample outside) -- and then against the brute-force span loop on the GPU (tests/test_gpu_round4.py):
+
+* iSWAP . L . B (either order):  x >= 1/4  and  |z| <= 1/4   -- 97.75 % of the Haar measure, the fraction of targets the
+  brute-force loop of config 3 ([iSWAP, B, iSWAP][:k]) solves with two gates;
+* g . L . g for an XY-type gate g = (a, a, 0), a <= 1/4 (``RiSwapGate(alpha)``, alpha = 4a <= 1; zero-phase conversion-only or
+  gain-only ``ConversionGainGate``):  |z| <= x - y,  x + y + |z| <= 4a,  x <= 2a   (a = 1/4: the sqrt(iSWAP) rule above).
+
 ``span_lower_bound`` is sound (a target is never placed above its true size: tests/test_gpu_round3.py checks it against the
 brute-force span loop on the config-4 and config-5 bases) but not tight: the span loop starts at the bound instead of at 1
 and targets whose bound exceeds the template's maximum are not optimised at all.
@@ -112,9 +123,78 @@ def span_lower_bound(target_coords, gate_coords_seq, k_max=None, slack: float = 
     gf = _fold(g[:1])[0]
     same = np.max(np.abs(np.abs(c) - np.abs(gf)), axis=1) < _TOL
     lb = np.full(n, k_max + 1, dtype=np.int64)
+    region2 = two_gate_region(g[0], g[1]) if k_max >= 2 else None
     for k in range(k_max, 1, -1):
-        ok = np.all(mt <= cum[k - 1] + slack, axis=1)
+        if k == 2 and region2 is not None:
+            ok = region2(c[:, 0], c[:, 1], c[:, 2], _TOL + slack)  # the pair's exact coverage region instead of the strength test
+        else:
+            ok = np.all(mt <= cum[k - 1] + slack, axis=1)
         lb = np.where(ok, k, lb)
     lb = np.where(same, 1, lb)
     lb = np.where(local, 0, lb)
     return lb
+
+
+def _is(g, ref) -> bool:
+    return bool(np.max(np.abs(np.abs(_fold(g)[0]) - np.array(ref))) < _TOL)
+
+
+def two_gate_region(g1, g2):
+    """Exact coverage of the two-gate product g_2 L g_1 (L any local unitary) in the folded chamber, for the pairs whose region is
+    known here: a function ``(x, y, z arrays, tol) -> bool array``, or None.  Symmetric in (g1, g2): transposition swaps the order
+    and leaves the Weyl coordinates alone."""
+    a1, a2 = np.abs(_fold(g1)[0]), np.abs(_fold(g2)[0])
+    same = bool(np.max(np.abs(a1 - a2)) < _TOL)
+    if same:
+        if _is(g1, FAMILIES["cx"]) or _is(g1, FAMILIES["iswap"]):
+            return lambda x, y, z, tol: np.abs(z) < tol  # the c3 = 0 face
+        if _is(g1, FAMILIES["b"]):
+            return lambda x, y, z, tol: np.ones(len(x), dtype=bool)
+        a = float(a1[0])
+        if abs(a1[1] - a) < _TOL and a1[2] < _TOL and _TOL < a <= 0.25 + _TOL:  # XY-type (a, a, 0), a <= 1/4
+            return lambda x, y, z, tol: (np.abs(z) <= x - y + tol) & (x + y + np.abs(z) <= 4 * a + tol) & (x <= 2 * a + tol)
+        return None
+    pair = (_is(g1, FAMILIES["iswap"]) and _is(g2, FAMILIES["b"])) or (_is(g1, FAMILIES["b"]) and _is(g2, FAMILIES["iswap"]))
+    if pair:
+        return lambda x, y, z, tol: (x >= 0.25 - tol) & (np.abs(z) <= 0.25 + tol)
+    return None
+
+
+_UNIVERSAL_IN_3 = ("cx", "iswap", "sqiswap", "b")
+
+
+def sequence_is_exact(gate_coords_seq, k_max: int) -> bool:
+    """True when ``sequence_minimal_span`` knows the exact template size of every target for the first ``k_max`` gates of the
+    sequence: one gate (its class), two (``two_gate_region``), and three or more when every gate is in a class three of which
+    reach everything (the brute-force loop on the GPU solves every Haar target with three: tests)."""
+    g = np.asarray(gate_coords_seq, dtype=np.float64).reshape(-1, 3)
+    if k_max > len(g) or k_max < 1:
+        return False
+    if k_max >= 2 and two_gate_region(g[0], g[1]) is None:
+        return False
+    if k_max >= 3:
+        for gi in g[:k_max]:
+            if not any(_is(gi, FAMILIES[f]) for f in _UNIVERSAL_IN_3):
+                return False
+    return k_max <= 3
+
+
+def sequence_minimal_span(target_coords, gate_coords_seq, k_max: int, slack: float = 0.0) -> np.ndarray:
+    """Exact number of leading gates of the sequence that reaches each target (0 = local, 1 = the first gate's class, 2 = inside
+    the pair's region, else 3), for sequences ``sequence_is_exact`` accepts; targets beyond ``k_max`` get ``k_max + 1``.
+    ``slack`` widens the k = 2 region (a caller that accepts loss < L accepts targets ~ sqrt(L) outside it)."""
+    g = np.asarray(gate_coords_seq, dtype=np.float64).reshape(-1, 3)
+    if not sequence_is_exact(g, k_max):
+        raise NotImplementedError("no exact coverage rule for this gate sequence: use span_lower_bound")
+    c = _fold(target_coords)
+    x, y, z = c[:, 0], c[:, 1], c[:, 2]
+    tol = _TOL + slack
+    local = np.max(np.abs(c), axis=1) < _TOL
+    gf = np.abs(_fold(g[:1])[0])
+    same = np.max(np.abs(np.abs(c) - gf), axis=1) < _TOL
+    k = np.full(len(c), 3 if k_max >= 3 else k_max + 1, dtype=np.int64)
+    if k_max >= 2:
+        k = np.where(two_gate_region(g[0], g[1])(x, y, z, tol), 2, k)
+    k = np.where(same, 1, k)
+    k = np.where(local, 0, k)
+    return k

@@ -32,7 +32,7 @@ class StubContext:
     def stats(self):
         return {k: (list(v) if isinstance(v, list) else v) for k, v in self._st.items()}
 
-    def decompose_range(self, first, count, k_min, k_max, gate_seqs, prm, threshold):
+    def decompose_range(self, first, count, k_min, k_max, gate_seqs, prm, threshold, fetch=True):
         idx = self._seed0 + first + np.arange(count)
         # every 7th target (by GLOBAL index) "fails": the solved count of the merged vector is then checkable
         loss = np.where(idx % 7 == 0, 1e-3, 1e-12 * (1 + idx % 5)).astype(np.float64)

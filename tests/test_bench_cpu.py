@@ -49,6 +49,32 @@ def test_two_ranks_through_the_launcher_and_the_file_communicator(scaling):
     assert out["value"] > 0
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_eight_ranks_slice_arithmetic_and_rank_diagnostics(scaling):
+    """The world size the driver's scaling run uses: 8 ranks through the launcher and the file communicator.  Checks the slice
+    arithmetic of the merged best-loss vector (rank * n_loc + (s - first_step) * n_per_step) through the solved count, and the
+    per-rank diagnostics a first 8-GPU run prints (own time, solved count, collective duration, evaluations per rank)."""
+    world, steps, warmup, n = 8, 3, 1, 256
+    p = _run(["--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup), "--targets", str(n), "--restarts", "2", "--scaling", scaling,
+              "--repeats", "3"], {"SLAM_BENCH_COMM": "file"}, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["scaling"] == scaling and len(out["rank_devices"]) == world
+    per_rank = n if scaling == "weak" else n // world
+    assert out["config"]["targets_per_step_per_gpu"] == per_rank
+    seed0 = 20260000
+    per_rank_solved = [_solved(seed0 + r * (steps + warmup) * per_rank + warmup * per_rank, steps * per_rank) for r in range(world)]
+    assert abs(out["solved_fraction"] - sum(per_rank_solved) / (world * steps * per_rank)) < 1e-12
+    d = out["rank_diag"]
+    assert d["solved"] == per_rank_solved  # every rank's own count, in rank order
+    assert len(d["own_ms"]) == world and all(v > 0 for v in d["own_ms"])
+    assert len(d["collective_ms"]) == world and all(v >= 0 for v in d["collective_ms"])
+    assert d["evals"] == [3 * 40 * steps * per_rank * 2] * world  # the stub's 40 evaluations per item and span
+    assert out["ms_per_step"] * steps >= max(d["own_ms"]) * 0.999  # the line's time is the MAX over ranks, barrier included
+
+
 def test_launcher_path_with_one_rank_and_plain_path_agree():
     """`SLAM_BENCH_FORCE_LAUNCH=1 bench.py --gpus 1` (launcher, rank process, communicator) and plain `bench.py` report the
     same work; and a rank whose communicator cannot come up ends the job non-zero instead of falling back."""

@@ -168,3 +168,71 @@ def test_shard_range_and_local_merge():
         assert cover == list(range(n))
     loss, x, cyc = merge_results(LocalComm(), 4, 0, np.arange(4.0), np.ones((4, 6)), np.array([1, 2, 3, 1]))
     assert np.array_equal(loss, np.arange(4.0)) and x.shape == (4, 6) and list(cyc) == [1, 2, 3, 1]
+
+
+def test_two_gate_coverage_regions_hold_on_sampled_products():
+    """span_rules.two_gate_region (round 4): the Weyl coordinates of g2 . L . g1 for random local L all lie inside the region the
+    rules state -- and reach its faces -- for iSWAP . L . B and for two XY-type gates (a, a, 0), a <= 1/4 (CPU: NumPy sampling, the
+    way the regions were obtained, tools/fit_two_gate_region.py)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fit_two_gate_region as fit
+
+    from slam_decomposition_amd import span_rules
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    for s1, s2 in (("iswap", "b"), ("b", "iswap"), ("riswap:0.4", "riswap:0.4"), ("sqiswap", "sqiswap"), ("riswap:0.2", "riswap:0.2"), ("cx", "cx"), ("b", "b")):
+        g1, g2 = fit.gate(s1), fit.gate(s2)
+        f = fit.fold(fit.sample_products(g1, g2, 30000, seed=5))
+        region = span_rules.two_gate_region(c1c2c3(g1), c1c2c3(g2))
+        assert region is not None
+        assert region(f[:, 0], f[:, 1], f[:, 2], 1e-9).all(), (s1, s2)
+    # the faces are reached (the region is not larger than the samples say): iSWAP . L . B touches x = 1/4 and |z| = 1/4
+    f = fit.fold(fit.sample_products(fit.gate("iswap"), fit.gate("b"), 30000, seed=6))
+    assert f[:, 0].min() < 0.2502 and np.abs(f[:, 2]).max() > 0.2495 and f[:, 0].max() > 0.4995
+    # exactness flags: [iSWAP, B, iSWAP] is exact up to three gates; an XY-type pair only up to two; a general pair not at all
+    isw, b = c1c2c3(fit.gate("iswap")), c1c2c3(fit.gate("b"))
+    assert span_rules.sequence_is_exact([isw, b, isw], 3) and span_rules.sequence_is_exact([b, isw], 2)
+    g = c1c2c3(fit.gate("riswap:0.4"))
+    assert span_rules.sequence_is_exact([g, g], 2) and not span_rules.sequence_is_exact([g, g, g], 3)
+    assert span_rules.two_gate_region(c1c2c3(fit.gate("cg:0.3:0.2")), isw) is None
+    # an XY-type gate with a > 1/4 has no rule here
+    assert span_rules.two_gate_region(c1c2c3(fit.gate("riswap:0.7")), c1c2c3(fit.gate("riswap:0.7"))) is None
+
+
+def test_target_data_list_semantics_on_the_host():
+    from slam_decomposition_amd.basis_abc import DataDictEntry, TargetDataList
+
+    x = np.arange(4 * 24, dtype=float).reshape(4, 24)
+    cyc = np.array([2, 3, 2, 1])
+    d = TargetDataList(np.array([True, True, False, True]), np.array([1e-12, 2e-12, 0.5, 3e-12]), x, cyc, lambda c: 6 * (c + 1))
+    assert len(d) == 4 and d[0].cycles == 2 and len(d[0].Xk) == 18 and len(d[1].Xk) == 24 and len(d[3].Xk) == 12
+    assert d[2].success_label == 0 and d[2].loss_result == 0.5 and d[-1] is d[3] and d[1] is d[1]
+    assert [e.cycles for e in d] == [2, 3, 2, 1] and isinstance(d[1:3], list) and len(d[1:3]) == 2
+    plain = [DataDictEntry(int(l), float(v), x[i, : 6 * (c + 1)], int(c)) for i, (l, v, c) in enumerate(zip([1, 1, 0, 1], [1e-12, 2e-12, 0.5, 3e-12], cyc))]
+    assert d == plain and plain == d and not (d == plain[:3])
+    import pytest
+
+    with pytest.raises(IndexError):
+        d[4]
+    (a, b, c, e) = d  # unpacks like a list
+    assert a is d[0] and e is d[3]
+
+
+def test_fd_reference_fixture_is_what_the_oracle_computes():
+    """tests/golden/fd_reference.npz (the GPU parity test's reference-path results) spot-checked against a live run of the same
+    oracle call: scipy BFGS with finite differences, sequential restarts (src/slam/optimizer.py:233-303)."""
+    import os
+
+    from oracle import slam_oracle as o
+
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fd_reference.npz"))
+    assert int(ref["n"]) >= 64
+    idx = 3
+    target = o.haar_philox_port(int(ref["target_seed"]), idx)
+    best, xk, k, _ = o.run_reference(target, [o.riswap_matrix(0.5)], range(1, 4), int(ref["restarts"]), float(ref["level"]),
+                                     x0_fn=lambda kk, r: o.x0_philox(int(ref["opt_seed"]), idx, r, kk), analytic_jac=False)
+    assert k == int(ref["sqiswap_cycles"][idx]) and abs(best - float(ref["sqiswap_loss"][idx])) < 1e-12
+    assert np.max(np.abs(o.c1c2c3_raw(target) - ref["sqiswap_target_coords"][idx])) < 1e-12

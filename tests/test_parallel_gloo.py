@@ -79,8 +79,12 @@ def test_two_rank_merge_equals_single_rank(tmp_path):
 
 
 def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path):
-    """exchange_unique_id: rank 0 publishes atomically, the others (started earlier or later) read 128 bytes."""
+    """exchange_unique_id: the ranks (started earlier or later than rank 0) end with rank 0's 128 bytes; rank 0 returns once every
+    rank has acknowledged, and cleans the files up."""
     import threading
+    import time
+
+    import pytest
 
     from slam_decomposition_amd.parallel import exchange_unique_id, rendezvous_path
 
@@ -88,35 +92,36 @@ def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path):
     uid = bytes(range(128))
     got = {}
 
-    def reader(r):
+    def reader(r, delay):
+        time.sleep(delay)
         got[r] = exchange_unique_id(r, 3, path, lambda: b"", timeout=20)
 
-    ts = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
-    ts[0].start()
-    import time
-
-    time.sleep(0.1)
-    assert exchange_unique_id(0, 3, path, lambda: uid) == uid
-    ts[1].start()
+    ts = [threading.Thread(target=reader, args=(1, 0.0)), threading.Thread(target=reader, args=(2, 0.3))]
+    for t in ts:
+        t.start()
+    time.sleep(0.1)  # rank 1 is already waiting, rank 2 has not arrived yet
+    assert exchange_unique_id(0, 3, path, lambda: uid, timeout=20) == uid
     for t in ts:
         t.join()
     assert got == {1: uid, 2: uid}
-    # world 1 needs no file; ranks of one launcher derive the same path, another launcher's port a different one
+    assert os.listdir(str(tmp_path)) == []  # id, ready and ack files are gone
+    # world 1 needs no file; ranks of one launcher derive the same path, another launcher's port or restart count a different one
     assert exchange_unique_id(0, 1, str(tmp_path / "none"), lambda: uid) == uid
     a = rendezvous_path({"MASTER_PORT": "29500"})
     assert a == rendezvous_path({"MASTER_PORT": "29500"}) and a != rendezvous_path({"MASTER_PORT": "29501"})
+    assert a != rendezvous_path({"MASTER_PORT": "29500", "TORCHELASTIC_RESTART_COUNT": "1"})  # an elastic restart is a new attempt
     assert rendezvous_path({"SLAM_COMM_FILE": "/x/y"}) == "/x/y"
-    import pytest
-
     with pytest.raises(TimeoutError):
         exchange_unique_id(1, 2, str(tmp_path / "never"), lambda: uid, timeout=0.2)
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(0, 2, str(tmp_path / "alone"), lambda: uid, timeout=0.2)  # rank 0 without its peer: no silent success
 
 
 def test_file_rendezvous_rejects_stale_and_foreign_ids(tmp_path):
-    """a 128-byte file left at the rendezvous path by a crashed job (fixed SLAM_COMM_FILE, repeated torchrun
-    key) or by an EARLIER communicator of the same job must never be taken for this communicator's id -- the ranks
-    would sit in ncclCommInitRank with different ids for ever."""
-    import os
+    """ADVICE r2 + r3: whatever a crashed earlier attempt with the same key left at the rendezvous path -- an id file (of any age:
+    a torchrun elastic restart reuses the key within seconds), ready or ack files -- or an EARLIER communicator of the same job
+    must never be taken for this communicator's id: the ranks would sit in ncclCommInitRank with different ids for ever.  The
+    handshake carries per-attempt nonces; no wall clock is involved."""
     import struct
     import threading
     import time
@@ -128,31 +133,40 @@ def test_file_rendezvous_rejects_stale_and_foreign_ids(tmp_path):
 
     path = str(tmp_path / "id")
     old, new = bytes([7]) * 128, bytes(range(128))
-    # (a) a bare 128-byte leftover (round 2's format) and a well-formed file from long ago: both ignored
-    open(path, "wb").write(old)
-    with pytest.raises(TimeoutError):
-        exchange_unique_id(1, 2, path, lambda: b"", timeout=0.2)
-    open(path, "wb").write(parallel._ID_MAGIC + struct.pack("<qqd", 0, 2, time.time() - 86400.0) + old)
-    with pytest.raises(TimeoutError):
-        exchange_unique_id(1, 2, path, lambda: b"", timeout=0.2)
-    # (b) a reader that started before rank 0 gets the NEW id: rank 0 removes the leftover before it makes its own
+    # (a) leftovers at the id path: a bare 128-byte file (round 2's format), round 3's time-stamped format written a moment ago,
+    #     and a well-formed file of THIS format from an attempt that died a second ago (foreign nonces): none is ever accepted
+    leftovers = [old,
+                 b"SLAMID01" + struct.pack("<qqd", 0, 2, time.time()) + old,
+                 parallel._ID_MAGIC + struct.pack("<qqQ", 0, 2, 0x2222222222222223) + struct.pack("<Q", 0x1234567812345679) + old]
+    for blob in leftovers:
+        open(path, "wb").write(blob)
+        with pytest.raises(TimeoutError):
+            exchange_unique_id(1, 2, path, lambda: b"", timeout=0.2)
+    # (b) the crashed attempt also left rank 1's ready and ack files (consistent with each other and with the stale id file).
+    #     The new rank 0 starts FIRST: it picks the stale nonce up and publishes an id for it, but the stale ack does not carry
+    #     rank 0's nonce, so it keeps waiting; the live rank 1 arrives later with its own nonce, rank 0 re-publishes, both end
+    #     with the NEW id
+    open(path + ".ready.1", "wb").write(struct.pack("<Q", 0x1234567812345679))
+    open(path + ".ack.1", "wb").write(struct.pack("<QQ", 0x1234567812345679, 0x2222222222222223))
     got = {}
-    t = threading.Thread(target=lambda: got.setdefault(1, exchange_unique_id(1, 2, path, lambda: b"", timeout=20)))
-    t.start()
-    time.sleep(0.1)
-    assert exchange_unique_id(0, 2, path, lambda: new) == new
-    t.join()
-    assert got[1] == new
-    # (c) the second communicator on the same path has its own file: generation 0's id is never read for generation 1,
-    # neither is a file written for another world size
+    t0 = threading.Thread(target=lambda: got.setdefault(0, exchange_unique_id(0, 2, path, lambda: new, timeout=20)))
+    t0.start()
+    time.sleep(0.3)
+    assert 0 not in got  # the leftovers did not release rank 0
+    assert exchange_unique_id(1, 2, path, lambda: b"", timeout=20) == new
+    t0.join()
+    assert got[0] == new and os.listdir(str(tmp_path)) == []
+    # (c) the second communicator on the same path has its own files: generation 0's id is never read for generation 1,
+    #     neither is a file written for another world size
+    t0 = threading.Thread(target=lambda: got.setdefault("g0", exchange_unique_id(0, 2, path, lambda: new, timeout=5)))
+    t0.start()
     with pytest.raises(TimeoutError):
-        exchange_unique_id(1, 2, path, lambda: b"", timeout=0.2, generation=1)
+        exchange_unique_id(1, 2, path, lambda: b"", timeout=0.3, generation=1)
     with pytest.raises(TimeoutError):
-        exchange_unique_id(1, 3, path, lambda: b"", timeout=0.2)
-    newer = bytes([9]) * 128
-    assert exchange_unique_id(0, 2, path, lambda: newer, generation=1) == newer
-    assert exchange_unique_id(1, 2, path, lambda: b"", timeout=5, generation=1) == newer
-    assert exchange_unique_id(1, 2, path, lambda: b"", timeout=5) == new and os.path.exists(path + ".g1")
+        exchange_unique_id(1, 3, path, lambda: b"", timeout=0.3)
+    assert exchange_unique_id(1, 2, path, lambda: b"", timeout=5) == new  # (the timed-out readers' ready files do not disturb it)
+    t0.join()
+    assert got["g0"] == new
 
 
 FILE_WORKER = textwrap.dedent(

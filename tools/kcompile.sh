@@ -5,7 +5,7 @@ K=${1:-3}; GC=${2:-2}; shift 2
 mkdir -p build/kc
 cat > build/kc/one.hip <<SRC
 #include "../../slam_decomposition_amd/csrc/slam_kernels.hpp"
-template __global__ void slamdev::minimize_kernel<$K, $GC>(slamdev::MinimizeArgs<$K>);
+template __global__ void slamdev::minimize_kernel<$K, $GC, ${MQ:-false}>(slamdev::MinimizeArgs<$K>, const slamdev::MinimizeArgs<$K>*, int);
 SRC
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c --cuda-device-only -save-temps=obj -Rpass-analysis=kernel-resource-usage "$@" -o build/kc/one.o build/kc/one.hip 2> build/kc/usage.txt || { cat build/kc/usage.txt | head -30; exit 1; }
 grep -E "VGPRs:|ScratchSize|VGPRs Spill|SGPRs Spill|Occupancy" build/kc/usage.txt | sed 's/.*:     //; s/ \[-Rpass.*//' | tr '\n' ';'; echo

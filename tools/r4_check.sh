@@ -1,0 +1,26 @@
+#!/bin/bash
+# GPU box: the round's standing check -- GPU test suite, then the driver's bench command (line kept under gpurun_out/r4_check/).
+# usage: tools/r4_check.sh [pytest -k expression]
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/r4_check; mkdir -p $OUT
+if [ -n "$1" ]; then
+  timeout -k 10 900 python3 -m pytest tests -m gpu -x -q -k "$1" > $OUT/pytest.txt 2>&1 || { tail -40 $OUT/pytest.txt; exit 1; }
+else
+  timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > $OUT/pytest.txt 2>&1 || { tail -40 $OUT/pytest.txt; exit 1; }
+fi
+tail -3 $OUT/pytest.txt
+timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err || { tail -20 $OUT/bench_default.err; exit 1; }
+python3 - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r4_check/bench_default.json").read().strip().splitlines()[-1])
+r = d["roofline"]
+print("value %.4g ms/step %.3f [%.3f..%.3f] frac %.3f frac_kernel %s" % (d["value"], d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"], r["frac"], r.get("frac_kernel")))
+print("per_span", {k: (round(v["hip_event_ms"], 3), round(v["frac"], 3)) for k, v in r["per_span"].items() if k != "all"}, r["per_span"]["all"])
+print("parity", d.get("parity_sample"))
+print("cpu", {k: d["cpu_baseline"][k] for k in ("value", "cores", "per_core")})
+s = d.get("secondary", {})
+print("cfg2", s.get("cfg2", {}).get("value"), s.get("cfg2", {}).get("roofline_frac"))
+print("v2", s.get("v2", {}).get("value"), s.get("v2", {}).get("roofline_frac"))
+print("api", s.get("api"))
+PY
