@@ -239,7 +239,7 @@ def traffic_per_launch(workload: str):
     """HBM bytes per optimizer-kernel launch (mean over the three spans) from the committed PMC passes
     (profiles/r2_traffic.json, else r1d_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
     None for workloads that were not profiled."""
-    for name in ("r3_traffic.json", "r2_traffic.json", "r1d_traffic.json"):
+    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1d_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload]
             return sum(t.values()) / len(t)
@@ -252,7 +252,7 @@ def pmc_figures(workload: str):
     """VALU-busy and achieved HBM GB/s of the optimizer launches, per span, from the committed rocprofv3 --pmc passes
     (profiles/r3_pmc.json, else r2_pmc.json; tools/profile_r3.sh writes them).  Counters cannot be collected inside an
     unprofiled run: these are the figures of the committed profile of the same command, named in `source`."""
-    for name in ("r3_pmc.json", "r2_pmc.json"):
+    for name in ("r4_pmc.json", "r3_pmc.json", "r2_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             per = d[workload]
@@ -517,12 +517,21 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     group = max(1, min(group, steps))
     # (the basis sweep cannot group its steps -- every step has its own gate -- so it keeps more of them in flight; measured on
     # MI355X, 160 steps: 4 in flight 1.42e6 decompositions/s / 0.289 of peak, 8: 1.68e6 / 0.338, 16: 1.82e6 / 0.363)
-    n_streams = n_streams_arg if n_streams_arg else (16 if gname == "cgsweep" else (4 if small else 5))
+    sweep = gname == "cgsweep"
+    # the basis sweep as ONE chain of kernels per 8 bases (round 4, slam_decompose_multi: per span one multi-queue optimizer launch
+    # over the bases' work queues -- a wavefront works on one basis at a time, gates stay scalar operands -- and one bookkeeping
+    # launch), 4 such calls in flight; --no-multi: one call per basis, 16 in flight (round 3).  Measured on MI355X (160 steps,
+    # tools/r4_cfg5b.sh): bases per call x calls in flight 16 x 2 -> 0.325 of peak, 16 x 4 0.324, 8 x 4 0.385, 8 x 6 0.381,
+    # 4 x 8 0.381, 2 x 12 0.375; one call per basis x 16 in flight 0.346.  (A launch over 16 queues runs exactly as fast as one queue
+    # of the same total size -- tools/r4_mq_probe.py --; what separates the rows is how well the calls' stage tails overlap.)
+    mq = sweep and not (main and args.span_rules) and not (main and args.no_multi)
+    if mq:
+        group = min(args.group if (main and args.group) else 8, SWEEP_BASES_PER_GPU, steps)
+    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else 5))
     n_streams = max(1, min(n_streams, (steps + group - 1) // group))
-    ctxs = [_ffi.Context(device) for _ in range(n_streams)]
+    ctxs = [_ffi.Context(device) for _ in range(n_streams * (group if mq else 1))]
     dev_name, cus, _ = ctxs[0].device_info()
     table = gate_table(gname)
-    sweep = gname == "cgsweep"
     host_targets = main and args.host_targets
     span_rules_mode = main and args.span_rules
     stub_mode = bool(os.environ.get("SLAM_BENCH_TEST_STUB"))
@@ -530,8 +539,17 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     # sampler (slam_sample_haar; --host-targets: SciPy's sampler on the host, ~55 us per target, then uploaded)
     n_resident = n_per_step if sweep else total_steps * n_per_step  # the sweep's targets are shared by all bases
     targets = make_targets(n_resident, seed0 if not sweep else TARGET_SEED0) if host_targets else None
-    for c in ctxs:
-        c.set_gates(table)
+    def basis_of(s: int) -> int:
+        # rank r takes column p = r of the (m, p) grid: all 16 strengths m, so every GPU has weak and strong gates
+        return (s % SWEEP_BASES_PER_GPU) * 8 + rank % 8
+
+    ctx_basis = {}
+    for i, c in enumerate(ctxs):
+        # multi-queue sweep: context i of a call's group serves the steps with s mod group == i mod group -- with 16 steps per call
+        # that is ONE basis for the whole run (its gate is set once, here)
+        if mq:
+            ctx_basis[id(c)] = basis_of(i % group)
+        c.set_gates(np.stack([sweep_gate(basis_of(i % group))]) if mq else table)
         if host_targets:
             c.set_targets(targets)
         else:
@@ -541,10 +559,6 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     flags = _ffi.FLAG_EARLY_EXIT | (0 if args.fast_exit else _ffi.FLAG_ORDERED)
     prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=flags, items_per_quad=ipq)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
-
-    def basis_of(s: int) -> int:
-        # rank r takes column p = r of the (m, p) grid: all 16 strengths m, so every GPU has weak and strong gates
-        return (s % SWEEP_BASES_PER_GPU) * 8 + rank % 8
 
     gate_coords = None
     if span_rules_mode:
@@ -629,6 +643,19 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
 
         def worker(w):
             for g in groups[w::n_streams]:
+                if mq:
+                    # one library call for up to 16 consecutive steps = 16 different bases (step s -> basis slot s mod 16)
+                    cg = ctxs[w * group : (w + 1) * group]
+                    sub = [cg[s % group] for s in g]
+                    for s, c in zip(g, sub):
+                        if ctx_basis[id(c)] != basis_of(s):  # (fewer than 16 steps per call: the slot changes its basis)
+                            c.set_gates(np.stack([sweep_gate(basis_of(s))]))
+                            ctx_basis[id(c)] = basis_of(s)
+                    _ffi.decompose_multi(sub, 0, n_per_step, 1, 3, gate_seqs, prm, threshold)
+                    for s, c in zip(g, sub):
+                        bl, _, bc = c.fetch_results_range(3, 0, n_per_step)
+                        results[s] = (bl, bc)
+                    continue
                 if len(g) == 1 or g != list(range(g[0], g[0] + len(g))):
                     for s in g:
                         results[s] = one_step(s, ctxs[w])
@@ -671,7 +698,10 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     # set-up, not a step: every context runs one batch once so that its device buffers exist and its
     # kernels are loaded (with 8 contexts, W < 8 warm-up steps would leave some of them cold)
     def prime_one(c):
-        if group > 1:
+        if mq:
+            w = ctxs.index(c) // group
+            _ffi.decompose_multi(ctxs[w * group : (w + 1) * group], 0, n_per_step, 1, 3, gate_seqs, prm, threshold)
+        elif group > 1:
             # the grouped call's work buffers are sized by its item count: allocate them here, not inside the timed region
             # (W < group warm-up steps would make a smaller call), and bring the device out of its idle clock state
             c.decompose_range(0, min(group, total_steps) * n_per_step, 1, 3, gate_seqs, prm, threshold)
@@ -679,7 +709,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
             one_step(0, c)
 
     if n_streams > 1 or group > 1:
-        prime = [threading.Thread(target=prime_one, args=(c,)) for c in ctxs]
+        prime = [threading.Thread(target=prime_one, args=(c,)) for c in (ctxs[::group] if mq else ctxs)]
         for t in prime:
             t.start()
         for t in prime:
@@ -837,7 +867,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         "cyc_hist": cyc_hist, "worst": worst, "per_basis": per_basis, "st": st, "achieved": achieved, "kernel_s": kernel_s,
         "rejected": rejected, "flops_accepted": flops_accepted, "flops_strict": flops_strict, "per_span": per_span,
         "resident_merge": resident_merge, "rep_ms": rep_ms, "strong": strong, "group": group, "gpu_sample": gpu_sample,
-        "rank_diag": rank_diag,
+        "rank_diag": rank_diag, "mq": mq,
     }
 
 
@@ -871,6 +901,7 @@ def main():
                     help="repetitions of the timed region (each exactly --steps steps between barriers); the line reports the median one and min / max")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU gets its own full-size batches; strong: one GPU's batch per step is split over the --gpus ranks")
+    ap.add_argument("--no-multi", action="store_true", help="cfg5: one library call per basis, 16 in flight (round 3) instead of slam_decompose_multi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets of the CPU baseline sample (default 4 x host cores)")
     ap.add_argument("--per-span-steps", type=int, default=3, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
@@ -977,6 +1008,7 @@ def main():
                                       if m["resident_merge"] else f"min-all-reduce of the best-loss vector ({type(comm).__name__})")),
                 "batches_in_flight_per_gpu": m["n_streams"],
                 "steps_per_library_call": m["group"],
+                **({"library_call": "slam_decompose_multi: one multi-queue optimizer launch per span over the call's bases"} if m["mq"] else {}),
                 "items_per_quad": m["ipq"],
                 "device": m["dev_name"],
                 "compute_units": m["cus"],

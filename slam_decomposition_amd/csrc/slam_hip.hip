@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace slamdev;
@@ -682,17 +683,11 @@ int decompose_impl(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
 // (e.g. the bases of a parametric-Hamiltonian sweep, BASELINE configs[4]) -- enqueued as ONE chain of kernels on the first
 // context's stream: per span ONE multi-queue optimizer launch (minimize_kernel<K, GC, true>: a wavefront works on one
 // sub-problem at a time, so gates stay scalar operands) and ONE epilogue launch for all of them.  Every context ends with the
-// results its own slam_decompose_range call would have left (ordered early exit: bit for bit).
+// results its own slam_decompose_range call would have left (ordered early exit: bit for bit) -- which is why contexts whose gates
+// fall into different structure classes get one optimizer launch PER CLASS (measured: the same item run through the GC_XRI1 and the
+// GC_XRI instantiation ends 1e-14 apart -- the compiler contracts the surrounding products differently -- so a launch in the most
+// general class of the group would not reproduce the per-context calls).
 // -----------------------------------------------------------------------------------------------------------------------
-int join_gate_class(int a, int b) {
-    if (a == b) return a;
-    auto xri_like = [](int g) { return g == GC_XRI1 || g == GC_XRI; };
-    if (xri_like(a) && xri_like(b)) return GC_XRI;
-    auto x_like = [&](int g) { return xri_like(g) || g == GC_XGEN; };
-    if (x_like(a) && x_like(b)) return GC_XGEN;
-    return GC_DENSE;
-}
-
 template <int K, int GC>
 int launch_minimize_multi(slam_ctx* lead, const MinimizeArgs<K>& common, const MinimizeArgs<K>* d_subs, int n, int64_t items_max_total) {
     const size_t lds = lds_bytes<K, GC>();
@@ -701,10 +696,8 @@ int launch_minimize_multi(slam_ctx* lead, const MinimizeArgs<K>& common, const M
     const int64_t cap = lead->resident_waves_mq[K][GC] > 0 ? lead->resident_waves_mq[K][GC] : 1;
     if (blocks > cap) blocks = cap;
     if (blocks < n) blocks = n;  // every sub-problem has a wavefront that starts on it
-    HIP_TRY(hipEventRecord(lead->ev_a[K], lead->stream));
     hipLaunchKernelGGL((minimize_kernel<K, GC, true>), dim3((unsigned)blocks), dim3(kWave), lds, lead->stream, common, d_subs, n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(lead->ev_b[K], lead->stream));
     return SLAM_OK;
 }
 
@@ -786,46 +779,58 @@ int decompose_multi_body(slam_ctx** cs, int n, int64_t first, int64_t count, int
     for (int k = k_min; k <= k_max; ++k) {
         char* h = static_cast<char*>(lead->h_mq_args) + slot * (size_t)k;
         char* d = static_cast<char*>(lead->mq_args.p) + slot * (size_t)k;
-        int gc = -1;
         MinimizeArgs<1>* h_ma = reinterpret_cast<MinimizeArgs<1>*>(h);  // (one layout for every span)
         EpilogueArgs* h_ep = reinterpret_cast<EpilogueArgs*>(h + (size_t)n * sz_ma);
-        for (int i = 0; i < n; ++i) {
+        // contexts ordered by the structure class of their gates: one contiguous run of argument blocks, one launch, per class
+        std::vector<int> order((size_t)n), cls((size_t)n);
+        for (int i = 0; i < n; ++i) { order[(size_t)i] = i; cls[(size_t)i] = classify_gates(cs[i], k, gs); }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[(size_t)a] < cls[(size_t)b]; });
+        for (int slot_i = 0; slot_i < n; ++slot_i) {
+            const int i = order[(size_t)slot_i];
             slam_ctx* c = cs[i];
-            const int g = classify_gates(c, k, gs);
-            gc = gc < 0 ? g : join_gate_class(gc, g);
             const double* d_stage_targets = d_active[(size_t)i] ? c->stage_targets.as<double>() : c->targets.as<double>();
             StageLaunch sl{success_threshold, gs, d_stage_targets, d_active[(size_t)i], 0, nullptr, N * (int64_t)prm->restarts, prm, stage_ctl(c, k)};
             switch (k) {
-                case 1: rc = build_minimize_args<1>(c, sl, *reinterpret_cast<MinimizeArgs<1>*>(&h_ma[i])); break;
-                case 2: rc = build_minimize_args<2>(c, sl, *reinterpret_cast<MinimizeArgs<2>*>(&h_ma[i])); break;
-                default: rc = build_minimize_args<3>(c, sl, *reinterpret_cast<MinimizeArgs<3>*>(&h_ma[i])); break;
+                case 1: rc = build_minimize_args<1>(c, sl, *reinterpret_cast<MinimizeArgs<1>*>(&h_ma[slot_i])); break;
+                case 2: rc = build_minimize_args<2>(c, sl, *reinterpret_cast<MinimizeArgs<2>*>(&h_ma[slot_i])); break;
+                default: rc = build_minimize_args<3>(c, sl, *reinterpret_cast<MinimizeArgs<3>*>(&h_ma[slot_i])); break;
             }
             if (rc) return rc;
             if (c != lead) HIP_TRY(hipStreamSynchronize(c->stream));  // (its gate slot may just have been staged on its own stream)
             SpanLoopStep step{success_threshold, true, k < k_max, success_threshold, nxt[(size_t)i]->as<int32_t>()};
             const ReduceArgs r = build_reduce_args(c, k, d_active[(size_t)i], prm, success_threshold, true);
-            h_ep[i] = build_epilogue_args(c, k, r, step);
+            h_ep[slot_i] = build_epilogue_args(c, k, r, step);
         }
         HIP_TRY(hipMemcpyAsync(d, h, slot, hipMemcpyHostToDevice, lead->stream));
-        const int64_t items_total = (int64_t)n * N * prm->restarts;
 #define SLAM_MQ_CASE(KK)                                                                                                                         \
     case KK: {                                                                                                                                   \
-        const MinimizeArgs<KK>& a0 = *reinterpret_cast<const MinimizeArgs<KK>*>(&h_ma[0]);                                                       \
-        const MinimizeArgs<KK>* dsub = reinterpret_cast<const MinimizeArgs<KK>*>(d);                                                             \
-        if (gc == GC_CX) rc = launch_minimize_multi<KK, GC_CX>(lead, a0, dsub, n, items_total);                                                  \
-        else if (gc == GC_XRI1) rc = launch_minimize_multi<KK, GC_XRI1>(lead, a0, dsub, n, items_total);                                         \
-        else if (gc == GC_XRI) rc = launch_minimize_multi<KK, GC_XRI>(lead, a0, dsub, n, items_total);                                           \
-        else if (gc == GC_XGEN) rc = launch_minimize_multi<KK, GC_XGEN>(lead, a0, dsub, n, items_total);                                         \
-        else rc = launch_minimize_multi<KK, GC_DENSE>(lead, a0, dsub, n, items_total);                                                           \
+        const MinimizeArgs<KK>& a0 = *reinterpret_cast<const MinimizeArgs<KK>*>(&h_ma[lo]);                                                      \
+        const MinimizeArgs<KK>* dsub = reinterpret_cast<const MinimizeArgs<KK>*>(d) + lo;                                                        \
+        if (gc == GC_CX) rc = launch_minimize_multi<KK, GC_CX>(lead, a0, dsub, cnt, items_total);                                                \
+        else if (gc == GC_XRI1) rc = launch_minimize_multi<KK, GC_XRI1>(lead, a0, dsub, cnt, items_total);                                       \
+        else if (gc == GC_XRI) rc = launch_minimize_multi<KK, GC_XRI>(lead, a0, dsub, cnt, items_total);                                         \
+        else if (gc == GC_XGEN) rc = launch_minimize_multi<KK, GC_XGEN>(lead, a0, dsub, cnt, items_total);                                       \
+        else rc = launch_minimize_multi<KK, GC_DENSE>(lead, a0, dsub, cnt, items_total);                                                         \
     } break;
-        switch (k) {
-            SLAM_MQ_CASE(1)
-            SLAM_MQ_CASE(2)
-            SLAM_MQ_CASE(3)
-            default: return fail(SLAM_ERR_UNSUPPORTED, "slam_decompose_multi runs spans 1..3");
+        HIP_TRY(hipEventRecord(lead->ev_a[k], lead->stream));
+        for (int lo = 0; lo < n;) {
+            const int gc = cls[(size_t)order[(size_t)lo]];
+            int hi = lo;
+            while (hi < n && cls[(size_t)order[(size_t)hi]] == gc) ++hi;
+            const int cnt = hi - lo;
+            const int64_t items_total = (int64_t)cnt * N * prm->restarts;
+            switch (k) {
+                SLAM_MQ_CASE(1)
+                SLAM_MQ_CASE(2)
+                SLAM_MQ_CASE(3)
+                default: return fail(SLAM_ERR_UNSUPPORTED, "slam_decompose_multi runs spans 1..3");
+            }
+            if (rc) return rc;
+            lead->stats.kernel_launches += 1;
+            lo = hi;
         }
+        HIP_TRY(hipEventRecord(lead->ev_b[k], lead->stream));
 #undef SLAM_MQ_CASE
-        if (rc) return rc;
         hipLaunchKernelGGL(stage_epilogue_multi_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), 0, lead->stream,
                            reinterpret_cast<const EpilogueArgs*>(d + (size_t)n * sz_ma));
         HIP_TRY(hipGetLastError());
@@ -861,7 +866,6 @@ int decompose_multi_body(slam_ctx** cs, int n, int64_t first, int64_t count, int
         HIP_TRY(hipEventElapsedTime(&kms, lead->ev_a[k], lead->ev_b[k]));
         lead->stats.kernel_ms += kms;
         lead->stats.kernel_ms_span[k] += kms;
-        lead->stats.kernel_launches += 1;
     }
     return SLAM_OK;
 }

@@ -12,8 +12,8 @@ constexpr double kStallDf = 1e-15;
 constexpr double kStallGnorm = 1e-5;
 // An accepted step whose slope along p fell by less than (1 - c2) was too short (weak-Wolfe curvature condition violated).  Such a
 // pair (s, y) carries a tiny s.y relative to the slope: it is NOT used to update the metric (round 3: SciPy's Wolfe search never
-// produces one; used, it pollutes the metric -- mean evaluations per item -11 .. -17 % at equal minima, oracle study in DESIGN.md),
-// and the next first trial step is longer.  c2 = 0.7, growth 8 (oracle grid; round 2: 0.9 / 4, growth only).
+// produces one; used, it pollutes the metric -- mean evaluations per item -11 .. -17 % at equal minima, oracle study in HISTORY.md),
+// and the next first trial step is longer.  c2 = 0.7, growth 8 (oracle grid, HISTORY.md; round 2: 0.9 / 4, growth only).
 constexpr double kWolfeC2 = 0.7;      // too short:
 constexpr double kGrowFactor = 8.0;   // the next first trial step is this much longer (compounding while it keeps
 constexpr double kGrowMax = 1048576.0;  // happening).  Covers negative curvature, where the update is skipped.

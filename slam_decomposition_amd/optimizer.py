@@ -86,8 +86,17 @@ class TemplateOptimizer:
             raise ValueError("Unrecognized Cost Function")
         if use_callback and not deterministic:
             raise ValueError("use_callback=True records the reference's sequential restart loop: it needs deterministic=True")
-        if override_method not in (None, "BFGS") and not (self._v2 and override_method in ("L-BFGS-B", "SLSQP")):
-            raise NotImplementedError(f"override_method={override_method!r}: the HIP path implements BFGS only")
+        # optimizer.py:266-268: override_method goes to scipy.optimize.minimize.  "BFGS" (and, for V2 templates, the methods the
+        # reference selects itself for bounds / constraints) is the loop the kernels run; "Nelder-Mead" (cost_function_comparison.ipynb)
+        # is driven from the host with the objective evaluated on the device (host_methods.py); anything else is not implemented
+        from . import host_methods
+
+        self._host_method = None
+        if override_method in host_methods.SUPPORTED and not self._v2 and not use_callback:
+            self._host_method = override_method
+        elif override_method not in (None, "BFGS") and not (self._v2 and override_method in ("L-BFGS-B", "SLSQP")):
+            raise NotImplementedError(f"override_method={override_method!r}: implemented are BFGS (device), Nelder-Mead (fixed-gate "
+                                      "templates without callback; host-driven, device objective), L-BFGS-B / SLSQP for V2 templates")
         if self.training_restarts <= 0:
             raise ValueError("training_restarts must be positive")
         self.device = basis.device if device is None else device
@@ -218,6 +227,61 @@ class TemplateOptimizer:
             self._set_stats([p[1] for p in parts])
         # per target the first 6 (cycles + 1) parameters of its row: the padded block goes back as it is (rows are cut when an
         # entry is looked at: 65 536 per-row slices cost more than the span loop on the GPU)
+        return best_loss, best_x, best_cycles
+
+    def _run_batch_host_method(self, targets: np.ndarray, spanning_range):
+        """``_run`` (optimizer.py:233-303) with ``override_method="Nelder-Mead"`` (:266-268): the simplex iterations of all
+        (target, restart) items of a span advance in lock-step on the host (host_methods.nelder_mead_batch: SciPy's algorithm and
+        defaults, ``maxiter=2500``), every objective value -- CircuitTemplate.eval + the cost -- comes from the device
+        (``slam_eval_loss_grad``, one launch per simplex operation).  Start points: ``parameter_guess`` (basis.py:106-111), i.e.
+        NumPy's global generator when ``seed`` is None, else a generator keyed on (seed, span).  Restart semantics as everywhere:
+        the result of a span is the lowest-index restart below the threshold, else the lowest loss."""
+        from . import host_methods
+
+        ks = [int(k) for k in spanning_range]
+        if not ks:
+            raise ValueError("empty spanning range")
+        n, R = len(targets), int(self.training_restarts)
+        ctx = runtime.get_context(self.devices[0])
+        ctx.set_targets(np.asarray(targets, dtype=np.complex128))
+        ctx.set_gates(self.basis.gate_matrices)
+        ctx.set_cost(self._cost_kind)
+        best_loss = np.full(n, np.inf)
+        best_x = [None] * n
+        best_cycles = np.full(n, -1, dtype=np.int32)
+        self._span_losses = np.full((n, _ffi.MAX_SPAN_EVAL), np.nan)
+        evals = [0] * (_ffi.MAX_SPAN_EVAL + 1)
+        for k in ks:
+            if k <= 0:
+                raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
+            if k > _ffi.MAX_SPAN_EVAL:
+                raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_EVAL} are implemented on the HIP path (got {k})")
+            act = np.nonzero(~(best_loss < self.success_threshold))[0]
+            if len(act) == 0:
+                break
+            npar = 6 * (k + 1)
+            if self.seed is None:
+                x0 = np.random.random((len(act), R, npar)) * 2 * np.pi
+            else:
+                x0 = np.random.default_rng([int(self.seed) & 0xFFFFFFFF, k]).random((n, R, npar))[act] * 2 * np.pi
+            seq = self.basis.gate_sequence(k)
+            tof = np.repeat(act, R).astype(np.int32)
+
+            def fun(items, X, tof=tof, seq=seq):
+                return ctx.eval_loss_grad(seq, X, tof[items], want_grad=False)[0]
+
+            x, f, _, nfev = host_methods.nelder_mead_batch(fun, x0.reshape(len(act) * R, npar), maxiter=MAXITER)
+            evals[k] += int(nfev.sum())
+            f, x = f.reshape(len(act), R), x.reshape(len(act), R, npar)
+            for j, t in enumerate(act):
+                below = np.nonzero(f[j] < self.success_threshold)[0]
+                r = int(below[0]) if len(below) else int(np.argmin(f[j]))  # optimizer.py:281-295: sequential restarts, first success wins
+                if best_cycles[t] < 0 or f[j, r] < best_loss[t]:
+                    best_loss[t], best_x[t], best_cycles[t] = float(f[j, r]), x[j, r].copy(), k
+                self._span_losses[t, k - 1] = best_loss[t]
+        self._set_stats([{"kernel_ms": 0.0, "kernel_launches": 0, "evals": evals, "items": [0] * len(evals), "total_ms": 0.0,
+                          "kernel_ms_span": [0.0] * len(evals), "wave_rounds": [0] * len(evals), "evals_accepted": [0] * len(evals),
+                          "evals_preempted": [0] * len(evals)}])
         return best_loss, best_x, best_cycles
 
     def _run_batch_any_order(self, targets: np.ndarray, ks):
@@ -588,14 +652,18 @@ class TemplateOptimizer:
         self._want_span_losses = log_on
         ctx0 = runtime.get_context(self.devices[0])
         need_coords = log_on or (self.basis.use_polytopes and not self._v2)
-        fast = (not need_coords and not self.use_callback and not self._v2 and not self.basis.use_polytopes)
+        fast = (not need_coords and not self.use_callback and not self._v2 and not self.basis.use_polytopes and self._host_method is None)
         if not fast and isinstance(stacked, _ResidentTargets):
             stacked = stacked.as_array()
         # target_invariant (basis_abc.py:80-84) for the whole batch, on the device
         coords_arr = ctx0.c1c2c3(stacked) if need_coords else None
         self.basis.assign_seed(None)  # optimizer.py:150-152
         spans_of = None
-        if self._v2 and not self.use_callback:
+        if self._host_method is not None:
+            spanning_range = list(self.basis.get_spanning_range(stacked[0]))
+            spans_of = [spanning_range] * n
+            best_loss, best_xs, best_cycles = self._run_batch_host_method(stacked, spanning_range)
+        elif self._v2 and not self.use_callback:
             spanning_range = list(self.basis.get_spanning_range(stacked[0]))
             spans_of = [spanning_range] * n
             best_loss, best_xs, best_cycles = self._run_batch_v2(stacked, spanning_range)

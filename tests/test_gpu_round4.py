@@ -177,3 +177,88 @@ def test_per_item_results_come_through_the_packed_records():
         W = o.template_eval(out["best_x"][t], [g] * k)
         assert abs(o.basic_cost(W, T[t]) - out["best_loss"][t]) < 1e-12
     assert X is None or X.shape[0] == N
+
+
+def test_decompose_multi_equals_one_call_per_context():
+    """slam_decompose_multi: the span loops of several contexts -- one basis gate each, the same targets -- as
+    ONE chain of kernels (a multi-queue optimizer launch per span) leave in every context exactly what its own slam_decompose_range
+    call leaves: losses, parameters and cycles bit for bit (ordered early exit), the same items per stage.  Contexts whose
+    gates fall into different structure classes get one launch per class (the same item through two instantiations ends 1e-14
+    apart); windows and repeated calls work."""
+    import bench
+
+    N, R = 700, 8
+    bases = [bench.sweep_gate(b) for b in (16, 40, 71, 96, 127)] + [G.RiSwapGate(0.5).to_matrix(), G.BerkeleyGate().to_matrix()]
+    prm = _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=31, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+    seqs = [[0], [0, 0], [0, 0, 0]]
+    ctxs = [_ffi.Context(0) for _ in bases]
+    try:
+        for c, g in zip(ctxs, bases):
+            c.sample_haar(808, N)
+            c.set_gates(g[None])
+        solo = []
+        for c in ctxs:
+            c.reset_stats()
+            solo.append(c.decompose_range(0, N, 1, 3, seqs, prm, 1e-10) + (c.stats(),))
+        for c in ctxs:
+            c.reset_stats()
+        _ffi.decompose_multi(ctxs, 0, N, 1, 3, seqs, prm, 1e-10)
+        for c, (l0, x0, c0, st0) in zip(ctxs, solo):
+            l1, x1, c1 = c.fetch_results_range(3, 0, N)
+            assert np.array_equal(l0, l1) and np.array_equal(c0, c1) and np.array_equal(x0, x1)
+            st1 = c.stats()
+            assert st1["items"] == st0["items"] and st1["evals"][1] == st0["evals"][1]  # (k >= 2: pre-empted evaluations depend on timing)
+        assert ctxs[0].stats()["kernel_launches"] == 6 and ctxs[1].stats()["kernel_launches"] == 0  # two gate classes x three spans
+        # a window, three of the contexts, spans 2..3 only, twice in a row
+        sub = [ctxs[4], ctxs[1], ctxs[6]]
+        want = [c.decompose_range(100, 333, 2, 3, seqs[1:], prm, 1e-10) for c in sub]
+        for _ in range(2):
+            _ffi.decompose_multi(sub, 100, 333, 2, 3, seqs[1:], prm, 1e-10)
+            for c, (l0, x0, c0) in zip(sub, want):
+                l1, x1, c1 = c.fetch_results_range(3, 100, 333)
+                assert np.array_equal(l0, l1) and np.array_equal(c0, c1) and np.array_equal(x0, x1)
+        # refused: the same context twice, no ordered early exit, spans beyond 3
+        with pytest.raises(_ffi.SlamHipError):
+            _ffi.decompose_multi([ctxs[0], ctxs[0]], 0, N, 1, 3, seqs, prm, 1e-10)
+        with pytest.raises(_ffi.SlamHipError):
+            _ffi.decompose_multi(ctxs[:2], 0, N, 1, 3, seqs, _ffi.OptParams(restarts=R, seed=31, flags=_ffi.FLAG_EARLY_EXIT), 1e-10)
+        # the contexts are usable on their own afterwards
+        l2, _, c2 = ctxs[0].decompose_range(0, N, 1, 3, seqs, prm, 1e-10)
+        assert np.array_equal(l2, solo[0][0]) and np.array_equal(c2, solo[0][2])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_override_method_nelder_mead_runs_scipys_simplex_on_the_device_objective():
+    """TemplateOptimizer(override_method="Nelder-Mead") (optimizer.py:266-268; cost_function_comparison.ipynb): the simplex method
+    driven from the host in lock-step over all restarts, objective values from the device.  From the same start points SciPy's own
+    Nelder-Mead on the CPU oracle takes the same path: equal losses to 1e-9 (the objective values differ in the last bits only) for
+    nearly every restart; "BFGS" is accepted; a method that is not implemented raises."""
+    import scipy.optimize as sopt
+
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    from slam_decomposition_amd.sampler import HaarBatch
+
+    gate = G.RiSwapGate(0.5)
+    basis = CircuitTemplate(base_gates=[gate], maximum_span_guess=1)
+    T = HaarBatch(seed0=77, n_samples=3).as_array()
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=3, seed=4, override_fail=True, override_method="Nelder-Mead")
+    tl, _, data = opt.approximate_from_distribution(HaarBatch(seed0=77, n_samples=3))
+    assert len(data) == 3 and all(d.cycles == 1 and d.success_label == 0 and len(d.Xk) == 12 for d in data)
+    x0 = np.random.default_rng([4, 1]).random((3, 3, 12)) * 2 * np.pi
+    g = o.riswap_matrix(0.5)
+    agree = 0
+    for t in range(3):
+        ref = [sopt.minimize(lambda xx: o.loss(xx, [g], T[t]), x0[t, r], method="Nelder-Mead", options={"maxiter": 2500}) for r in range(3)]
+        best = min(r.fun for r in ref)
+        agree += abs(best - data[t].loss_result) < 1e-9
+        assert abs(o.loss(np.asarray(data[t].Xk), [g], T[t]) - data[t].loss_result) < 1e-12  # the returned point has the returned loss
+        assert data[t].loss_result < best + 1e-3
+    assert agree >= 2
+    assert opt.last_stats["evals"][1] > 3 * 3 * 100
+    TemplateOptimizer(basis, BasicCost(), override_method="BFGS")
+    with pytest.raises(NotImplementedError):
+        TemplateOptimizer(basis, BasicCost(), override_method="Powell")

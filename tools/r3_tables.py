@@ -51,7 +51,7 @@ def main():
         "| `secondary.v2`": [f"**{sci(v2['value'])}**", f"{v2['ms_per_step']:.3f}", f"**{v2['roofline_frac']:.3f}**", "—"],
         "| CPU port": [f"{cb['value']:.1f} (finite differences, as the reference) / {cb['analytic_jac']['value']:.1f} (analytic gradient)", "—", "—", "—"],
     }
-    path = os.path.join(ROOT, "DESIGN.md")
+    path = os.path.join(ROOT, "HISTORY.md")  # (the round-3 document; DESIGN.md is the current design)
     text = open(path).read()
     start = text.index("Numbers measured on MI355X (round 3 build")
     end = text.index("**Why the k = 1 launch writes", start)
