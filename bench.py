@@ -450,7 +450,7 @@ def run_v2(rank: int, local_rank: int, steps: int = 64, warmup: int = 8, n_targe
     }
 
 
-def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: int = 3):
+def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: int = 3, shards: int = 0):
     """secondary.api: the drop-in method north_star names, end to end --
     ``TemplateOptimizer(CircuitTemplate([RiSwapGate(1/2)], maximum_span_guess=3), BasicCost(), training_restarts=32)
     .approximate_from_distribution(DeviceHaarBatch(n_samples=65536))`` (src/slam/optimizer.py:180-186): targets generated on the
@@ -467,7 +467,8 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
     basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3, device=device)
     times, solved = [], 0
     for r in range(reps + 1):
-        opt = TemplateOptimizer(basis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True)
+        opt = TemplateOptimizer(basis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True,
+                                **({"devices": [device] * shards} if shards else {}))
         t0 = time.perf_counter()
         loss, _, data = opt.approximate_from_distribution(DeviceHaarBatch(seed=TARGET_SEED0 + 9_000_000 + r, n_samples=n_targets, device=device))
         dt = time.perf_counter() - t0
@@ -926,7 +927,9 @@ def main():
         print(json.dumps(run_v2(0, 0)), flush=True)
         return
     if args.api_only:
-        print(json.dumps(run_api(0)), flush=True)
+        for sh in (0, 2, 4):  # 0: the default (auto_shards = 4 same-device shards for big batches)
+            r = run_api(0, shards=sh)
+            print(json.dumps({"shards": sh, "value": r["value"], "wall_ms_all": r["wall_ms_all"], "kernel_ms": r["kernel_ms"]}), flush=True)
         return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):

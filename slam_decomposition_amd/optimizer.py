@@ -59,6 +59,7 @@ class TemplateOptimizer:
         gtol=DEFAULT_GTOL,
         stop_loss=None,
         deterministic=True,
+        auto_shards=1,
     ):
         self.basis = basis
         self.objective = objective
@@ -107,6 +108,7 @@ class TemplateOptimizer:
             raise ValueError("devices must not be empty")
         self.seed = seed
         self.deterministic = bool(deterministic)
+        self.auto_shards = int(auto_shards)
         self.gtol = float(gtol)
         if stop_loss is None:
             stop_loss = min(DEFAULT_STOP_LOSS, 0.1 * self.success_threshold)
@@ -114,6 +116,7 @@ class TemplateOptimizer:
         self.last_stats = None
 
     # ------------------------------------------------------------------------------------------
+    AUTO_SHARD_MIN_TARGETS = 16384
     _device_sampler = None
     _want_span_losses = True
     last_stats_per_device = None
@@ -171,11 +174,19 @@ class TemplateOptimizer:
         prm = self._opt_params()
         n = len(targets)
 
-        def run_shard(device, first, count):
-            # a private context per shard holding only the shard's targets; the seeds are keyed on the GLOBAL target
-            # index (target_base), so a sharded run draws exactly the seeds of the single-device run
-            single = len(self.devices) == 1
-            ctx = runtime.get_context(device) if single else _ffi.Context(device)
+        devices = self.devices
+        if len(devices) == 1 and self.auto_shards > 1 and n >= self.AUTO_SHARD_MIN_TARGETS:
+            # opt-in (auto_shards > 1): a big batch on one GPU as target shards side by side (one cached context + stream + host
+            # thread each), bit-equal with the unsharded run.  Measured on MI355X, 65 536 x 32 sqrt(iSWAP) through
+            # approximate_from_distribution (tools/r4_api_probe.py): 1 / 2 / 4 / 8 shards -> 21.7 / 21.5 / 22.8 / 26.4 ms: ONE call
+            # gains nothing from being split -- what several batches in flight buy is the overlap of SUCCESSIVE
+            # batches; the shards of one batch still end with their own tails.  Hence the default of 1.
+            devices = devices * int(self.auto_shards)
+        def run_shard(device, first, count, r=0):
+            # a context per shard holding only the shard's targets (kept in runtime's cache: shard r uses slot r of its device);
+            # the seeds are keyed on the GLOBAL target index (target_base), so a sharded run draws exactly the seeds of the unsharded one
+            single = len(devices) == 1
+            ctx = runtime.get_context(device, 0 if single else r)
             try:
                 if self._device_sampler is not None:
                     self._device_sampler.fill(ctx, first, count)  # generated in place, nothing crosses PCIe
@@ -192,28 +203,26 @@ class TemplateOptimizer:
                 sl = ctx.fetch_span_losses(0, count) if self._want_span_losses else None
                 return out + (sl,), ctx.stats()
             finally:
-                if len(self.devices) > 1:
-                    ctx.close()
+                pass
 
-        if len(self.devices) == 1 or n < len(self.devices):
-            (best_loss, best_x, best_cycles, self._span_losses), st = run_shard(self.devices[0], 0, n)
+        if len(devices) == 1 or n < len(devices):
+            (best_loss, best_x, best_cycles, self._span_losses), st = run_shard(devices[0], 0, n)
             self._set_stats([st])
         else:
             import threading
 
             from .parallel import shard_range
 
-            parts = [None] * len(self.devices)
+            parts = [None] * len(devices)
             errors = []
-
             def work(r):
                 try:
-                    first, count = shard_range(n, r, len(self.devices))
-                    parts[r] = run_shard(self.devices[r], first, count)
+                    first, count = shard_range(n, r, len(devices))
+                    parts[r] = run_shard(devices[r], first, count, r)
                 except Exception as exc:  # surfaced below, in rank order
                     errors.append(exc)
 
-            threads = [threading.Thread(target=work, args=(r,)) for r in range(len(self.devices))]
+            threads = [threading.Thread(target=work, args=(r,)) for r in range(len(devices))]
             for t in threads:
                 t.start()
             for t in threads:

@@ -121,8 +121,9 @@ def test_span_lower_bounds_for_mixed_sequences_and_other_gates():
 
     isw, b, cx = (0.5, 0.5, 0.0), (0.5, 0.25, 0.0), (0.5, 0.0, 0.0)
     coords = np.array([(0, 0, 0), isw, b, (0.4, 0.3, 0.2), (0.5, 0.5, 0.5), (0.7, 0.2, 0.05)])
-    # [iSWAP, B, iSWAP]: local 0, the FIRST gate's class 1, everything else at least 2 (strong gates: the bound stops there)
-    assert span_rules.span_lower_bound(coords, [isw, b, isw]).tolist() == [0, 1, 2, 2, 2, 2]
+    # [iSWAP, B, iSWAP]: local 0, the FIRST gate's class 1; round 4: at k = 2 the pair's exact coverage region (x >= 1/4, |z| <= 1/4)
+    # stands in for the strength test -- SWAP (|z| = 1/2) needs the third gate
+    assert span_rules.span_lower_bound(coords, [isw, b, isw]).tolist() == [0, 1, 2, 2, 3, 2]
     # the bound never exceeds the exact rules of the single-gate families
     rng = np.random.default_rng(0)
     c = np.sort(rng.uniform(0, 0.5, (2000, 3)), axis=1)[:, ::-1]
@@ -133,12 +134,15 @@ def test_span_lower_bounds_for_mixed_sequences_and_other_gates():
     lb = span_rules.span_lower_bound(np.array([(0.05, 0.05, 0.0), (0.15, 0.1, 0.05), (0.3, 0.2, 0.1), (0.5, 0.5, 0.5)]), [weak] * 3)
     assert lb.tolist() == [2, 2, 3, 4]  # 4 = not reachable with the whole sequence
     assert np.allclose(span_rules.strength(np.array([(0.7, 0.2, 0.05)])), [[0.55, 0.3]])  # folds to (0.3, 0.2, -0.05)
-    # the template: exact for one known gate, lower bound + brute force from there otherwise
+    # the template: exact for one known gate and (round 4) for the [iSWAP, B] sequence; lower bound + brute force from there otherwise
     t = CircuitTemplate(base_gates=[RiSwapGate(1.0), BerkeleyGate()], use_polytopes=True, maximum_span_guess=3)
-    assert not t.span_rules_exact and CircuitTemplate(base_gates=[RiSwapGate(0.5)], use_polytopes=True).span_rules_exact
-    assert t.get_spanning_range(o.riswap_matrix(1.0)) == range(1, 4)       # iSWAP's own class: from one gate on
-    assert t.get_spanning_range(o.cx_matrix()) == range(2, 4)
-    assert t.get_spanning_range(np.eye(4)) == range(0, 4)
+    assert t.span_rules_exact and CircuitTemplate(base_gates=[RiSwapGate(0.5)], use_polytopes=True).span_rules_exact
+    assert t.get_spanning_range(o.riswap_matrix(1.0)) == range(1, 2)       # iSWAP's own class: one gate
+    assert t.get_spanning_range(o.cx_matrix()) == range(2, 3)               # (1/2, 0, 0): inside the pair's region
+    assert t.get_spanning_range(np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex)) == range(3, 4)  # SWAP
+    assert t.get_spanning_range(np.eye(4)) == range(0, 1)
+    t5 = CircuitTemplate(base_gates=[RiSwapGate(1.0), BerkeleyGate()], use_polytopes=True, maximum_span_guess=5)  # beyond three gates: bounds
+    assert not t5.span_rules_exact and t5.get_spanning_range(o.cx_matrix()) == range(2, 6)
     w = CircuitTemplate(base_gates=[RiSwapGate(0.2)], use_polytopes=True, maximum_span_guess=3)  # (0.1, 0.1, 0): no closed form
     assert not w.span_rules_exact
     with pytest.raises(ValueError, match="did not find a polytope"):          # polytope_wrap.py:91-93
