@@ -23,6 +23,7 @@ MAX_SPAN_MINIMIZE = 5
 ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED = range(6)
 FLAG_EARLY_EXIT = 1
 FLAG_ORDERED = 2  # with EARLY_EXIT: the lowest-index successful restart wins (reference semantics, reproducible)
+FLAG_STAGED = 4  # span loops: never use the one-wavefront-per-target kernel (small batches)
 MAX_MAXITER = 4000
 V2_MAX_SPAN = 5
 OP_SUM, OP_MAX, OP_MIN = 0, 2, 3

@@ -131,6 +131,7 @@ struct slam_ctx {
     slam_stats stats{};
     bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][kGateClasses][3] = {};  // [.][.][0] eval kernel, [1] optimizer kernel, [2] its multi-queue form
     int64_t resident_waves_mq[SLAM_MAX_SPAN_EVAL + 1][kGateClasses] = {};
+    int64_t resident_waves_wl[kGateClasses] = {};  // span_wave_kernel<GC>: resident wavefronts (0 = not asked yet)
     // slam_decompose_multi (this context leads the call): the sub-problems' argument blocks / epilogue arguments per span, staged
     // through pinned memory
     DevBuf mq_args;
@@ -587,6 +588,129 @@ void finish_fetch(slam_ctx* ctx, const FetchReq& fr) {
     if (fr.best_cycles) std::memcpy(fr.best_cycles, h + fr.b_loss + fr.b_x, fr.b_cyc);
 }
 
+// -----------------------------------------------------------------------------------------------------------------------
+// Small batches: the whole span loop of a target in ONE wavefront (span_wave_kernel, slam_kernels.hpp) -- one launch per call, no
+// stage barrier across targets, no bookkeeping launches.  Used when the batch is at most kWaveLoopTargetsPerSimd targets per SIMD,
+// spans <= 3, ordered early exit, one gate structure class for all spans; SLAM_FLAG_STAGED forces the per-span launches.
+// -----------------------------------------------------------------------------------------------------------------------
+constexpr int kWaveLoopTargetsPerSimd = 1;
+
+template <int GC>
+int launch_span_wave(slam_ctx* c, const WaveLoopArgs& a, int64_t count) {
+    const size_t lds = sizeof(double) * (size_t)(lds_doubles<3, GC>() + kWlLdsDoubles);
+    if (c->resident_waves_wl[GC] == 0) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&span_wave_kernel<GC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&span_wave_kernel<GC>), kWave, lds));
+        c->resident_waves_wl[GC] = (int64_t)(per_cu < 1 ? 1 : per_cu) * c->compute_units;
+    }
+    const int64_t blocks = count;  // one wavefront per target
+    hipLaunchKernelGGL((span_wave_kernel<GC>), dim3((unsigned)blocks), dim3(kWave), lds, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+// returns SLAM_OK and *taken = true when the call was served by the wave-loop kernel; *taken = false: not eligible (nothing enqueued)
+int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* prm,
+                        double success_threshold, FetchReq* fetch, bool* taken) {
+    *taken = false;
+    if (prm->flags & SLAM_FLAG_STAGED) return SLAM_OK;
+    if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED)) return SLAM_OK;
+    if (k_max > 3 || c->trace_cap > 0) return SLAM_OK;
+    if (count > (int64_t)kWaveLoopTargetsPerSimd * 4 * c->compute_units) return SLAM_OK;
+    int gc = -1;
+    {
+        const int32_t* gs = gate_seqs;
+        for (int k = k_min; k <= k_max; ++k) {
+            const int g = classify_gates(c, k, gs);
+            if (gc >= 0 && g != gc) return SLAM_OK;  // (per-span classes differ: the per-span launches use each span's own class)
+            gc = g;
+            gs += k;
+        }
+    }
+    // argument blocks of the spans (the kernels' own MinimizeArgs layout), staged through pinned memory
+    const size_t need = sizeof(MinimizeArgs<1>) * (size_t)(SLAM_MAX_SPAN_EVAL + 1);
+    HIP_TRY(c->mq_args.reserve(need));
+    if (need > c->h_mq_cap) {
+        if (c->h_mq_args) (void)hipHostFree(c->h_mq_args);
+        c->h_mq_args = nullptr;
+        c->h_mq_cap = 0;
+        HIP_TRY(hipHostMalloc(&c->h_mq_args, need, hipHostMallocDefault));
+        c->h_mq_cap = need;
+    }
+    MinimizeArgs<1>* h = static_cast<MinimizeArgs<1>*>(c->h_mq_args);
+    const int32_t* gs = gate_seqs;
+    for (int k = k_min; k <= k_max; ++k) {
+        StageLaunch sl{success_threshold, gs, c->targets.as<double>(), nullptr, 0, nullptr, count * (int64_t)prm->restarts, prm, stage_ctl(c, k)};
+        int rc;
+        switch (k) {
+            case 1: rc = build_minimize_args<1>(c, sl, *reinterpret_cast<MinimizeArgs<1>*>(&h[k])); break;
+            case 2: rc = build_minimize_args<2>(c, sl, *reinterpret_cast<MinimizeArgs<2>*>(&h[k])); break;
+            default: rc = build_minimize_args<3>(c, sl, *reinterpret_cast<MinimizeArgs<3>*>(&h[k])); break;
+        }
+        if (rc) return rc;
+        gs += k;
+    }
+    *taken = true;
+    HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->mq_args.p, h, need, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), c->stream));
+    WaveLoopArgs a{};
+    a.stage_args = c->mq_args.as<MinimizeArgs<1>>();
+    a.ctl = c->counters.as<StageCtl>();
+    a.k_min = k_min;
+    a.k_max = k_max;
+    a.first = (int32_t)first;
+    a.count = (int32_t)count;
+    a.threshold = success_threshold;
+    a.best_loss = c->best_loss.as<double>();
+    a.best_x = c->best_x.as<double>();
+    a.best_cycles = c->best_cycles.as<int32_t>();
+    a.span_loss = c->span_loss.as<double>();
+    a.nmax = c->result_nmax;
+    // every wavefront leaves a stage after this many rounds whatever happens: far above what R restarts of maxiter iterations
+    // (each at most 1 + 21 line-search evaluations) can need when they run 16 at a time
+    {
+        const double need_rounds = ((double)prm->restarts / 16.0 + 1.0) * ((double)prm->maxiter + 2.0) * 22.0;
+        a.round_cap = need_rounds > 4.0e9 ? 0xffffffffu : (uint32_t)need_rounds;
+    }
+    HIP_TRY(hipEventRecord(c->ev_a[k_min], c->stream));
+    int rc;
+    if (gc == GC_CX) rc = launch_span_wave<GC_CX>(c, a, count);
+    else if (gc == GC_XRI1) rc = launch_span_wave<GC_XRI1>(c, a, count);
+    else if (gc == GC_XRI) rc = launch_span_wave<GC_XRI>(c, a, count);
+    else if (gc == GC_XGEN) rc = launch_span_wave<GC_XGEN>(c, a, count);
+    else rc = launch_span_wave<GC_DENSE>(c, a, count);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev_b[k_min], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    if (fetch) {
+        rc = enqueue_fetch_n(c, c->result_nmax, first, count, *fetch);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_ctl, c->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_done, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_done));
+    if (fetch) finish_fetch(c, *fetch);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    c->stats.total_ms = ms;
+    float kms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&kms, c->ev_a[k_min], c->ev_b[k_min]));
+    c->stats.kernel_ms += kms;
+    c->stats.kernel_ms_span[k_min] += kms;  // (one launch for all spans: its time is booked on the first one)
+    c->stats.kernel_launches += 1;
+    for (int k = k_min; k <= k_max; ++k) {
+        if (c->h_ctl[k].n_active <= 0) continue;
+        c->stats.evals[k] += (int64_t)c->h_ctl[k].evals;
+        c->stats.evals_accepted[k] += (int64_t)c->h_ctl[k].evals_accepted;
+        c->stats.evals_preempted[k] += (int64_t)c->h_ctl[k].evals_preempted;
+        c->stats.wave_rounds[k] += (int64_t)c->h_ctl[k].rounds;
+        c->stats.items[k] += (int64_t)c->h_ctl[k].n_active * prm->restarts;
+    }
+    return SLAM_OK;
+}
+
 // h_list != nullptr: the batch is the explicit list of resident-target indices h_list[0..count) (first ignored)
 int decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs,
                    const slam_opt_params* prm, double success_threshold, const int32_t* h_list, int k_layout,
@@ -623,6 +747,11 @@ int decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
         return fail(SLAM_ERR_STATE, "resident results were produced with a different k_max");
     rc = ensure_results(c, k_layout);
     if (rc) return rc;
+    if (!h_list && k_layout == k_max) {
+        bool taken = false;
+        rc = decompose_wave_loop(c, first, count, k_min, k_max, gate_seqs, prm, success_threshold, fetch, &taken);
+        if (rc || taken) return rc;
+    }
     const int64_t N = count;
     HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
     HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));

@@ -200,8 +200,28 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MinimizeArgs<
 // it finishes, so lanes stay busy although items need very different iteration counts.
 // All quads of a wave evaluate in lock-step (one fused loss+gradient per round).
 // ---------------------------------------------------------------------------------
-template <int K, int GC, bool MQ = false>
-__global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args, const MinimizeArgs<K>* subs, int n_sub) {
+// Wave-local stage (WL, span_wave_kernel): ONE wavefront runs all restarts of ONE target -- the queue is the restart range, the
+// early-exit flag an LDS word, and instead of per-item records in HBM the wavefront keeps the stage's winner (ordered rule: the
+// lowest-index restart below the exit level, else the lowest loss, ties to the lower index) as it goes.
+struct WlStage {
+    int t;               // resident index of the wavefront's target
+    int* flag;           // LDS: restarts - r of the lowest-index successful restart so far (0: none)
+    double* win_x;       // LDS: the winner's parameters [n]
+    double win_loss;     // wave-uniform
+    int win_r;           // wave-uniform; -1: no finite restart yet
+    bool hit;            // wave-uniform: a restart below the exit level has finished
+    unsigned long long ev_all, ev_acc, ev_pre;  // per lane (lane q = 0 of a quad): evaluations of the items it finished
+    unsigned rounds;
+    unsigned round_cap;  // exit condition every wavefront reaches whatever the state machine does (never met by a sane run)
+};
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K, int GC, bool MQ, bool WL>
+__device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const MinimizeArgs<K>* subs, int n_sub, WlStage& wl) {
+    static_assert(!WL || MQ, "the wave-local stage reads its argument block from device memory");
     using C = Cfg<K, psq_layout<K, GC>()>;
     constexpr int NA = C::NA;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -229,10 +249,12 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
     unsigned sub_idx = MQ ? (unsigned)blockIdx.x % (unsigned)n_sub : 0u;
     unsigned long long cur = MQ ? (unsigned long long)(subs + sub_idx) : 0ull;  // wave-uniform
     int sub_tries = 0;
-    unsigned n_act = (unsigned)(MQ ? cold_args<K, MQ>(cur)->ctl->n_active : args.ctl->n_active);
+    unsigned n_act = WL ? 1u : (unsigned)(MQ ? cold_args<K, MQ>(cur)->ctl->n_active : args.ctl->n_active);
     unsigned n_items = n_act * (unsigned)args.restarts;
     unsigned n_waves = (n_items + kQuadsPerWave - 1) / kQuadsPerWave;
-    if constexpr (!MQ) {
+    if constexpr (WL) {
+        n_waves = 1;  // this wavefront is the stage
+    } else if constexpr (!MQ) {
         if (args.items_per_quad > 1) {
             n_waves = (n_items + kQuadsPerWave * args.items_per_quad - 1) / (kQuadsPerWave * args.items_per_quad);
             if (n_waves < 1 && n_items) n_waves = 1;
@@ -274,13 +296,15 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
     h_set_identity_where<NA>(H, q, true);
     bool exhausted = false;  // wave-uniform
     const unsigned kChunk = kChunkV;  // wave-uniform: 16 (small batches: spread over all waves) .. 64
-    unsigned cur_next = 0, cur_end = 0;  // wave-uniform
+    unsigned cur_next = 0, cur_end = WL ? n_items : 0u;  // wave-uniform (WL: the whole restart range is this wavefront's chunk)
     unsigned pre_base = 0;               // lane 0: base of the prefetched chunk
     unsigned rounds = 0;                 // wave-uniform
-    if (lane == 0) pre_base = atomicAdd(&cold_args<K, MQ>(cur)->ctl->work_counter, kChunk);
+    if constexpr (!WL) {
+        if (lane == 0) pre_base = atomicAdd(&cold_args<K, MQ>(cur)->ctl->work_counter, kChunk);
+    }
 
     while (true) {
-        if constexpr (MQ) {
+        if constexpr (MQ && !WL) {
             // this sub-problem's queue is exhausted and the wavefront's quads have drained: on to the next one
             if (exhausted && !__any(live)) {
                 if (lane == 0 && rounds) atomicAdd(&cold_args<K, MQ>(cur)->ctl->rounds, (unsigned long long)rounds);
@@ -317,7 +341,9 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             const int n_idle = __popcll(__ballot(!live && q == 0));
             const bool go = n_idle >= kRefillBatch || n_idle == __popcll(__ballot(q == 0));
             while (go && !exhausted && __any(!live)) {
-                if (cur_next >= cur_end) {
+                if constexpr (WL) {
+                    if (cur_next >= cur_end) { exhausted = true; break; }
+                } else if (cur_next >= cur_end) {
                     const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)pre_base);
                     cur_next = b;
                     cur_end = (b + kChunk < n_items) ? b + kChunk : n_items;
@@ -339,7 +365,9 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                     // (SLAM_FLAG_ORDERED): only restarts with a HIGHER index than a successful one are dropped, so the
                     // winner is the lowest-index successful restart whatever the scheduling -- the restart the
                     // reference's sequential loop stops at (optimizer.py:287-295).
-                    const int fl = __hip_atomic_load(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[psl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int fl;
+                    if constexpr (WL) fl = *reinterpret_cast<volatile int*>(wl.flag);
+                    else fl = __hip_atomic_load(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[psl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int mine = args.restarts - (int)prs;
                     skipv = (args.flags & 2u) ? (fl > mine) : (fl != 0);
                 }
@@ -354,11 +382,13 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                 // the window is consumed up to the last position handed out (all of it when every position with work
                 // found a quad); the rest is looked at again next time
                 const unsigned consumed = (n_take == n_av) ? wlen : (unsigned)(64 - __builtin_clzll(handed_mask));
-                if (valid && skipv && (unsigned)lane < consumed) {
-                    // a sibling restart already succeeded: nothing to do for this item
-                    // (outputs and explicit seeds keep the [slot][restart] layout whatever the processing order)
-                    const unsigned o = psl * (unsigned)args.restarts + prs;
-                    item_rec_store_dropped(cold_args<K, MQ>(cur)->item_rec + o, ST_PREEMPTED);
+                if constexpr (!WL) {
+                    if (valid && skipv && (unsigned)lane < consumed) {
+                        // a sibling restart already succeeded: nothing to do for this item
+                        // (outputs and explicit seeds keep the [slot][restart] layout whatever the processing order)
+                        const unsigned o = psl * (unsigned)args.restarts + prs;
+                        item_rec_store_dropped(cold_args<K, MQ>(cur)->item_rec + o, ST_PREEMPTED);
+                    }
                 }
                 int* wp = reinterpret_cast<int*>(xchg);  // wave-private, dead between rounds: [16] slots, [16] restarts
                 if (handed) {
@@ -386,8 +416,13 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
                         slot = (int)sl;
                         const unsigned restart = rs;
                         // three independent loads (no load feeds another's address)
-                        tgt = cold_args<K, MQ>(cur)->orig ? cold_args<K, MQ>(cur)->orig[sl] : cold_args<K, MQ>(cur)->first_target + (int)sl;
-                        tcol = cold_args<K, MQ>(cur)->targets + (int64_t)sl * 32 + q * 2;
+                        if constexpr (WL) {
+                            tgt = wl.t;
+                            tcol = cold_args<K, MQ>(cur)->targets + (int64_t)wl.t * 32 + q * 2;
+                        } else {
+                            tgt = cold_args<K, MQ>(cur)->orig ? cold_args<K, MQ>(cur)->orig[sl] : cold_args<K, MQ>(cur)->first_target + (int)sl;
+                            tcol = cold_args<K, MQ>(cur)->targets + (int64_t)sl * 32 + q * 2;
+                        }
                         if (!shared) {
 #pragma unroll
                             for (int a = 0; a < NA; ++a) {
@@ -450,8 +485,11 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
         }
         if (!__any(live)) {
-            if constexpr (MQ) continue;  // (nothing is live, hence nothing loop-carried to copy: the next sub-problem, or out)
+            if constexpr (MQ && !WL) continue;  // (nothing is live, hence nothing loop-carried to copy: the next sub-problem, or out)
             else break;
+        }
+        if constexpr (WL) {
+            if (rounds >= wl.round_cap) break;
         }
         ++rounds;
 
@@ -459,8 +497,10 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
         // (loaded for every quad -- slot 0 for idle ones -- and only looked at after the evaluation, so that
         // the round does not start with a wait for global memory)
         int sflag = 0;
-        if (args.flags & 1u)
-            sflag = __hip_atomic_load(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (args.flags & 1u) {
+            if constexpr (WL) sflag = *reinterpret_cast<volatile int*>(wl.flag);
+            else sflag = __hip_atomic_load(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 
         // ---- 2. one fused loss + gradient evaluation at the trial point x + alpha p (x itself when
         //         fresh: alpha = 0, p = 0)
@@ -470,7 +510,8 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             double xt[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) xt[a] = fma(alpha, p[a], x[a]);
-            eval_quad<K, false, GC>(xt, tcol, MQ ? cold_args<K, MQ>(cur)->gates : args.gates, xq, fh, tbl, q, theta_bits, args.cost_kind, ft, gt, Wr, Wi);
+            eval_quad<K, false, GC>(xt, tcol, MQ ? cold_args<K, MQ>(cur)->gates : args.gates, xq, fh, tbl, q, theta_bits,
+                                    WL ? __builtin_amdgcn_readfirstlane(args.cost_kind) : args.cost_kind, ft, gt, Wr, Wi);
         }
         const bool active = live;
         const bool finite = isfinite(ft);
@@ -634,11 +675,45 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             const int mine = args.restarts - (int)(item - (unsigned)slot * (unsigned)args.restarts);
             const bool beaten = (args.flags & 2u) ? (sflag > mine) : (sflag != 0);
             if (active && !done && beaten) { status = ST_PREEMPTED; done = true; }
-            if (active && done && status != ST_PREEMPTED && f < args.exit_loss && q == 0)
-                __hip_atomic_fetch_max(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[slot], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (active && done && status != ST_PREEMPTED && f < args.exit_loss && q == 0) {
+                if constexpr (WL) __hip_atomic_fetch_max(wl.flag, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_fetch_max(&(MQ ? cold_args<K, MQ>(cur)->solved : args.solved)[slot], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         // ---- 6. finished items leave; their quads pull new work next round
-        if (active && done) {
+        if constexpr (WL) {
+            // the stage's winner, kept up to date as restarts finish (those of one round one after the other; item == restart here)
+            const bool fin = active && done;
+            if (fin && q == 0) {
+                const unsigned long long e = (unsigned long long)(nev & 0xFFFFF);
+                wl.ev_all += e;
+                if (status == ST_PREEMPTED) wl.ev_pre += e;
+                else wl.ev_acc += (unsigned long long)((unsigned)nev >> 20);
+            }
+            unsigned long long m = __ballot(fin && q == 0 && status != ST_PREEMPTED);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const double lf = readlane_f64(f, l);
+                const int lr = __builtin_amdgcn_readlane((int)item, l);
+                const bool below = lf < args.exit_loss;
+                const bool take = wl.hit ? (below && lr < wl.win_r) : (below || lf < wl.win_loss || (lf == wl.win_loss && lr < wl.win_r));
+                if (take) {  // wave-uniform
+                    wl.win_loss = lf;
+                    wl.win_r = lr;
+                    wl.hit = wl.hit || below;
+                    if ((lane >> 2) == (l >> 2)) {
+#pragma unroll
+                        for (int a = 0; a < NA; ++a)
+                            if (4 * a + q < C::N) wl.win_x[4 * a + q] = x[a];
+                    }
+                }
+            }
+            if (fin) {
+                live = false;
+                alpha = 0.0;
+            }
+        } else if (active && done) {
             if (q == 0) item_rec_store(cold_args<K, MQ>(cur)->item_rec + item, f, iters, status, nev & 0xFFFFF, (int)((unsigned)nev >> 20));
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
@@ -649,8 +724,114 @@ __global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(Minim
             alpha = 0.0;  // an idle quad keeps evaluating x + 0 p (its direction is reset when it takes the next item)
         }
     }
-    if constexpr (!MQ) {
+    if constexpr (WL) {
+        wl.rounds = rounds;
+        lds_fence();
+    } else if constexpr (!MQ) {
         if (lane == 0 && rounds) atomicAdd(&cold_args<K>()->ctl->rounds, (unsigned long long)rounds);
+    }
+}
+
+template <int K, int GC, bool MQ = false>
+__global__ void __launch_bounds__(kWave, (K <= 2 ? 2 : 1)) minimize_kernel(MinimizeArgs<K> args, const MinimizeArgs<K>* subs, int n_sub) {
+    WlStage none{};
+    minimize_body<K, GC, MQ, false>(args, subs, n_sub, none);
+}
+
+// ---------------------------------------------------------------------------------
+// The WHOLE span loop of a target in one wavefront (small batches: at most a few targets per SIMD).  Wavefront <-> target: all R
+// restarts of span k run in its 16 quads (wave-local queue, LDS early-exit flag), the winner is reduced as restarts finish, merged
+// into the target's running best (optimizer.py:281-284), and if that is still above the threshold (optimizer.py:301) the same
+// wavefront goes straight on to span k + 1 -- no stage barrier across targets, no bookkeeping launch, no per-item records.  A lone
+// 1024 x 16 batch then takes the longest PER-TARGET chain (sum over spans of that target's slowest needed restart) instead of the sum
+// of the three stages' slowest items.  Same items, same seeds, same quasi-Newton loop (minimize_body): the results are those of the
+// per-span kernels bit for bit.  One wavefront per SIMD (the k = 3 body's registers).
+// ---------------------------------------------------------------------------------
+struct WaveLoopArgs {
+    const MinimizeArgs<1>* stage_args;  // [SLAM_MAX_SPAN_EVAL + 1]: block k = the argument block of span k (one layout for all spans)
+    StageCtl* ctl;                      // [k]: counters; ctl[0].work_counter hands out the targets
+    int32_t k_min, k_max;
+    int32_t first, count;               // target window
+    double threshold;
+    double* best_loss;
+    double* best_x;
+    int32_t* best_cycles;
+    double* span_loss;
+    int32_t nmax;
+    uint32_t round_cap;                 // rounds after which a wavefront leaves a stage whatever happens
+};
+constexpr int kSpanLossStride = 5;  // = SLAM_MAX_SPAN_EVAL
+constexpr int kWlLdsDoubles = 40;  // winner row (<= 36 parameters) + the flag word
+
+template <int K, int GC>
+__device__ __forceinline__ void wave_stage(const WaveLoopArgs& a, int t, double* lds, double& best_loss, int& best_cycles) {
+    using C = Cfg<K, psq_layout<K, GC>()>;
+    const int lane = threadIdx.x;
+    const MinimizeArgs<K>* blk = reinterpret_cast<const MinimizeArgs<K>*>(a.stage_args) + K;
+    // the stage's argument block through scalar loads (wave-uniform: it feeds scalar operands and uniform branches)
+    MinimizeArgs<K> args;
+    {
+        unsigned long long pa = (unsigned long long)blk;
+        asm volatile("" : "+s"(pa));
+        __builtin_memcpy(&args, (const __attribute__((address_space(4))) void*)pa, sizeof(args));
+    }
+    WlStage wl{};
+    wl.t = t;
+    wl.win_x = lds + lds_doubles<3, GC>();
+    wl.flag = reinterpret_cast<int*>(wl.win_x + 36);
+    wl.win_loss = INFINITY;
+    wl.win_r = -1;
+    wl.hit = false;
+    wl.round_cap = a.round_cap;
+    if (lane == 0) *wl.flag = 0;
+    if (lane < 36) wl.win_x[lane] = 0.0;
+    lds_fence();
+    minimize_body<K, GC, true, true>(args, blk, 1, wl);
+    // counters of the stage: one atomic each per wavefront
+    unsigned long long e0 = wl.ev_all, e1 = wl.ev_acc, e2 = wl.ev_pre;
+    for (int off = 32; off > 0; off >>= 1) {
+        e0 += __shfl_down(e0, off);
+        e1 += __shfl_down(e1, off);
+        e2 += __shfl_down(e2, off);
+    }
+    if (lane == 0) {
+        StageCtl* c = a.ctl + K;
+        atomicAdd(&c->evals, e0);
+        atomicAdd(&c->evals_accepted, e1);
+        atomicAdd(&c->evals_preempted, e2);
+        atomicAdd(&c->rounds, (unsigned long long)wl.rounds);
+        atomicAdd(&c->n_active, 1);
+    }
+    // merge into the running best (optimizer.py:281-284), record the "Cycle (k =...)" value
+    const double stage_loss = wl.win_r >= 0 ? wl.win_loss : (double)INFINITY;
+    if (best_cycles < 0 || stage_loss < best_loss) {
+        best_loss = stage_loss;
+        best_cycles = K;
+        if (lane < a.nmax) a.best_x[(int64_t)t * a.nmax + lane] = (lane < C::N) ? wl.win_x[lane] : 0.0;
+    }
+    if (lane == 0) a.span_loss[(int64_t)t * kSpanLossStride + (K - 1)] = best_loss;
+    lds_fence();
+}
+
+template <int GC>
+__global__ void __launch_bounds__(kWave, 1) span_wave_kernel(WaveLoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    // one workgroup (= wavefront) per target: the grid IS the batch (at most a few wavefronts per SIMD by the host's eligibility rule).
+    // (A persistent form -- wavefronts pulling targets from a counter in a loop around the stages -- hung on the GPU: the compiler
+    // structurises that outer loop with per-lane exit masks around three inlined optimizer loops; a grid of independent wavefronts
+    // needs no loop and lets the hardware hand out the targets.)
+    const int i = (int)blockIdx.x;
+    if (i >= a.count) return;
+    const int t = a.first + i;
+    double best_loss = INFINITY;
+    int best_cycles = -1;
+    if (a.k_min <= 1 && a.k_max >= 1) wave_stage<1, GC>(a, t, lds, best_loss, best_cycles);
+    if (a.k_min <= 2 && a.k_max >= 2 && !(best_loss < a.threshold)) wave_stage<2, GC>(a, t, lds, best_loss, best_cycles);
+    if (a.k_min <= 3 && a.k_max >= 3 && !(best_loss < a.threshold)) wave_stage<3, GC>(a, t, lds, best_loss, best_cycles);
+    if (lane == 0) {
+        a.best_loss[t] = best_loss;
+        a.best_cycles[t] = best_cycles;
     }
 }
 
@@ -679,7 +860,6 @@ struct ReduceArgs {
     int32_t* best_cycles;      // [n_targets]
     double* span_loss;         // [n_targets][kSpanLossStride]: running best after span k at [k - 1] ("Cycle (k =...), Best Loss")
 };
-constexpr int kSpanLossStride = 5;  // = SLAM_MAX_SPAN_EVAL
 
 struct EvalCounts {
     unsigned long long all = 0, accepted = 0, preempted = 0;

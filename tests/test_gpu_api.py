@@ -120,7 +120,7 @@ def test_unsupported_arguments_raise():
     with pytest.raises(ValueError):
         TemplateOptimizer(basis, BasicCost(), use_callback=True, deterministic=False)
     with pytest.raises(NotImplementedError):
-        TemplateOptimizer(basis, BasicCost(), override_method="Nelder-Mead")
+        TemplateOptimizer(basis, BasicCost(), override_method="Powell")  # (round 4: "Nelder-Mead" runs, tests/test_gpu_round4.py)
     with pytest.raises(NotImplementedError):
         CircuitTemplate(base_gates=[RiSwapGate(0.5)], use_polytopes=True, preseed=True)  # no silent no-op
 

@@ -262,3 +262,35 @@ def test_override_method_nelder_mead_runs_scipys_simplex_on_the_device_objective
     TemplateOptimizer(basis, BasicCost(), override_method="BFGS")
     with pytest.raises(NotImplementedError):
         TemplateOptimizer(basis, BasicCost(), override_method="Powell")
+
+
+@pytest.mark.parametrize("basis,R", [("sqiswap", 16), ("cx", 5), ("b", 40)])
+def test_one_wavefront_per_target_span_loop_equals_the_staged_launches(basis, R):
+    """Small batches run the whole span loop of a target in ONE wavefront (span_wave_kernel: one launch, no stage barrier, the winner
+    reduced as restarts finish); SLAM_FLAG_STAGED forces one optimizer + one bookkeeping launch per span.  Same items, same seeds, same
+    quasi-Newton loop: losses, parameters, cycles and the per-span running best are equal bit for bit -- also with more restarts than
+    quads (R = 40: wave-local refill) and fewer (R = 5) -- and the wave path is ONE kernel launch."""
+    N = 300
+    gate = {"sqiswap": G.RiSwapGate(0.5), "cx": G.CXGate(), "b": G.BerkeleyGate()}[basis].to_matrix()
+    seqs = [[0], [0, 0], [0, 0, 0]]
+    flags = _ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED
+    with _ffi.Context(0) as ctx:
+        ctx.sample_haar(2024, 1000)
+        ctx.set_gates(gate[None])
+        out = {}
+        for name, fl in (("wave", flags), ("staged", flags | _ffi.FLAG_STAGED)):
+            prm = _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=12, flags=fl)
+            ctx.reset_stats()
+            res = ctx.decompose_range(200, N, 1, 3, seqs, prm, 1e-10)
+            out[name] = res + (ctx.fetch_span_losses(200, N), ctx.stats())
+        (l0, x0, c0, s0, st0), (l1, x1, c1, s1, st1) = out["wave"], out["staged"]
+        assert np.array_equal(l0, l1) and np.array_equal(c0, c1) and np.array_equal(x0, x1)
+        assert np.array_equal(np.isnan(s0), np.isnan(s1)) and np.array_equal(np.nan_to_num(s0), np.nan_to_num(s1))
+        assert st0["kernel_launches"] == 1 and st1["kernel_launches"] == (2 if basis == "b" else 3)  # (B reaches everything in two)
+        assert st0["items"] == st1["items"] and st0["evals"][1] == st1["evals"][1]  # (k = 1: nothing is pre-empted)
+        assert np.all(l0 < 1e-8)
+        # spans 2..3 only, and a batch too big for the wave path (falls back by itself)
+        prm = _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=12, flags=flags)
+        a = ctx.decompose_range(0, 64, 2, 3, seqs[1:], prm, 1e-10)
+        b = ctx.decompose_range(0, 64, 2, 3, seqs[1:], _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=12, flags=flags | _ffi.FLAG_STAGED), 1e-10)
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
