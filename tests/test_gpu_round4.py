@@ -294,3 +294,32 @@ def test_one_wavefront_per_target_span_loop_equals_the_staged_launches(basis, R)
         a = ctx.decompose_range(0, 64, 2, 3, seqs[1:], prm, 1e-10)
         b = ctx.decompose_range(0, 64, 2, 3, seqs[1:], _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=12, flags=flags | _ffi.FLAG_STAGED), 1e-10)
         assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+def test_wave_loop_edge_cases_square_cost_dense_gate_single_target():
+    """The one-wavefront-per-target span loop on the corners: ONE target with ONE restart, spans 3..3 only, SquareCost, a dense
+    (unstructured) basis gate, a mixed-class sequence (falls back to the per-span launches by itself) -- each equal to the staged path."""
+    rng = np.random.default_rng(5)
+    q, _ = np.linalg.qr(rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4)))  # a dense 4x4 unitary as basis gate
+    flags = _ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED
+    cases = [
+        ("one target, one restart", G.RiSwapGate(0.5).to_matrix()[None], 1, 1, 1, 3, [[0], [0, 0], [0, 0, 0]], _ffi.COST_BASIC),
+        ("span 3 only", G.CXGate().to_matrix()[None], 40, 6, 3, 3, [[0, 0, 0]], _ffi.COST_BASIC),
+        ("SquareCost", G.RiSwapGate(0.5).to_matrix()[None], 50, 7, 1, 3, [[0], [0, 0], [0, 0, 0]], _ffi.COST_SQUARE),
+        ("dense gate", q[None], 30, 4, 1, 2, [[0], [0, 0]], _ffi.COST_BASIC),
+        ("mixed classes", np.stack([G.RiSwapGate(1.0).to_matrix(), G.BerkeleyGate().to_matrix()]), 60, 8, 1, 3, [[0], [0, 1], [0, 1, 0]], _ffi.COST_BASIC),
+    ]
+    with _ffi.Context(0) as ctx:
+        ctx.sample_haar(11, 64)
+        for name, table, N, R, k0, k1, seqs, cost in cases:
+            ctx.set_gates(table)
+            ctx.set_cost(cost)
+            res = []
+            for extra in (0, _ffi.FLAG_STAGED):
+                prm = _ffi.OptParams(restarts=R, maxiter=300, gtol=1e-9, stop_loss=1e-13, seed=2, flags=flags | extra)
+                ctx.reset_stats()
+                res.append(ctx.decompose_range(3, N, k0, k1, seqs, prm, 1e-10) + (ctx.stats()["kernel_launches"],))
+            (l0, x0, c0, n0), (l1, x1, c1, n1) = res
+            assert np.array_equal(l0, l1) and np.array_equal(x0, x1) and np.array_equal(c0, c1), name
+            assert n0 == (1 if name != "mixed classes" else n1), (name, n0, n1)
+        ctx.set_cost(_ffi.COST_BASIC)
