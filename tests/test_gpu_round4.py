@@ -309,9 +309,9 @@ def test_wave_loop_edge_cases_square_cost_dense_gate_single_target():
         ("dense gate", q[None], 30, 4, 1, 2, [[0], [0, 0]], _ffi.COST_BASIC),
         ("mixed classes", np.stack([G.RiSwapGate(1.0).to_matrix(), G.BerkeleyGate().to_matrix()]), 60, 8, 1, 3, [[0], [0, 1], [0, 1, 0]], _ffi.COST_BASIC),
     ]
-    with _ffi.Context(0) as ctx:
-        ctx.sample_haar(11, 64)
-        for name, table, N, R, k0, k1, seqs, cost in cases:
+    for name, table, N, R, k0, k1, seqs, cost in cases:
+        with _ffi.Context(0) as ctx:  # (a context's resident results have ONE row width: a fresh one per template size)
+            ctx.sample_haar(11, 64)
             ctx.set_gates(table)
             ctx.set_cost(cost)
             res = []
@@ -322,4 +322,3 @@ def test_wave_loop_edge_cases_square_cost_dense_gate_single_target():
             (l0, x0, c0, n0), (l1, x1, c1, n1) = res
             assert np.array_equal(l0, l1) and np.array_equal(x0, x1) and np.array_equal(c0, c1), name
             assert n0 == (1 if name != "mixed classes" else n1), (name, n0, n1)
-        ctx.set_cost(_ffi.COST_BASIC)

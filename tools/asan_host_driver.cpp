@@ -52,6 +52,9 @@ int main() {
     EXPECT(slam_decompose_range(nullptr, 0, 1, 1, 3, i32, &prm, 1e-10) == SLAM_ERR_INVALID);
     EXPECT(slam_decompose_range_fetch(nullptr, 0, 1, 1, 3, i32, &prm, 1e-10, d, d, i32) == SLAM_ERR_INVALID);
     EXPECT(slam_decompose_list(nullptr, i32, 1, 1, 3, 3, i32, &prm, 1e-10) == SLAM_ERR_INVALID);
+    EXPECT(slam_decompose_multi(nullptr, 0, 0, 1, 1, 3, i32, &prm, 1e-10) == SLAM_ERR_INVALID);
+    { slam_ctx* none[2] = {nullptr, nullptr}; EXPECT(slam_decompose_multi(none, 2, 0, 1, 1, 3, i32, &prm, 1e-10) == SLAM_ERR_INVALID); }
+    EXPECT(slam_abi_version() == SLAM_ABI_VERSION);
     EXPECT(slam_fetch_results(nullptr, 3, d, d, i32) == SLAM_ERR_INVALID);
     EXPECT(slam_fetch_results_range(nullptr, 3, 0, 1, d, d, i32) == SLAM_ERR_INVALID);
     EXPECT(slam_fetch_span_losses(nullptr, 0, 1, d) == SLAM_ERR_INVALID);
