@@ -826,6 +826,8 @@ __global__ void __launch_bounds__(kWave, 1) span_wave_kernel(WaveLoopArgs a) {
     const int t = a.first + i;
     double best_loss = INFINITY;
     int best_cycles = -1;
+    // "span not run" for every span first (what init_results_kernel does for the per-span launches); the stages overwrite theirs
+    if (lane < kSpanLossStride) a.span_loss[(int64_t)t * kSpanLossStride + lane] = NAN;
     if (a.k_min <= 1 && a.k_max >= 1) wave_stage<1, GC>(a, t, lds, best_loss, best_cycles);
     if (a.k_min <= 2 && a.k_max >= 2 && !(best_loss < a.threshold)) wave_stage<2, GC>(a, t, lds, best_loss, best_cycles);
     if (a.k_min <= 3 && a.k_max >= 3 && !(best_loss < a.threshold)) wave_stage<3, GC>(a, t, lds, best_loss, best_cycles);

@@ -276,9 +276,14 @@ def test_one_wavefront_per_target_span_loop_equals_the_staged_launches(basis, R)
     flags = _ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED
     with _ffi.Context(0) as ctx:
         ctx.sample_haar(2024, 1000)
-        ctx.set_gates(gate[None])
         out = {}
         for name, fl in (("wave", flags), ("staged", flags | _ffi.FLAG_STAGED)):
+            # (first another basis on the same window, so that the resident records hold an earlier call's values: the spans a call
+            # does not run must read "not run" afterwards on either path)
+            other = G.CXGate().to_matrix() if basis != "cx" else G.BerkeleyGate().to_matrix()
+            ctx.set_gates(other[None])
+            ctx.decompose_range(200, N, 1, 3, seqs, _ffi.OptParams(restarts=3, maxiter=200, seed=1, flags=fl), 1e-10, fetch=False)
+            ctx.set_gates(gate[None])
             prm = _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=12, flags=fl)
             ctx.reset_stats()
             res = ctx.decompose_range(200, N, 1, 3, seqs, prm, 1e-10)
