@@ -484,7 +484,7 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
 
 
 # ------------------------------------------------------------------------------------------------
-def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool):
+def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool, group_arg: int = 0):
     """Run `warmup` untimed + `steps` timed steps of one workload; returns the dict of measurements."""
     from slam_decomposition_amd import _ffi
 
@@ -514,7 +514,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     # the ordered early exit every step's results are bit for bit those of its own call (tests/test_gpu_round2.py).
     group = 1
     if (small or (main and args.group)) and not (gname == "cgsweep") and not (main and args.span_rules):
-        group = args.group if (main and args.group) else 20  # measured (320 steps, 4 streams): 10 -> 0.40, 16 -> 0.44, 20 -> 0.445, 32 -> 0.44 of peak
+        group = args.group if (main and args.group) else (group_arg or 20)  # measured (320 steps, 4 streams): 10 -> 0.40, 16 -> 0.44, 20 -> 0.445, 32 -> 0.44 of peak
     group = max(1, min(group, steps))
     # (the basis sweep cannot group its steps -- every step has its own gate -- so it keeps more of them in flight; measured on
     # MI355X, 160 steps: 4 in flight 1.42e6 decompositions/s / 0.289 of peak, 8: 1.68e6 / 0.338, 16: 1.82e6 / 0.363)
@@ -960,6 +960,13 @@ def main():
             "solved_fraction": s2["solved_all"] / (world * 320 * s2["n_per_step"]),
             "roofline_frac": fl2 / s2["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
         }}
+        # the same batches ONE per library call, one call in flight: the latency of a lone small batch (round 4: the whole span loop of
+        # a target in one wavefront, one launch -- span_wave_kernel)
+        s3 = run_workload(args, "cfg2", rank, world, local_rank, comm, 40, 8, 1, main=False, group_arg=1)
+        fl3 = sum(s3["st"]["evals"][k] * f_eval(k) for k in (1, 2, 3))
+        secondary["cfg2"]["one_batch_per_call"] = {"value": s3["solved_all"] / s3["elapsed"], "ms_per_step": 1e3 * s3["elapsed"] / 40,
+                                                   "roofline_frac": fl3 / s3["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                                   "kernel_launches_per_step": s3["st"]["kernel_launches"] / 40}
         if rank == 0 and not os.environ.get("SLAM_BENCH_TEST_STUB"):
             secondary["v2"] = run_v2(rank, local_rank)
             secondary["api"] = run_api(local_rank)
