@@ -62,8 +62,9 @@ extern "C" {
                                    reproducible for a fixed seed); without it the first restart to FINISH wins, which
                                    runs fewer evaluations but depends on timing. */
 #define SLAM_FLAG_STAGED 4u     /* span loops (slam_decompose*): always one optimizer launch + one bookkeeping launch per span.
-                                   Without it a SMALL batch (at most one target per SIMD, spans <= 3, ordered early exit, one
-                                   gate structure class) runs through the one-wavefront-per-target kernel: a single launch in
+                                   Without it a SMALL batch (at most one target per SIMD, at most 16 restarts -- or up to 64
+                                   when targets x restarts fill the chip --, spans <= 3, ordered early exit, one gate structure
+                                   class) runs through the one-wavefront-per-target kernel: a single launch in
                                    which every target goes from span to span on its own -- same items, same seeds, same
                                    results bit for bit, no stage barrier (round 4). */
 

@@ -618,6 +618,10 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
     if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED)) return SLAM_OK;
     if (k_max > 3 || c->trace_cap > 0) return SLAM_OK;
     if (count > (int64_t)kWaveLoopTargetsPerSimd * 4 * c->compute_units) return SLAM_OK;
+    // a wavefront runs its target's restarts 16 at a time: with many restarts and few targets the per-span launches, which spread the
+    // items over the whole chip, are faster (measured, CNOT, profiles/r4_wave_probe.txt: R = 32: 1024 targets 1.34 vs 1.63 ms, 16
+    // targets 1.00 vs 0.81; R = 64: 1024 targets 2.01 vs 2.41, 256 targets 1.96 vs 1.44; R = 128: 1024 targets 3.52 vs 3.25)
+    if (prm->restarts > 16 && !(prm->restarts <= 64 && count * (int64_t)prm->restarts >= 32768)) return SLAM_OK;
     int gc = -1;
     {
         const int32_t* gs = gate_seqs;

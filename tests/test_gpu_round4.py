@@ -270,12 +270,12 @@ def test_one_wavefront_per_target_span_loop_equals_the_staged_launches(basis, R)
     reduced as restarts finish); SLAM_FLAG_STAGED forces one optimizer + one bookkeeping launch per span.  Same items, same seeds, same
     quasi-Newton loop: losses, parameters, cycles and the per-span running best are equal bit for bit -- also with more restarts than
     quads (R = 40: wave-local refill) and fewer (R = 5) -- and the wave path is ONE kernel launch."""
-    N = 300
+    N = 900 if R > 16 else 300  # (more than 16 restarts: the wave path is taken only when targets x restarts fill the chip)
     gate = {"sqiswap": G.RiSwapGate(0.5), "cx": G.CXGate(), "b": G.BerkeleyGate()}[basis].to_matrix()
     seqs = [[0], [0, 0], [0, 0, 0]]
     flags = _ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED
     with _ffi.Context(0) as ctx:
-        ctx.sample_haar(2024, 1000)
+        ctx.sample_haar(2024, 1200)
         out = {}
         for name, fl in (("wave", flags), ("staged", flags | _ffi.FLAG_STAGED)):
             # (first another basis on the same window, so that the resident records hold an earlier call's values: the spans a call
