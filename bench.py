@@ -350,14 +350,16 @@ def make_comm(rank: int, world: int, local_rank: int):
     return comm
 
 
-def run_v2(rank: int, local_rank: int, steps: int = 64, warmup: int = 8, n_targets: int = 4096, restarts: int = 16, n_streams: int = 4, group: int = 8,
+def run_v2(rank: int, local_rank: int, steps: int = 128, warmup: int = 16, n_targets: int = 4096, restarts: int = 16, n_streams: int = 4, group: int = 16,
            base_gate=None, gate_desc: str = "RiSwapGate"):
     """secondary.v2: CircuitTemplateV2(base_gates=[RiSwapGate]) -- every gate instance with its own free alpha -- SquareCost,
     spans 1..3, `n_targets` Haar targets x `restarts` restarts per step.  The span loop is the one TemplateOptimizer runs for a
     V2 template (optimizer.py:_run_batch_v2 -> slam_v2_decompose_range): enqueued on the device as one chain of kernels per
     step.  Like the configs[1]-sized steps of the fixed-gate path, `group` consecutive steps (windows of one resident array) go
     to the library as ONE call -- one device-side work queue per span over all their items -- on `n_streams` host threads /
-    contexts / streams (measured, MI355X: one step per call 2.5e6 decompositions/s / 0.19 of peak, 8 per call 6.4e6 / 0.31)."""
+    contexts / streams (measured, MI355X: one step per call 2.5e6 decompositions/s / 0.19 of peak, 8 per call 6.4e6 / 0.31; round 4,
+    tools/r4_v2_sweep.sh: 64 steps at 8 per call x 4 in flight 6.2e6 / 0.31, 128 steps at 16 x 4 7.6e6 / 0.36 (the default now), 8 x 8
+    6.8e6 / 0.33, 32 x 2 7.3e6 / 0.34, 256 steps at 32 x 4 7.7e6 / 0.345)."""
     from slam_decomposition_amd import _ffi
     from slam_decomposition_amd.basisv2 import CircuitTemplateV2
     from slam_decomposition_amd.gates import RiSwapGate
@@ -924,7 +926,8 @@ def main():
         mod.install()
 
     if args.v2_only:
-        print(json.dumps(run_v2(0, 0)), flush=True)
+        kw = {k: int(os.environ[e]) for k, e in (("steps", "SLAM_V2_STEPS"), ("group", "SLAM_V2_GROUP"), ("n_streams", "SLAM_V2_STREAMS"), ("n_targets", "SLAM_V2_TARGETS")) if e in os.environ}
+        print(json.dumps(run_v2(0, 0, **kw)), flush=True)  # (dev: SLAM_V2_STEPS / _GROUP / _STREAMS / _TARGETS override the defaults)
         return
     if args.api_only:
         for sh in (0, 2, 4):  # 0: the default (auto_shards = 4 same-device shards for big batches)
