@@ -530,7 +530,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     mq = sweep and not (main and args.span_rules) and not (main and args.no_multi)
     if mq:
         group = min(args.group if (main and args.group) else 8, SWEEP_BASES_PER_GPU, steps)
-    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else 5))
+    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else (8 if n_per_step * restarts < (1 << 20) else 5)))
     n_streams = max(1, min(n_streams, (steps + group - 1) // group))
     ctxs = [_ffi.Context(device) for _ in range(n_streams * (group if mq else 1))]
     dev_name, cus, _ = ctxs[0].device_info()
@@ -886,7 +886,8 @@ def main():
     ap.add_argument("--restarts", type=int, default=None)
     ap.add_argument("--streams", type=int, default=None,
                     help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 5 otherwise "
-                         "(measured on cfg3: 3 -> 2.95e6, 4 -> 3.0e6, 5 -> 3.19e6, 6 -> 3.20e6 decompositions/s)")
+                         "(measured on cfg3: 3 -> 2.95e6, 4 -> 3.0e6, 5 -> 3.19e6, 6 -> 3.20e6 decompositions/s; batches below 2^20 items per span, "
+                         "e.g. the cfg4 shard: 8 -- round 4, tools/r4_cfg4_sweep.sh: 5 -> 1.03e7, 8 -> 1.16e7)")
     ap.add_argument("--group", type=int, default=0,
                     help="small batches: consecutive steps handed to the library as one call = one device-side work queue per span "
                          "(default 20 for cfg2-sized batches, 1 otherwise)")
