@@ -530,7 +530,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     mq = sweep and not (main and args.span_rules) and not (main and args.no_multi)
     if mq:
         group = min(args.group if (main and args.group) else 8, SWEEP_BASES_PER_GPU, steps)
-    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else (8 if n_per_step * restarts < (1 << 20) else 5)))
+    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else (8 if (n_per_step * restarts < (1 << 20) or (main and args.span_rules)) else 5)))
     n_streams = max(1, min(n_streams, (steps + group - 1) // group))
     ctxs = [_ffi.Context(device) for _ in range(n_streams * (group if mq else 1))]
     dev_name, cus, _ = ctxs[0].device_info()
