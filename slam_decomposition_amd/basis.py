@@ -201,3 +201,189 @@ class CircuitTemplate(VariationalTemplate):
     def to_qiskit_order(cls, Xk: Sequence[float]) -> np.ndarray:
         n = len(Xk)
         return np.array([Xk[i] for i in cls.qiskit_parameter_order(n)])
+
+
+class CircuitCoverage:
+    """One entry of a coverage set: the circuits made of a given multiset of basis gates with free local gates in between -- what
+    a ``monodromy.coverage.CircuitPolytope`` is to the reference (``operations`` = gate keys, ``cost``; polytope_wrap.py:78-90,
+    basis.py:336-359) -- with the polytope replaced by ``span_rules.multiset_coverage``: the exact region where it is known in
+    closed form, otherwise a sound outer bound that only an optimisation on the device turns into a decision."""
+
+    def __init__(self, operations, cost, gate_indices, gate_coords):
+        self.operations = list(operations)
+        self.cost = cost
+        self.gate_indices = [int(i) for i in gate_indices]
+        self.gate_coords = np.asarray(gate_coords, dtype=np.float64).reshape(-1, 3)
+
+    def __len__(self):
+        return len(self.operations)
+
+    def __repr__(self):
+        return f"CircuitCoverage(operations={self.operations}, cost={self.cost})"
+
+    def inside(self, target_coords, slack: float = 8e-8):
+        """``(mask, exact)`` for Weyl coordinates [N, 3] (units of pi): see ``span_rules.multiset_coverage``."""
+        return span_rules.multiset_coverage(np.asarray(target_coords, dtype=np.float64).reshape(-1, 3), self.gate_coords, slack)
+
+    @property
+    def exact(self) -> bool:
+        return bool(self.inside(np.array([[0.3, 0.2, 0.1]]))[1])
+
+    def has_element(self, target_coords) -> bool:
+        """``CircuitPolytope.has_element`` for one target -- only where the region is exact."""
+        mask, exact = self.inside(target_coords)
+        if not exact:
+            raise NotImplementedError(f"no closed-form coverage region for {self.operations}: membership is decided by optimising "
+                                      "(MixedOrderBasisCircuitTemplate.get_spanning_range / TemplateOptimizer do)")
+        return bool(mask[0])
+
+
+class MixedOrderBasisCircuitTemplate(CircuitTemplate):
+    """Templates over a SET of basis gates in which every target gets the cheapest circuit that reaches it (reference:
+    src/slam/basis.py:213-359 with ``monodromy_range_from_target``, src/slam/utils/polytopes/polytope_wrap.py:39-94: the coverage set
+    sorted by cost, the first entry containing the target is bound with ``set_polytope`` and ``build`` lays out ITS gates).
+
+    The reference takes the coverage set from monodromy (``gate_set_to_coverage`` or a pickled file); neither exists here.  The
+    coverage set is every multiset of the basis gates up to ``maximum_span_guess`` gates, sorted by cost (sum of ``gate.cost()``,
+    polytope_wrap.py:175-176); an entry "contains" a target where ``span_rules`` knows its region exactly, and otherwise -- inside
+    the strength bound -- iff the optimiser reaches the target with it: the template-size lookup and the optimisation are then the
+    same device computation (``TemplateOptimizer`` runs the entries in cost order over the targets still open).
+
+    Kept from the reference: the constructor checks and their errors, ``gc < gg`` ordering and unit duration of the gates,
+    ``gate_hash`` / ``coverage`` / ``scores`` / ``set_polytope`` / ``unit_cost`` / ``build(n, scaled_gate)``.  Deviation:
+    ``get_spanning_range`` returns ``range(k, k + 1)`` with k the number of gates of the bound entry; the reference returns the
+    entry's INDEX in the sorted list (polytope_wrap.py:94), which equals k for one basis gate and trips ``build``'s
+    ``assert n_repetitions == len(gate_list)`` (basis.py:358) for several."""
+
+    mixed_order = True
+
+    def __init__(self, base_gates, chatty_build=True, cost_1q=0, bare_cost=True, coverage_saved_memory=True,
+                 use_smush_polytope=False, maximum_span_guess=3, device=0, **kwargs):
+        import itertools
+
+        from .gates import ConversionGainGate
+        from .weyl import c1c2c3
+
+        self.homogenous = len(base_gates) == 1
+        if cost_1q != 0 or bare_cost is False:
+            raise ValueError("just don't do this lol")  # basis.py:235-240
+        if not all(isinstance(gate, ConversionGainGate) for gate in base_gates):
+            raise ValueError("all base gates must be ConversionGainGate")  # basis.py:242-243
+        if use_smush_polytope:
+            raise ValueError("Smush Polytope not in memory, need to compute using parallel_drive_volume.py")  # basis.py:291-294
+        # gc < gg so that both orderings share a coverage set, durations normalised to 1 (basis.py:245-260)
+        new_base_gates = []
+        for gate in base_gates:
+            if not gate.params[2] < gate.params[3]:
+                p = list(gate.params)
+                p[2], p[3] = p[3], p[2]
+                gate = ConversionGainGate(*p)
+            else:
+                gate = ConversionGainGate(*gate.params)
+            gate.normalize_duration(1)
+            new_base_gates.append(gate)
+        super().__init__(n_qubits=2, base_gates=new_base_gates, edge_params=[[(0, 1)]], no_exterior_1q=False, use_polytopes=True,
+                         maximum_span_guess=maximum_span_guess, preseed=False, device=device)
+        self.gate_hash = {}
+        for gate in self.base_gates:
+            if str(gate) in self.gate_hash:
+                raise ValueError("need unique gate strings for hashing to work")  # polytope_wrap.py:148-149
+            self.gate_hash[str(gate)] = gate
+        keys = list(self.gate_hash)
+        coords = [c1c2c3(m) for m in self.gate_matrices]
+        costs = [float(g.cost()) for g in self.base_gates]
+        entries = []
+        for k in range(1, int(maximum_span_guess) + 1):
+            for combo in itertools.combinations_with_replacement(range(len(keys)), k):
+                entries.append(CircuitCoverage([keys[i] for i in combo], sum(costs[i] for i in combo), combo, [coords[i] for i in combo]))
+        entries.sort(key=lambda e: (round(e.cost, 12), len(e), e.gate_indices))
+        self.coverage = entries
+        self.scores = None
+        self.circuit_polytope = None
+        self.cost = None
+        self._span_exact = all(e.exact for e in entries)
+
+    # ---- the bound entry ------------------------------------------------------------------------
+    def set_polytope(self, circuit_polytope):
+        self.circuit_polytope = circuit_polytope
+        self.cost = circuit_polytope.cost
+
+    def unit_cost(self, n_):
+        return self.cost
+
+    def _reset(self):
+        self.circuit_polytope = None
+        super()._reset()
+
+    def build(self, n_repetitions, scaled_gate=None):
+        """basis.py:336-359: the template of the bound coverage entry (its gates, in its order)."""
+        assert self.circuit_polytope is not None
+        entry = self.circuit_polytope
+        if scaled_gate is not None:
+            if not self.homogenous:
+                raise ValueError("Can't use this hacky substitute method for mixed basis sets")
+            self.base_gates = [scaled_gate]
+            self.gate_matrices = np.stack([gate_matrix(scaled_gate)])
+            seq = [0] * int(n_repetitions)
+        else:
+            seq = list(entry.gate_indices)
+        assert n_repetitions == len(seq)
+        if n_repetitions <= 0:
+            raise ValueError()
+        self.cycles = int(n_repetitions)
+        self._sequence = seq
+        self.circuit_polytope = entry
+
+    def gate_sequence(self, k=None) -> List[int]:
+        if self.circuit_polytope is None:
+            raise ValueError("set_polytope() a coverage entry first (get_spanning_range does)")
+        seq = getattr(self, "_sequence", None) or list(self.circuit_polytope.gate_indices)
+        if k is not None and k != len(seq):
+            raise ValueError(f"the bound coverage entry has {len(seq)} gates, not {k}")
+        return list(seq)
+
+    # ---- lookup ---------------------------------------------------------------------------------
+    def candidate_entries(self, target_coords):
+        """Per coverage entry, in cost order: ``(entry, mask[N], exact)`` -- the targets the entry can contain."""
+        c = np.asarray(target_coords, dtype=np.float64).reshape(-1, 3)
+        return [(e,) + tuple(e.inside(c)) for e in self.coverage]
+
+    def minimal_spans(self, target_coords) -> np.ndarray:
+        """Number of gates of the cheapest entry that can contain each target (exact where every entry is, see
+        ``span_rules_exact``); 0 for local targets."""
+        c = np.asarray(target_coords, dtype=np.float64).reshape(-1, 3)
+        k = np.full(len(c), -1, dtype=np.int64)
+        for e, mask, _ in self.candidate_entries(c):
+            k = np.where((k < 0) & mask, len(e), k)
+        k = np.where(np.max(np.abs(span_rules._fold(c)), axis=1) < span_rules._TOL, 0, k)
+        if np.any(k < 0):
+            raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
+        return k
+
+    def get_spanning_range(self, target_u):
+        """``monodromy_range_from_target`` (polytope_wrap.py:39-94): binds the cheapest coverage entry that contains the target and
+        returns the one-element range of its size.  Entries without a closed-form region are tested by optimising on the device."""
+        from .weyl import c1c2c3
+
+        coords = np.array([c1c2c3(target_u)])
+        if np.max(np.abs(coords)) < span_rules._TOL:
+            return range(0, 1)  # polytope_wrap.py:53-54
+        for e, mask, exact in self.candidate_entries(coords):
+            if mask[0] and (exact or self._device_reaches(e, target_u)):
+                self.set_polytope(e)
+                self._sequence = None
+                return range(len(e), len(e) + 1)
+        raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
+
+    def _device_reaches(self, entry, target_u, restarts: int = 16, threshold: float = 1e-10) -> bool:
+        from . import _ffi
+
+        ctx = runtime.get_context(self.device)
+        ctx.set_targets(np.asarray(target_u, dtype=np.complex128).reshape(1, 4, 4))
+        ctx.set_gates(self.gate_matrices)
+        ctx.set_cost(_ffi.COST_BASIC)
+        k = len(entry)
+        prm = _ffi.OptParams(restarts=restarts, stop_loss=0.1 * threshold, seed=20260004, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+        ctx.decompose_list(np.array([0]), k, k, [entry.gate_indices], prm, threshold, k_layout=k)
+        loss, _, _ = ctx.fetch_results_range(k, 0, 1)
+        return bool(loss[0] < threshold)

@@ -175,6 +175,15 @@ class ConversionGainGate(Gate2Q):
         g1, g2, t = self.params[2], self.params[3], self.params[4]
         return f"2QGate({g1:.8f}, {g2:.8f}, {t:.8f})"
 
+    def normalize_duration(self, new_duration):
+        """custom_gates.py:192-205: rescale the drive strengths so that the gate lasts ``new_duration`` (same unitary, same cost)."""
+        t = self.params[-1]
+        self.params[2] = self.params[2] * t / new_duration
+        self.params[3] = self.params[3] * t / new_duration
+        self.params[-1] = new_duration
+        self.duration = self.cost()
+        self.name = str(self)
+
     def _matrix(self):
         p1, p2, g1, g2, t = (float(v) for v in self.params)
         return conversion_gain_matrix(p1, p2, g1, g2, t)

@@ -98,6 +98,8 @@ class TemplateOptimizer:
         elif override_method not in (None, "BFGS") and not (self._v2 and override_method in ("L-BFGS-B", "SLSQP")):
             raise NotImplementedError(f"override_method={override_method!r}: implemented are BFGS (device), Nelder-Mead (fixed-gate "
                                       "templates without callback; host-driven, device objective), L-BFGS-B / SLSQP for V2 templates")
+        if getattr(basis, "mixed_order", False) and (use_callback or self._host_method is not None):
+            raise NotImplementedError("MixedOrderBasisCircuitTemplate: use_callback / override_method are not implemented")
         if self.training_restarts <= 0:
             raise ValueError("training_restarts must be positive")
         self.device = basis.device if device is None else device
@@ -325,6 +327,51 @@ class TemplateOptimizer:
             best_loss[better], best_x[better], best_cycles[better] = loss[better], x[better], k
             self._span_losses[todo, k - 1] = best_loss[todo]
         self._set_stats([ctx.stats()])
+        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
+        return best_loss, xs, best_cycles
+
+    def _run_batch_mixed_order(self, targets: np.ndarray, coords: np.ndarray):
+        """``MixedOrderBasisCircuitTemplate``: the coverage entries (gate multisets) are visited in cost order; an entry is
+        optimised over the targets still open that it can contain (polytope_wrap.py:78-90 with the membership test replaced by
+        ``CircuitCoverage.inside`` -- and, where that is only an outer bound, by the optimisation itself).  One
+        ``slam_decompose_list`` per entry; the batch stays resident.  ``self.circuit_polytopes[t]`` is the entry target t ended
+        with (what the reference leaves bound in ``basis.circuit_polytope``)."""
+        n = len(targets)
+        local = np.max(np.abs(coords), axis=1) < 2e-8
+        if np.any(local):
+            raise ValueError()  # range(0, 1) -> CircuitTemplate.build(0), polytope_wrap.py:53-54, basis.py:127-128
+        self.basis.minimal_spans(coords)  # raises for a target no entry can contain (polytope_wrap.py:91-93)
+        entries = self.basis.candidate_entries(coords)
+        k_top = max(len(e) for e, _, _ in entries)
+        if k_top > _ffi.MAX_SPAN_MINIMIZE:
+            raise NotImplementedError(f"template spans up to {_ffi.MAX_SPAN_MINIMIZE} are implemented on the HIP path (got {k_top})")
+        prm = self._opt_params()
+        ctx = runtime.get_context(self.devices[0])
+        ctx.set_targets(targets)
+        ctx.set_gates(self.basis.gate_matrices)
+        ctx.set_cost(self._cost_kind)
+        ctx.reset_stats()
+        best_loss = np.full(n, np.inf)
+        best_x = np.zeros((n, 6 * (k_top + 1)))
+        best_cycles = np.full(n, -1, dtype=np.int32)
+        best_entry = np.full(n, -1, dtype=np.int64)
+        self._span_losses = None
+        self._entries_tried = [[] for _ in range(n)]
+        for j, (e, mask, _) in enumerate(entries):
+            todo = np.nonzero(mask & ~(best_loss < self.success_threshold))[0]
+            if len(todo) == 0:
+                continue
+            k = len(e)
+            ctx.decompose_list(todo, k, k, [e.gate_indices], prm, self.success_threshold, k_layout=k_top)
+            loss, x, _ = ctx.fetch_results_range(k_top, 0, n)
+            better = np.zeros(n, bool)
+            better[todo] = (best_cycles[todo] < 0) | (loss[todo] < best_loss[todo])  # optimizer.py:281-284
+            best_loss[better], best_x[better], best_cycles[better], best_entry[better] = loss[better], x[better], k, j
+            if self._want_span_losses:  # (only the log lines read it)
+                for t in todo:
+                    self._entries_tried[t].append((j, float(best_loss[t])))
+        self._set_stats([ctx.stats()])
+        self.circuit_polytopes = [entries[j][0] for j in best_entry]
         xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
         return best_loss, xs, best_cycles
 
@@ -567,6 +614,15 @@ class TemplateOptimizer:
     def _log_span_loop(self, i: int, spans) -> None:
         """The per-span log lines of ``_run`` (optimizer.py:234,297,302) for target i, from the running best loss
         the device recorded after every span."""
+        if getattr(self.basis, "mixed_order", False):
+            for j, v in self._entries_tried[i]:
+                k = len(self.basis.coverage[j])
+                logging.info(f"Starting opt on template size {k}")
+                logging.info(f"Cycle (k ={k}), Best Loss={v}")
+                if v < self.success_threshold:
+                    logging.info(f"Break on cycle {k}")
+                    break
+            return
         sl = getattr(self, "_span_losses", None)
         if sl is None:
             return
@@ -618,6 +674,12 @@ class TemplateOptimizer:
         ctx.set_gates(self.basis.gate_matrices)
         if ctx.n_targets == 0:
             ctx.set_targets(np.eye(4, dtype=np.complex128)[None])
+        if getattr(self.basis, "mixed_order", False):
+            ids = np.array([id(e) for e in self.circuit_polytopes])
+            for v in np.unique(ids):
+                idx = np.nonzero(ids == v)[0]
+                found[idx] = ctx.eval_c1c2c3(self.circuit_polytopes[idx[0]].gate_indices, np.stack([best_xs[i] for i in idx]))
+            return found
         for k in np.unique(best_cycles):
             idx = np.nonzero(best_cycles == k)[0]
             X = np.stack([best_xs[i] for i in idx])
@@ -683,6 +745,9 @@ class TemplateOptimizer:
             else:
                 spans_of = [list(self.basis.get_spanning_range(stacked[0]))] * n
             best_loss, best_xs, best_cycles = self._run_batch_callback(stacked, spans_of)
+        elif getattr(self.basis, "mixed_order", False):
+            best_loss, best_xs, best_cycles = self._run_batch_mixed_order(stacked, coords_arr)
+            spans_of = [None] * n  # (the log lines come from _entries_tried)
         elif self.basis.use_polytopes:
             # get_spanning_range per target (optimizer.py:233 with basis.py:95-100): only the template size
             # the target needs.  Targets are grouped by that size; each group is one batch.
@@ -699,6 +764,8 @@ class TemplateOptimizer:
             best_loss, best_xs, best_cycles = self._run_batch(stacked, spanning_range)
         best_loss = np.asarray(best_loss, dtype=np.float64)
         best_cycles = np.asarray(best_cycles)
+        if getattr(self.basis, "mixed_order", False):
+            self.basis.set_polytope(self.circuit_polytopes[-1])
         self.basis.build(n_repetitions=int(best_cycles[-1]))  # the reference leaves the template at the last size
         padded = isinstance(best_xs, np.ndarray) and best_xs.ndim == 2  # [n, 6 (k_max + 1)] rows, cut at 6 (cycles + 1) on access
         if not log_on and not self.use_callback:

@@ -198,3 +198,37 @@ def sequence_minimal_span(target_coords, gate_coords_seq, k_max: int, slack: flo
     k = np.where(same, 1, k)
     k = np.where(local, 0, k)
     return k
+
+
+def multiset_coverage(target_coords, gate_coords_list, slack: float = 4 * _TOL):
+    """Coverage test for a circuit of the gates ``gate_coords_list`` (any order -- transposition and inversion map the Weyl
+    coordinates of a product onto those of the reordered one -- with free local gates in between): ``(inside, exact)``.
+    ``inside[t]`` False means target t is certainly NOT reachable; with ``exact`` True, ``inside`` is the coverage set itself (what
+    ``CircuitPolytope.has_element`` answers in the reference, polytope_wrap.py:78-90), otherwise it is a superset (the strength
+    bound of ``span_lower_bound``) and only an optimisation decides.  Local targets are reported outside (the reference handles
+    them before the lookup, polytope_wrap.py:53-54)."""
+    g = np.asarray(gate_coords_list, dtype=np.float64).reshape(-1, 3)
+    k = len(g)
+    if k < 1:
+        raise ValueError("a coverage entry needs at least one gate")
+    c = _fold(target_coords)
+    x, y, z = c[:, 0], c[:, 1], c[:, 2]
+    tol = _TOL + slack
+    local = np.max(np.abs(c), axis=1) < _TOL
+    if k == 1:
+        gf = np.abs(_fold(g[:1])[0])
+        return (np.max(np.abs(np.abs(c) - gf), axis=1) < _TOL) & ~local, True
+    classes = [next((f for f in _UNIVERSAL_IN_3 if _is(gi, FAMILIES[f])), None) for gi in g]
+    if k == 2:
+        region = two_gate_region(g[0], g[1])
+        if region is not None:
+            return region(x, y, z, tol) & ~local, True
+    else:
+        # everything is reachable when two of the gates are B (B L B is already the whole chamber), when all are one gate of a class
+        # three of which suffice, or for iSWAP / B mixtures (the brute-force loop solves every Haar target: tests/test_gpu_round4.py)
+        everything = classes.count("b") >= 2 or (None not in classes and (len(set(classes)) == 1 or set(classes) <= {"iswap", "b"}))
+        if everything:
+            return ~local, True
+    mt = strength(c)
+    avail = strength(g).sum(axis=0)
+    return np.all(mt <= avail + slack, axis=1) & ~local, False

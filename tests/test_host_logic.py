@@ -240,3 +240,62 @@ def test_fd_reference_fixture_is_what_the_oracle_computes():
                                      x0_fn=lambda kk, r: o.x0_philox(int(ref["opt_seed"]), idx, r, kk), analytic_jac=False)
     assert k == int(ref["sqiswap_cycles"][idx]) and abs(best - float(ref["sqiswap_loss"][idx])) < 1e-12
     assert np.max(np.abs(o.c1c2c3_raw(target) - ref["sqiswap_target_coords"][idx])) < 1e-12
+
+
+def test_mixed_order_template_constructor_and_coverage_set():
+    """MixedOrderBasisCircuitTemplate (basis.py:213-359): the constructor's checks and errors, gc < gg ordering, unit duration, the
+    coverage set sorted by cost, set_polytope / build / unit_cost -- no device needed."""
+    from slam_decomposition_amd.basis import CircuitCoverage, MixedOrderBasisCircuitTemplate
+    from slam_decomposition_amd.gates import ConversionGainGate, RiSwapGate
+
+    pi = np.pi
+    with pytest.raises(ValueError, match="just don't do this lol"):
+        MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 4, 0, 1)], cost_1q=0.1)
+    with pytest.raises(ValueError, match="just don't do this lol"):
+        MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 4, 0, 1)], bare_cost=False)
+    with pytest.raises(ValueError, match="all base gates must be ConversionGainGate"):
+        MixedOrderBasisCircuitTemplate([RiSwapGate(0.5)])
+    with pytest.raises(ValueError, match="Smush Polytope not in memory"):
+        MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 4, 0, 1)], use_smush_polytope=True)
+    with pytest.raises(ValueError, match="need unique gate strings"):
+        MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 4, 0, 1), ConversionGainGate(0, 0, 0, pi / 4, 1)])  # equal after gc < gg
+    # sqrt(iSWAP) given with t = 2 and half the strength, iSWAP: durations become 1, gc <= gg, costs 0.5 and 1
+    b = MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 8, 0, 2), ConversionGainGate(0, 0, pi / 2, 0, 1)])
+    assert not b.homogenous and b.use_polytopes and b.spanning_range is None and b.scores is None
+    for g in b.base_gates:
+        assert g.params[4] == 1 and g.params[2] <= g.params[3]
+    assert [round(g.cost(), 12) for g in b.base_gates] == [0.5, 1.0]
+    assert list(b.gate_hash) == [str(g) for g in b.base_gates]
+    costs = [e.cost for e in b.coverage]
+    assert costs == sorted(costs) and len(b.coverage) == 2 + 3 + 4
+    assert [tuple(e.gate_indices) for e in b.coverage[:5]] == [(0,), (1,), (0, 0), (0, 1), (0, 0, 0)]
+    assert all(isinstance(e, CircuitCoverage) and e.operations == [str(b.base_gates[i]) for i in e.gate_indices] for e in b.coverage)
+    # exact entries: single gates, equal pairs of the known classes, three equal gates; the mixed pair is an outer bound
+    ex = {tuple(e.gate_indices): e.exact for e in b.coverage}
+    assert ex[(0,)] and ex[(1,)] and ex[(0, 0)] and ex[(1, 1)] and ex[(0, 0, 0)] and ex[(1, 1, 1)] and not ex[(0, 1)]
+    assert not b.span_rules_exact
+    # membership: sqrt(iSWAP)'s own class in entry (0,), CNOT in (0, 0) [|z| <= x - y], SWAP in no two-gate entry
+    cnot, swap, sq = np.array([[0.5, 0, 0]]), np.array([[0.5, 0.5, 0.5]]), np.array([[0.25, 0.25, 0]])
+    assert b.coverage[0].has_element(sq) and not b.coverage[0].has_element(cnot)
+    assert b.coverage[2].has_element(cnot) and not b.coverage[2].has_element(swap)
+    with pytest.raises(NotImplementedError):
+        b.coverage[3].has_element(cnot)
+    # (SWAP sits exactly ON the strength bound of [sqrt(iSWAP), iSWAP] -- m1 = 1.5 = 0.5 + 1, m2 = 0.75 = 0.25 + 0.5 -- so the outer bound
+    # keeps it and the device decides: tests/test_gpu_round4.py)
+    assert b.coverage[3].inside(swap) == (np.array([True]), False)
+    assert list(b.minimal_spans(np.concatenate([sq, cnot, swap, np.zeros((1, 3))]))) == [1, 2, 2, 0]
+    # set_polytope / build / gate_sequence / unit_cost
+    with pytest.raises(AssertionError):
+        b.build(2)
+    b.set_polytope(b.coverage[3])
+    b.build(2)
+    assert b.cycles == 2 and b.gate_sequence() == [0, 1] and b.unit_cost(2) == 1.5 and b.n_params == 18
+    with pytest.raises(AssertionError):
+        b.build(3)
+    with pytest.raises(ValueError, match="hacky substitute"):
+        b.build(2, scaled_gate=ConversionGainGate(0, 0, 0, pi / 4, 1))
+    h = MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 4, 0, 1)])
+    assert h.homogenous and h.span_rules_exact and [len(e) for e in h.coverage] == [1, 2, 3]
+    h.set_polytope(h.coverage[1])
+    h.build(2, scaled_gate=ConversionGainGate(0, 0, 0, pi / 8, 1))
+    assert h.gate_sequence() == [0, 0] and abs(h.base_gates[0].params[3] - pi / 8) < 1e-15

@@ -1,0 +1,1 @@
+cd "$GRAFT_REPO_ROOT" && timeout -k 10 600 python3 -m pytest tests/test_gpu_round4.py -x -q -k "mixed_order" 2>&1 | tail -30
