@@ -59,8 +59,8 @@ class CircuitTemplate(VariationalTemplate):
         self.coverage = None
         self._span_exact = False
         if use_polytopes:
-            # the reference needs monodromy's precomputed coverage sets; here: analytic rules (span_rules.py) -- exact for
-            # one basis gate of a known class, otherwise a sound LOWER bound from which the span loop starts
+            # the reference needs monodromy's precomputed coverage sets; here: span_rules.py (closed forms for the CX, iSWAP,
+            # sqrt(iSWAP), B classes) and coverage.py (the monodromy inequalities themselves, any gate sequence) -- exact
             from .weyl import c1c2c3
 
             self._gate_coords_all = [c1c2c3(m) for m in self.gate_matrices]
@@ -73,8 +73,7 @@ class CircuitTemplate(VariationalTemplate):
                 except NotImplementedError:
                     pass
             if not self._span_exact:
-                # a sequence of different gates (or a gate outside the single-gate classes) whose one-, two- and three-gate
-                # coverage is known exactly (span_rules.sequence_minimal_span: e.g. [iSWAP, B])
+                # a sequence of different gates, or a gate outside the single-gate classes (span_rules.sequence_minimal_span)
                 seq = [self._gate_coords_all[i % len(self.base_gates)] for i in range(int(maximum_span_guess))]
                 if span_rules.sequence_is_exact(seq, int(maximum_span_guess)):
                     self._span_exact = self._span_sequence = True
@@ -118,8 +117,8 @@ class CircuitTemplate(VariationalTemplate):
 
     @property
     def span_rules_exact(self) -> bool:
-        """True: ``minimal_spans`` is the template size each target needs (one basis gate of a class with closed-form coverage
-        regions); False: a lower bound (mixed sequences, other gates) -- the span loop runs from it to ``maximum_span_guess``."""
+        """True: ``minimal_spans`` is the template size each target needs; False (templates longer than
+        ``span_rules.MAX_EXACT_SPAN`` only): a lower bound -- the span loop runs from it to ``maximum_span_guess``."""
         return self._span_exact
 
     def minimal_spans(self, target_coords) -> np.ndarray:
@@ -206,8 +205,7 @@ class CircuitTemplate(VariationalTemplate):
 class CircuitCoverage:
     """One entry of a coverage set: the circuits made of a given multiset of basis gates with free local gates in between -- what
     a ``monodromy.coverage.CircuitPolytope`` is to the reference (``operations`` = gate keys, ``cost``; polytope_wrap.py:78-90,
-    basis.py:336-359) -- with the polytope replaced by ``span_rules.multiset_coverage``: the exact region where it is known in
-    closed form, otherwise a sound outer bound that only an optimisation on the device turns into a decision."""
+    basis.py:336-359) -- with the polytope replaced by ``span_rules.multiset_coverage`` (14 half-spaces from ``coverage.region``)."""
 
     def __init__(self, operations, cost, gate_indices, gate_coords):
         self.operations = list(operations)
@@ -230,12 +228,8 @@ class CircuitCoverage:
         return bool(self.inside(np.array([[0.3, 0.2, 0.1]]))[1])
 
     def has_element(self, target_coords) -> bool:
-        """``CircuitPolytope.has_element`` for one target -- only where the region is exact."""
-        mask, exact = self.inside(target_coords)
-        if not exact:
-            raise NotImplementedError(f"no closed-form coverage region for {self.operations}: membership is decided by optimising "
-                                      "(MixedOrderBasisCircuitTemplate.get_spanning_range / TemplateOptimizer do)")
-        return bool(mask[0])
+        """``CircuitPolytope.has_element`` for one target."""
+        return bool(self.inside(target_coords)[0][0])
 
 
 class MixedOrderBasisCircuitTemplate(CircuitTemplate):
@@ -245,9 +239,9 @@ class MixedOrderBasisCircuitTemplate(CircuitTemplate):
 
     The reference takes the coverage set from monodromy (``gate_set_to_coverage`` or a pickled file); neither exists here.  The
     coverage set is every multiset of the basis gates up to ``maximum_span_guess`` gates, sorted by cost (sum of ``gate.cost()``,
-    polytope_wrap.py:175-176); an entry "contains" a target where ``span_rules`` knows its region exactly, and otherwise -- inside
-    the strength bound -- iff the optimiser reaches the target with it: the template-size lookup and the optimisation are then the
-    same device computation (``TemplateOptimizer`` runs the entries in cost order over the targets still open).
+    polytope_wrap.py:175-176), each with its exact region (``coverage.py``: the monodromy inequalities from first principles).
+    ``TemplateOptimizer`` runs the entries in cost order over the targets they contain; a target the optimiser misses in its entry
+    (too few restarts) stays open for the costlier entries that contain it too.
 
     Kept from the reference: the constructor checks and their errors, ``gc < gg`` ordering and unit duration of the gates,
     ``gate_hash`` / ``coverage`` / ``scores`` / ``set_polytope`` / ``unit_cost`` / ``build(n, scaled_gate)``.  Deviation:
@@ -362,28 +356,15 @@ class MixedOrderBasisCircuitTemplate(CircuitTemplate):
 
     def get_spanning_range(self, target_u):
         """``monodromy_range_from_target`` (polytope_wrap.py:39-94): binds the cheapest coverage entry that contains the target and
-        returns the one-element range of its size.  Entries without a closed-form region are tested by optimising on the device."""
+        returns the one-element range of its size."""
         from .weyl import c1c2c3
 
         coords = np.array([c1c2c3(target_u)])
         if np.max(np.abs(coords)) < span_rules._TOL:
             return range(0, 1)  # polytope_wrap.py:53-54
-        for e, mask, exact in self.candidate_entries(coords):
-            if mask[0] and (exact or self._device_reaches(e, target_u)):
+        for e, mask, _ in self.candidate_entries(coords):
+            if mask[0]:
                 self.set_polytope(e)
                 self._sequence = None
                 return range(len(e), len(e) + 1)
         raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
-
-    def _device_reaches(self, entry, target_u, restarts: int = 16, threshold: float = 1e-10) -> bool:
-        from . import _ffi
-
-        ctx = runtime.get_context(self.device)
-        ctx.set_targets(np.asarray(target_u, dtype=np.complex128).reshape(1, 4, 4))
-        ctx.set_gates(self.gate_matrices)
-        ctx.set_cost(_ffi.COST_BASIC)
-        k = len(entry)
-        prm = _ffi.OptParams(restarts=restarts, stop_loss=0.1 * threshold, seed=20260004, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
-        ctx.decompose_list(np.array([0]), k, k, [entry.gate_indices], prm, threshold, k_layout=k)
-        loss, _, _ = ctx.fetch_results_range(k, 0, 1)
-        return bool(loss[0] < threshold)

@@ -18,7 +18,7 @@ closed form the same answer comes from a few comparisons on (c1, c2, c3) (SURVEY
 
 For every other template -- a basis gate outside those classes (the ConversionGain(0, 0, gc, gg, 1) family of config 5),
 or a SEQUENCE of different gates (``[iSWAP, B]``, the territory of ``MixedOrderBasisCircuitTemplate``, basis.py:213-359) --
-the exact coverage polytopes are not available here, but a LOWER bound on the template size is:
+rounds 2-3 had a LOWER bound on the template size (superseded by ``coverage.py``, see the end; ``strength`` stays as a helper):
 
 * 0 gates iff the target is local; 1 gate iff the target is in the first gate's own class (exact);
 * k >= 2 gates g_1 .. g_k only if  m(T) <= m(g_1) + ... + m(g_k)  for the two interaction-strength measures
@@ -39,6 +39,12 @@ of a 0.02 grid inside, no sample outside) -- and then against the brute-force sp
 * g . L . g for an XY-type gate g = (a, a, 0), a <= 1/4 (``RiSwapGate(alpha)``, alpha = 4a <= 1; zero-phase conversion-only or
   gain-only ``ConversionGainGate``):  |z| <= x - y,  x + y + |z| <= 4a,  x <= 2a   (a = 1/4: the sqrt(iSWAP) rule above).
 
+Round 4, later -- the general case (``coverage.py``): the coverage set of ANY list of gates from the inequalities of the
+multiplicative eigenvalue problem for SU(4) (what monodromy computes for the reference), 14 half-spaces in the target's alcove
+coordinates per circuit.  It reproduces every rule above with no mismatch and replaces the strength bounds: ``two_gate_region``
+falls back to it, ``sequence_minimal_span`` / ``span_lower_bound`` / ``multiset_coverage`` are exact for every gate.  The closed
+forms stay as the fast path for their classes and as an independent check of the general code (tests/test_coverage.py).
+
 ``span_lower_bound`` is sound (a target is never placed above its true size: tests/test_gpu_round3.py checks it against the
 brute-force span loop on the config-4 and config-5 bases) but not tight: the span loop starts at the bound instead of at 1
 and targets whose bound exceeds the template's maximum are not optimised at all.
@@ -48,6 +54,8 @@ Coordinates are in units of pi, as returned by ``weylchamber.c1c2c3`` (8 digits)
 from __future__ import annotations
 
 import numpy as np
+
+from . import coverage
 
 _TOL = 2e-8  # coordinates are rounded to 8 digits
 
@@ -63,6 +71,15 @@ def _fold(coords: np.ndarray) -> np.ndarray:
     """(c1, c2, c3) with c3 >= 0, c1 in [0, 1]  ->  (x, y, z) with x <= 1/2 (z may become negative)."""
     c = np.array(coords, dtype=np.float64, copy=True).reshape(-1, 3)
     m = c[:, 0] > 0.5
+    c[m, 0] = 1.0 - c[m, 0]
+    c[m, 2] = -c[m, 2]
+    return c
+
+
+def _unfold(c: np.ndarray) -> np.ndarray:
+    """Inverse of ``_fold``: (x, y, z) with x <= 1/2, z of either sign -> (c1, c2, c3) with c3 >= 0."""
+    c = np.array(c, dtype=np.float64, copy=True).reshape(-1, 3)
+    m = c[:, 2] < 0
     c[m, 0] = 1.0 - c[m, 0]
     c[m, 2] = -c[m, 2]
     return c
@@ -107,7 +124,7 @@ def strength(coords) -> np.ndarray:
 
 
 def span_lower_bound(target_coords, gate_coords_seq, k_max=None, slack: float = 4 * _TOL) -> np.ndarray:
-    """Lower bound on the number of leading gates of the template sequence ``gate_coords_seq`` (Weyl coordinates of
+    """(Since ``coverage.py`` the bound is the exact size; the name stays for its callers.)  Lower bound on the number of leading gates of the template sequence ``gate_coords_seq`` (Weyl coordinates of
     g_1, g_2, ... in circuit order) that reach each target: int array [N] with values 0 .. k_max + 1 (k_max + 1 = not
     reachable with the whole sequence).  ``slack`` (in coordinate units) widens the test: a caller that accepts a loss
     below L as success accepts targets up to about sqrt(L) outside the reachable set (|coordinate error| ~ sqrt(loss))."""
@@ -117,18 +134,15 @@ def span_lower_bound(target_coords, gate_coords_seq, k_max=None, slack: float = 
         raise ValueError("gate sequence shorter than k_max")
     c = _fold(target_coords)
     n = len(c)
-    mt = strength(c)
-    cum = np.cumsum(strength(g[:k_max]), axis=0)  # [k][2]: strength available with k + 1 gates
     local = np.max(np.abs(c), axis=1) < _TOL
     gf = _fold(g[:1])[0]
     same = np.max(np.abs(np.abs(c) - np.abs(gf)), axis=1) < _TOL
     lb = np.full(n, k_max + 1, dtype=np.int64)
-    region2 = two_gate_region(g[0], g[1]) if k_max >= 2 else None
     for k in range(k_max, 1, -1):
-        if k == 2 and region2 is not None:
-            ok = region2(c[:, 0], c[:, 1], c[:, 2], _TOL + slack)  # the pair's exact coverage region instead of the strength test
+        if k == 2:
+            ok = two_gate_region(g[0], g[1])(c[:, 0], c[:, 1], c[:, 2], _TOL + slack)
         else:
-            ok = np.all(mt <= cum[k - 1] + slack, axis=1)
+            ok = coverage.contains(_unfold(c), g[:k], _TOL + slack)  # exact (it implies the strength test of round 3)
         lb = np.where(ok, k, lb)
     lb = np.where(same, 1, lb)
     lb = np.where(local, 0, lb)
@@ -140,9 +154,9 @@ def _is(g, ref) -> bool:
 
 
 def two_gate_region(g1, g2):
-    """Exact coverage of the two-gate product g_2 L g_1 (L any local unitary) in the folded chamber, for the pairs whose region is
-    known here: a function ``(x, y, z arrays, tol) -> bool array``, or None.  Symmetric in (g1, g2): transposition swaps the order
-    and leaves the Weyl coordinates alone."""
+    """Exact coverage of the two-gate product g_2 L g_1 (L any local unitary) in the folded chamber: a function
+    ``(x, y, z arrays, tol) -> bool array`` -- the closed form for the pairs that have one here, ``coverage.contains`` for the rest.
+    Symmetric in (g1, g2): transposition swaps the order and leaves the Weyl coordinates alone."""
     a1, a2 = np.abs(_fold(g1)[0]), np.abs(_fold(g2)[0])
     same = bool(np.max(np.abs(a1 - a2)) < _TOL)
     if same:
@@ -153,46 +167,44 @@ def two_gate_region(g1, g2):
         a = float(a1[0])
         if abs(a1[1] - a) < _TOL and a1[2] < _TOL and _TOL < a <= 0.25 + _TOL:  # XY-type (a, a, 0), a <= 1/4
             return lambda x, y, z, tol: (np.abs(z) <= x - y + tol) & (x + y + np.abs(z) <= 4 * a + tol) & (x <= 2 * a + tol)
-        return None
     pair = (_is(g1, FAMILIES["iswap"]) and _is(g2, FAMILIES["b"])) or (_is(g1, FAMILIES["b"]) and _is(g2, FAMILIES["iswap"]))
     if pair:
         return lambda x, y, z, tol: (x >= 0.25 - tol) & (np.abs(z) <= 0.25 + tol)
-    return None
+    gg = np.array([np.ravel(g1), np.ravel(g2)], dtype=np.float64)
+    return lambda x, y, z, tol: coverage.contains(_unfold(np.stack([x, y, z], axis=1)), gg, tol)  # any other pair: coverage.py
 
 
 _UNIVERSAL_IN_3 = ("cx", "iswap", "sqiswap", "b")
+MAX_EXACT_SPAN = 8  # (any length works -- coverage.region is linear in it; the kernels stop at 5)
 
 
 def sequence_is_exact(gate_coords_seq, k_max: int) -> bool:
     """True when ``sequence_minimal_span`` knows the exact template size of every target for the first ``k_max`` gates of the
-    sequence: one gate (its class), two (``two_gate_region``), and three or more when every gate is in a class three of which
-    reach everything (the brute-force loop on the GPU solves every Haar target with three: tests)."""
+    sequence -- since ``coverage.py``: for every gate sequence."""
     g = np.asarray(gate_coords_seq, dtype=np.float64).reshape(-1, 3)
-    if k_max > len(g) or k_max < 1:
-        return False
-    if k_max >= 2 and two_gate_region(g[0], g[1]) is None:
-        return False
-    if k_max >= 3:
-        for gi in g[:k_max]:
-            if not any(_is(gi, FAMILIES[f]) for f in _UNIVERSAL_IN_3):
-                return False
-    return k_max <= 3
+    return 1 <= k_max <= min(len(g), MAX_EXACT_SPAN)
 
 
 def sequence_minimal_span(target_coords, gate_coords_seq, k_max: int, slack: float = 0.0) -> np.ndarray:
     """Exact number of leading gates of the sequence that reaches each target (0 = local, 1 = the first gate's class, 2 = inside
-    the pair's region, else 3), for sequences ``sequence_is_exact`` accepts; targets beyond ``k_max`` get ``k_max + 1``.
-    ``slack`` widens the k = 2 region (a caller that accepts loss < L accepts targets ~ sqrt(L) outside it)."""
+    the pair's region, ...); targets beyond ``k_max`` get ``k_max + 1``.  ``slack`` widens the regions (a caller that accepts
+    loss < L accepts targets ~ sqrt(L) outside them)."""
     g = np.asarray(gate_coords_seq, dtype=np.float64).reshape(-1, 3)
     if not sequence_is_exact(g, k_max):
-        raise NotImplementedError("no exact coverage rule for this gate sequence: use span_lower_bound")
+        raise NotImplementedError("gate sequence shorter than k_max, or longer than MAX_EXACT_SPAN")
     c = _fold(target_coords)
     x, y, z = c[:, 0], c[:, 1], c[:, 2]
     tol = _TOL + slack
     local = np.max(np.abs(c), axis=1) < _TOL
     gf = np.abs(_fold(g[:1])[0])
     same = np.max(np.abs(np.abs(c) - gf), axis=1) < _TOL
-    k = np.full(len(c), 3 if k_max >= 3 else k_max + 1, dtype=np.int64)
+    k = np.full(len(c), k_max + 1, dtype=np.int64)
+    for kk in range(k_max, 2, -1):
+        classes = [next((f for f in _UNIVERSAL_IN_3 if _is(gi, FAMILIES[f])), None) for gi in g[:kk]]
+        if None not in classes and len(set(classes)) == 1:
+            k[:] = kk  # three or more equal gates of these classes reach everything
+        else:
+            k = np.where(coverage.contains(_unfold(c), g[:kk], tol), kk, k)
     if k_max >= 2:
         k = np.where(two_gate_region(g[0], g[1])(x, y, z, tol), 2, k)
     k = np.where(same, 1, k)
@@ -203,9 +215,8 @@ def sequence_minimal_span(target_coords, gate_coords_seq, k_max: int, slack: flo
 def multiset_coverage(target_coords, gate_coords_list, slack: float = 4 * _TOL):
     """Coverage test for a circuit of the gates ``gate_coords_list`` (any order -- transposition and inversion map the Weyl
     coordinates of a product onto those of the reordered one -- with free local gates in between): ``(inside, exact)``.
-    ``inside[t]`` False means target t is certainly NOT reachable; with ``exact`` True, ``inside`` is the coverage set itself (what
-    ``CircuitPolytope.has_element`` answers in the reference, polytope_wrap.py:78-90), otherwise it is a superset (the strength
-    bound of ``span_lower_bound``) and only an optimisation decides.  Local targets are reported outside (the reference handles
+    ``inside`` is the coverage set itself (what ``CircuitPolytope.has_element`` answers in the reference, polytope_wrap.py:78-90);
+    ``exact`` is True for every gate list since ``coverage.py`` (it was False where only the strength bound was known).  Local targets are reported outside (the reference handles
     them before the lookup, polytope_wrap.py:53-54)."""
     g = np.asarray(gate_coords_list, dtype=np.float64).reshape(-1, 3)
     k = len(g)
@@ -218,17 +229,6 @@ def multiset_coverage(target_coords, gate_coords_list, slack: float = 4 * _TOL):
     if k == 1:
         gf = np.abs(_fold(g[:1])[0])
         return (np.max(np.abs(np.abs(c) - gf), axis=1) < _TOL) & ~local, True
-    classes = [next((f for f in _UNIVERSAL_IN_3 if _is(gi, FAMILIES[f])), None) for gi in g]
     if k == 2:
-        region = two_gate_region(g[0], g[1])
-        if region is not None:
-            return region(x, y, z, tol) & ~local, True
-    else:
-        # everything is reachable when two of the gates are B (B L B is already the whole chamber), when all are one gate of a class
-        # three of which suffice, or for iSWAP / B mixtures (the brute-force loop solves every Haar target: tests/test_gpu_round4.py)
-        everything = classes.count("b") >= 2 or (None not in classes and (len(set(classes)) == 1 or set(classes) <= {"iswap", "b"}))
-        if everything:
-            return ~local, True
-    mt = strength(c)
-    avail = strength(g).sum(axis=0)
-    return np.all(mt <= avail + slack, axis=1) & ~local, False
+        return two_gate_region(g[0], g[1])(x, y, z, tol) & ~local, True
+    return coverage.contains(_unfold(c), g, tol) & ~local, True

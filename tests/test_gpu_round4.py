@@ -419,3 +419,39 @@ def test_mixed_order_homogeneous_equals_use_polytopes_template():
         out[name] = [d.cycles for d in data]
     assert out["mixed"] == out["plain"]
     assert 0.7 < np.mean(np.array(out["mixed"]) == 2) < 0.88  # KAT-4: 79 % of Haar targets in two sqrt(iSWAP)
+
+
+def test_exact_coverage_of_conversion_gain_gates_equals_the_brute_force_span_loop():
+    """coverage.py against the device: for bases of BASELINE configs[4]'s conversion-gain sweep (weak to strong, conversion- and
+    gain-heavy, none in a class with a closed-form rule) and a mixed three-gate sequence, the template size predicted from the
+    monodromy inequalities IS the size the brute-force span loop solves each target at, and the targets predicted out of reach of
+    three gates are exactly the ones it does not solve -- for every target at least 2e-4 away from a region boundary (the optimiser
+    accepts loss < 1e-10, i.e. coordinates ~1e-5 outside)."""
+    import bench
+    from slam_decomposition_amd import coverage
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    N = 3000
+    prm = _ffi.OptParams(restarts=24, seed=8, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+    cases = [(f"cg{b}", np.stack([bench.sweep_gate(b)]), [[0], [0, 0], [0, 0, 0]]) for b in (9, 27, 44, 52, 66, 77, 100, 125)]
+    cases.append(("cg40+cg100+sqiswap", np.stack([bench.sweep_gate(40), bench.sweep_gate(100), G.RiSwapGate(0.5).to_matrix()]), [[0], [0, 1], [0, 1, 2]]))
+    stats = {}
+    with _ffi.Context(0) as ctx:
+        ctx.sample_haar(515151, N)
+        coords = ctx.targets_c1c2c3(0, N)
+        for name, table, seqs in cases:
+            ctx.set_gates(table)
+            loss, _, cyc = ctx.decompose(1, 3, seqs, prm, 1e-10)
+            solved = loss < 1e-10
+            g = [c1c2c3(table[i]) for i in seqs[2]]
+            pred = coverage.minimal_prefix(coords, g, 3, tol=0.0)
+            clear = (coverage.minimal_prefix(coords, g, 3, tol=2e-4) == pred) & (coverage.minimal_prefix(coords, g, 3, tol=-2e-4) == pred)
+            assert clear.mean() > 0.97, name
+            reach = pred <= 3
+            assert np.array_equal(solved[clear], reach[clear]), (name, np.nonzero(solved[clear] != reach[clear])[0][:5])
+            ok = clear & reach
+            assert np.array_equal(cyc[ok], pred[ok]), (name, np.nonzero(cyc[ok] != pred[ok])[0][:5])
+            stats[name] = (float(reach.mean()), np.bincount(pred, minlength=5).tolist())
+    # the sweep covers the regimes: a weak gate reaches almost nothing with three applications, strong ones everything, most in two
+    fr = [s[0] for s in stats.values()]
+    assert min(fr) < 0.05 and max(fr) > 0.99 and any(0.2 < v < 0.95 for v in fr), stats

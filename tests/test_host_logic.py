@@ -141,12 +141,16 @@ def test_span_lower_bounds_for_mixed_sequences_and_other_gates():
     assert t.get_spanning_range(o.cx_matrix()) == range(2, 3)               # (1/2, 0, 0): inside the pair's region
     assert t.get_spanning_range(np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex)) == range(3, 4)  # SWAP
     assert t.get_spanning_range(np.eye(4)) == range(0, 1)
-    t5 = CircuitTemplate(base_gates=[RiSwapGate(1.0), BerkeleyGate()], use_polytopes=True, maximum_span_guess=5)  # beyond three gates: bounds
-    assert not t5.span_rules_exact and t5.get_spanning_range(o.cx_matrix()) == range(2, 6)
+    # (later in round 4: coverage.py makes every sequence exact -- templates of five gates, gates without a closed form)
+    t5 = CircuitTemplate(base_gates=[RiSwapGate(1.0), BerkeleyGate()], use_polytopes=True, maximum_span_guess=5)
+    assert t5.span_rules_exact and t5.get_spanning_range(o.cx_matrix()) == range(2, 3)
     w = CircuitTemplate(base_gates=[RiSwapGate(0.2)], use_polytopes=True, maximum_span_guess=3)  # (0.1, 0.1, 0): no closed form
-    assert not w.span_rules_exact
+    assert w.span_rules_exact
+    swap = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex)
     with pytest.raises(ValueError, match="did not find a polytope"):          # polytope_wrap.py:91-93
-        w.get_spanning_range(np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex))  # SWAP
+        w.get_spanning_range(swap)
+    w8 = CircuitTemplate(base_gates=[RiSwapGate(0.2)], use_polytopes=True, maximum_span_guess=8)  # 8 x 0.3 of strength >= SWAP's 1.5
+    assert w8.get_spanning_range(swap) == range(8, 9) and w8.get_spanning_range(o.cx_matrix()) == range(5, 6)
 
 
 def test_qiskit_parameter_order_helpers():
@@ -196,14 +200,14 @@ def test_two_gate_coverage_regions_hold_on_sampled_products():
     # the faces are reached (the region is not larger than the samples say): iSWAP . L . B touches x = 1/4 and |z| = 1/4
     f = fit.fold(fit.sample_products(fit.gate("iswap"), fit.gate("b"), 30000, seed=6))
     assert f[:, 0].min() < 0.2502 and np.abs(f[:, 2]).max() > 0.2495 and f[:, 0].max() > 0.4995
-    # exactness flags: [iSWAP, B, iSWAP] is exact up to three gates; an XY-type pair only up to two; a general pair not at all
-    isw, b = c1c2c3(fit.gate("iswap")), c1c2c3(fit.gate("b"))
-    assert span_rules.sequence_is_exact([isw, b, isw], 3) and span_rules.sequence_is_exact([b, isw], 2)
+    # pairs without a closed form go through coverage.py: a general conversion-gain gate with iSWAP, an XY-type gate with a > 1/4
+    isw = c1c2c3(fit.gate("iswap"))
+    for s1, s2 in (("cg:0.3:0.2", "iswap"), ("riswap:0.7", "riswap:0.7"), ("cg:0.9:0.4", "cg:0.2:0.7")):
+        g1, g2 = fit.gate(s1), fit.gate(s2)
+        f = fit.fold(fit.sample_products(g1, g2, 30000, seed=7))
+        assert span_rules.two_gate_region(c1c2c3(g1), c1c2c3(g2))(f[:, 0], f[:, 1], f[:, 2], 1e-7).all(), (s1, s2)
     g = c1c2c3(fit.gate("riswap:0.4"))
-    assert span_rules.sequence_is_exact([g, g], 2) and not span_rules.sequence_is_exact([g, g, g], 3)
-    assert span_rules.two_gate_region(c1c2c3(fit.gate("cg:0.3:0.2")), isw) is None
-    # an XY-type gate with a > 1/4 has no rule here
-    assert span_rules.two_gate_region(c1c2c3(fit.gate("riswap:0.7")), c1c2c3(fit.gate("riswap:0.7"))) is None
+    assert span_rules.sequence_is_exact([isw, g, isw], 3) and span_rules.sequence_is_exact([g, g, g], 3) and not span_rules.sequence_is_exact([g], 2)
 
 
 def test_target_data_list_semantics_on_the_host():
@@ -270,20 +274,19 @@ def test_mixed_order_template_constructor_and_coverage_set():
     assert costs == sorted(costs) and len(b.coverage) == 2 + 3 + 4
     assert [tuple(e.gate_indices) for e in b.coverage[:5]] == [(0,), (1,), (0, 0), (0, 1), (0, 0, 0)]
     assert all(isinstance(e, CircuitCoverage) and e.operations == [str(b.base_gates[i]) for i in e.gate_indices] for e in b.coverage)
-    # exact entries: single gates, equal pairs of the known classes, three equal gates; the mixed pair is an outer bound
-    ex = {tuple(e.gate_indices): e.exact for e in b.coverage}
-    assert ex[(0,)] and ex[(1,)] and ex[(0, 0)] and ex[(1, 1)] and ex[(0, 0, 0)] and ex[(1, 1, 1)] and not ex[(0, 1)]
-    assert not b.span_rules_exact
+    # every entry's region is exact (coverage.py)
+    assert all(e.exact for e in b.coverage) and b.span_rules_exact
     # membership: sqrt(iSWAP)'s own class in entry (0,), CNOT in (0, 0) [|z| <= x - y], SWAP in no two-gate entry
     cnot, swap, sq = np.array([[0.5, 0, 0]]), np.array([[0.5, 0.5, 0.5]]), np.array([[0.25, 0.25, 0]])
     assert b.coverage[0].has_element(sq) and not b.coverage[0].has_element(cnot)
     assert b.coverage[2].has_element(cnot) and not b.coverage[2].has_element(swap)
-    with pytest.raises(NotImplementedError):
-        b.coverage[3].has_element(cnot)
-    # (SWAP sits exactly ON the strength bound of [sqrt(iSWAP), iSWAP] -- m1 = 1.5 = 0.5 + 1, m2 = 0.75 = 0.25 + 0.5 -- so the outer bound
-    # keeps it and the device decides: tests/test_gpu_round4.py)
-    assert b.coverage[3].inside(swap) == (np.array([True]), False)
-    assert list(b.minimal_spans(np.concatenate([sq, cnot, swap, np.zeros((1, 3))]))) == [1, 2, 2, 0]
+    # [sqrt(iSWAP), iSWAP]: the plain product inside; CNOT and SWAP -- the latter exactly ON the strength bounds of round 3,
+    # m1 = 1.5 = 0.5 + 1, m2 = 0.75 = 0.25 + 0.5 -- outside
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    prod = np.array([c1c2c3(b.gate_matrices[1] @ np.kron(o.u3(0.3, 0.2, 0.1), o.u3(1.0, 0.5, 0.2)) @ b.gate_matrices[0])])
+    assert b.coverage[3].has_element(prod) and not b.coverage[3].has_element(cnot) and not b.coverage[3].has_element(swap)
+    assert list(b.minimal_spans(np.concatenate([sq, cnot, swap, np.zeros((1, 3))]))) == [1, 2, 3, 0]
     # set_polytope / build / gate_sequence / unit_cost
     with pytest.raises(AssertionError):
         b.build(2)
