@@ -132,6 +132,11 @@ struct slam_ctx {
     bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][kGateClasses][3] = {};  // [.][.][0] eval kernel, [1] optimizer kernel, [2] its multi-queue form
     int64_t resident_waves_mq[SLAM_MAX_SPAN_EVAL + 1][kGateClasses] = {};
     int64_t resident_waves_wl[kGateClasses] = {};  // span_wave_kernel<GC>: resident wavefronts (0 = not asked yet)
+    // speculative spans (span_spec_kernel): staging rows, two side streams, fork / join events
+    DevBuf spec_loss, spec_x, spec_ev;
+    hipStream_t spec_stream[2] = {nullptr, nullptr};
+    hipEvent_t spec_fork = nullptr, spec_join[2] = {nullptr, nullptr};
+    bool spec_attr_set[4][kGateClasses] = {};
     // slam_decompose_multi (this context leads the call): the sub-problems' argument blocks / epilogue arguments per span, staged
     // through pinned memory
     DevBuf mq_args;
@@ -153,6 +158,14 @@ struct slam_ctx {
         if (h_gates) (void)hipHostFree(h_gates);
         if (h_mq_args) (void)hipHostFree(h_mq_args);
         mq_args.release();
+        spec_loss.release();
+        spec_x.release();
+        spec_ev.release();
+        if (spec_fork) (void)hipEventDestroy(spec_fork);
+        for (int j = 0; j < 2; ++j) {
+            if (spec_join[j]) (void)hipEventDestroy(spec_join[j]);
+            if (spec_stream[j]) (void)hipStreamDestroy(spec_stream[j]);
+        }
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -167,6 +180,8 @@ int drained(slam_ctx* c, int rc) {
         const std::string keep = g_err;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        for (hipStream_t st : c->spec_stream)
+            if (st) (void)hipStreamSynchronize(st);
         (void)hipGetLastError();
         for (auto& st : c->staged) st.valid = false;
         g_err = keep;
@@ -610,6 +625,28 @@ int launch_span_wave(slam_ctx* c, const WaveLoopArgs& a, int64_t count) {
     return SLAM_OK;
 }
 
+// speculative spans: one launch per span, each on its own stream, then the merge (span_spec_kernel / span_spec_merge_kernel)
+template <int K, int GC>
+int launch_span_spec(slam_ctx* c, const WaveLoopArgs& a, int64_t count, hipStream_t stream) {
+    const size_t lds = sizeof(double) * (size_t)(lds_doubles<K, GC>() + kWlLdsDoubles);
+    if (!c->spec_attr_set[K][GC]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&span_spec_kernel<K, GC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->spec_attr_set[K][GC] = true;
+    }
+    hipLaunchKernelGGL((span_spec_kernel<K, GC>), dim3((unsigned)count), dim3(kWave), lds, stream, a);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+template <int K>
+int launch_span_spec_gc(slam_ctx* c, int gc, const WaveLoopArgs& a, int64_t count, hipStream_t stream) {
+    if (gc == GC_CX) return launch_span_spec<K, GC_CX>(c, a, count, stream);
+    if (gc == GC_XRI1) return launch_span_spec<K, GC_XRI1>(c, a, count, stream);
+    if (gc == GC_XRI) return launch_span_spec<K, GC_XRI>(c, a, count, stream);
+    if (gc == GC_XGEN) return launch_span_spec<K, GC_XGEN>(c, a, count, stream);
+    return launch_span_spec<K, GC_DENSE>(c, a, count, stream);
+}
+
 // returns SLAM_OK and *taken = true when the call was served by the wave-loop kernel; *taken = false: not eligible (nothing enqueued)
 int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* prm,
                         double success_threshold, FetchReq* fetch, bool* taken) {
@@ -680,14 +717,62 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
         const double need_rounds = ((double)prm->restarts / 16.0 + 1.0) * ((double)prm->maxiter + 2.0) * 22.0;
         a.round_cap = need_rounds > 4.0e9 ? 0xffffffffu : (uint32_t)need_rounds;
     }
+    // speculative spans (see span_spec_kernel): all spans of all targets at once when the loop has more than one span.
+    // SLAM_SPECULATE=0 keeps the one-wavefront-per-target loop (A/B runs, tests of that kernel).
+    static const bool env_no_spec = []{ const char* e = std::getenv("SLAM_SPECULATE"); return e && e[0] == '0'; }();
+    // Worth it while every (target, span) wavefront finds a SIMD of its own (measured, tools/r4_spec_probe.sh, CNOT x 16 restarts: 1
+    // target 0.51 -> 0.28 ms, 256 targets 0.80 -> 0.55; at 1024 targets the k = 2 and k = 3 stages no longer fit beside each other
+    // -- 256 + 304 registers -- and the two forms tie: 0.94 / 0.89 ms CNOT, 1.14 / 1.18 ms sqrt(iSWAP), where k = 3 is mostly wasted)
+    const bool spec = k_max > k_min && !env_no_spec && count <= 2 * (int64_t)c->compute_units;
+    int n_launch = 1;
     HIP_TRY(hipEventRecord(c->ev_a[k_min], c->stream));
     int rc;
-    if (gc == GC_CX) rc = launch_span_wave<GC_CX>(c, a, count);
-    else if (gc == GC_XRI1) rc = launch_span_wave<GC_XRI1>(c, a, count);
-    else if (gc == GC_XRI) rc = launch_span_wave<GC_XRI>(c, a, count);
-    else if (gc == GC_XGEN) rc = launch_span_wave<GC_XGEN>(c, a, count);
-    else rc = launch_span_wave<GC_DENSE>(c, a, count);
-    if (rc) return rc;
+    if (spec) {
+        HIP_TRY(c->spec_loss.reserve(sizeof(double) * 3 * (size_t)count));
+        HIP_TRY(c->spec_x.reserve(sizeof(double) * 3 * (size_t)count * (size_t)c->result_nmax));
+        HIP_TRY(c->spec_ev.reserve(sizeof(unsigned long long) * 9 * (size_t)count));
+        a.spec_loss = c->spec_loss.as<double>();
+        a.spec_x = c->spec_x.as<double>();
+        a.spec_ev = c->spec_ev.as<unsigned long long>();
+        if (!c->spec_stream[0]) {
+            for (int j = 0; j < 2; ++j) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->spec_stream[j], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c->spec_join[j], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&c->spec_fork, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(c->spec_fork, c->stream));
+        // the longest stage first, on the call's own stream; the others beside it
+        int side = 0;
+        for (int k = k_max; k >= k_min; --k) {
+            hipStream_t st = c->stream;
+            if (k != k_max) {
+                st = c->spec_stream[side];
+                HIP_TRY(hipStreamWaitEvent(st, c->spec_fork, 0));
+            }
+            switch (k) {
+                case 1: rc = launch_span_spec_gc<1>(c, gc, a, count, st); break;
+                case 2: rc = launch_span_spec_gc<2>(c, gc, a, count, st); break;
+                default: rc = launch_span_spec_gc<3>(c, gc, a, count, st); break;
+            }
+            if (rc) return rc;
+            if (k != k_max) {
+                HIP_TRY(hipEventRecord(c->spec_join[side], st));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->spec_join[side], 0));
+                ++side;
+            }
+        }
+        hipLaunchKernelGGL(span_spec_merge_kernel, dim3((unsigned)((count + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, a);
+        HIP_TRY(hipGetLastError());
+        n_launch = (k_max - k_min + 1) + 1;
+    } else {
+        if (gc == GC_CX) rc = launch_span_wave<GC_CX>(c, a, count);
+        else if (gc == GC_XRI1) rc = launch_span_wave<GC_XRI1>(c, a, count);
+        else if (gc == GC_XRI) rc = launch_span_wave<GC_XRI>(c, a, count);
+        else if (gc == GC_XGEN) rc = launch_span_wave<GC_XGEN>(c, a, count);
+        else rc = launch_span_wave<GC_DENSE>(c, a, count);
+        if (rc) return rc;
+    }
     HIP_TRY(hipEventRecord(c->ev_b[k_min], c->stream));
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     if (fetch) {
@@ -705,9 +790,9 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
     HIP_TRY(hipEventElapsedTime(&kms, c->ev_a[k_min], c->ev_b[k_min]));
     c->stats.kernel_ms += kms;
     c->stats.kernel_ms_span[k_min] += kms;  // (one launch for all spans: its time is booked on the first one)
-    c->stats.kernel_launches += 1;
+    c->stats.kernel_launches += n_launch;
     for (int k = k_min; k <= k_max; ++k) {
-        if (c->h_ctl[k].n_active <= 0) continue;
+        if (c->h_ctl[k].n_active <= 0 && c->h_ctl[k].evals == 0) continue;
         c->stats.evals[k] += (int64_t)c->h_ctl[k].evals;
         c->stats.evals_accepted[k] += (int64_t)c->h_ctl[k].evals_accepted;
         c->stats.evals_preempted[k] += (int64_t)c->h_ctl[k].evals_preempted;

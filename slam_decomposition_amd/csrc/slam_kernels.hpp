@@ -210,7 +210,8 @@ struct WlStage {
     double win_loss;     // wave-uniform
     int win_r;           // wave-uniform; -1: no finite restart yet
     bool hit;            // wave-uniform: a restart below the exit level has finished
-    unsigned long long ev_all, ev_acc, ev_pre;  // per lane (lane q = 0 of a quad): evaluations of the items it finished
+    unsigned ev_all, ev_acc, ev_pre;  // per lane (lane q = 0 of a quad): evaluations of the items it finished (32 bits: a quad's share of one
+                                      // target's restarts -- the 64-bit form cost the k = 3 stage the three registers that let it share a SIMD with k = 1)
     unsigned rounds;
     unsigned round_cap;  // exit condition every wavefront reaches whatever the state machine does (never met by a sane run)
 };
@@ -685,10 +686,10 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
             // the stage's winner, kept up to date as restarts finish (those of one round one after the other; item == restart here)
             const bool fin = active && done;
             if (fin && q == 0) {
-                const unsigned long long e = (unsigned long long)(nev & 0xFFFFF);
+                const unsigned e = (unsigned)(nev & 0xFFFFF);
                 wl.ev_all += e;
                 if (status == ST_PREEMPTED) wl.ev_pre += e;
-                else wl.ev_acc += (unsigned long long)((unsigned)nev >> 20);
+                else wl.ev_acc += (unsigned)nev >> 20;
             }
             unsigned long long m = __ballot(fin && q == 0 && status != ST_PREEMPTED);
             while (m) {
@@ -759,11 +760,15 @@ struct WaveLoopArgs {
     double* span_loss;
     int32_t nmax;
     uint32_t round_cap;                 // rounds after which a wavefront leaves a stage whatever happens
+    // speculative spans (span_spec_kernel): stage k of target i leaves its result in row (k - 1) * count + i
+    double* spec_loss;                  // [3 * count]: the stage's winner loss (INFINITY: no finite restart)
+    double* spec_x;                     // [3 * count][nmax]
+    unsigned long long* spec_ev;        // [3 * count][3]: evaluations (all, accepted, pre-empted) of the stage
 };
 constexpr int kSpanLossStride = 5;  // = SLAM_MAX_SPAN_EVAL
 constexpr int kWlLdsDoubles = 40;  // winner row (<= 36 parameters) + the flag word
 
-template <int K, int GC>
+template <int K, int GC, int KL = 3, bool SPEC = false>
 __device__ __forceinline__ void wave_stage(const WaveLoopArgs& a, int t, double* lds, double& best_loss, int& best_cycles) {
     using C = Cfg<K, psq_layout<K, GC>()>;
     const int lane = threadIdx.x;
@@ -777,7 +782,7 @@ __device__ __forceinline__ void wave_stage(const WaveLoopArgs& a, int t, double*
     }
     WlStage wl{};
     wl.t = t;
-    wl.win_x = lds + lds_doubles<3, GC>();
+    wl.win_x = lds + lds_doubles<KL, GC>();
     wl.flag = reinterpret_cast<int*>(wl.win_x + 36);
     wl.win_loss = INFINITY;
     wl.win_r = -1;
@@ -794,6 +799,21 @@ __device__ __forceinline__ void wave_stage(const WaveLoopArgs& a, int t, double*
         e1 += __shfl_down(e1, off);
         e2 += __shfl_down(e2, off);
     }
+    const double stage_loss = wl.win_r >= 0 ? wl.win_loss : (double)INFINITY;
+    if constexpr (SPEC) {
+        // a stage run ahead of the span loop's decision: its result and counters go to the staging rows; span_spec_merge_kernel
+        // applies the loop's bookkeeping (and books the evaluations of stages the loop would not have run as pre-empted)
+        const int64_t row = (int64_t)(K - 1) * a.count + (t - a.first);
+        if (lane == 0) {
+            a.spec_loss[row] = stage_loss;
+            a.spec_ev[row * 3 + 0] = e0;
+            a.spec_ev[row * 3 + 1] = e1;
+            a.spec_ev[row * 3 + 2] = e2;
+            atomicAdd(&a.ctl[K].rounds, (unsigned long long)wl.rounds);
+        }
+        if (lane < a.nmax) a.spec_x[row * a.nmax + lane] = (lane < C::N) ? wl.win_x[lane] : 0.0;
+        return;
+    }
     if (lane == 0) {
         StageCtl* c = a.ctl + K;
         atomicAdd(&c->evals, e0);
@@ -803,7 +823,6 @@ __device__ __forceinline__ void wave_stage(const WaveLoopArgs& a, int t, double*
         atomicAdd(&c->n_active, 1);
     }
     // merge into the running best (optimizer.py:281-284), record the "Cycle (k =...)" value
-    const double stage_loss = wl.win_r >= 0 ? wl.win_loss : (double)INFINITY;
     if (best_cycles < 0 || stage_loss < best_loss) {
         best_loss = stage_loss;
         best_cycles = K;
@@ -834,6 +853,82 @@ __global__ void __launch_bounds__(kWave, 1) span_wave_kernel(WaveLoopArgs a) {
     if (lane == 0) {
         a.best_loss[t] = best_loss;
         a.best_cycles[t] = best_cycles;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Speculative spans (small batches that leave the chip mostly empty): the stages of the span loop do not depend on each other's
+// RESULTS -- only on whether they are needed (optimizer.py:301-303 breaks at the first span below the threshold) -- so all spans of
+// all targets start at once, one wavefront per (target, span), one launch per span on its own stream (the k = 1, 2 kernels keep their
+// own register budget: two wavefronts per SIMD beside one of k = 3), and span_spec_merge_kernel then walks every target's stage
+// results in span order exactly as the loop would: running best with strict "<" (optimizer.py:281-284), stop at the first success.
+// Same items, same Philox start points (keyed by span), same winner rule per stage => the per-span launches' results bit for bit; a
+// lone batch takes the longest single stage instead of the sum of three.  Stages the loop would not have run are wasted work: their
+// evaluations are booked as pre-empted.  (For CNOT -- BASELINE configs[1] -- no Haar target is solved before k = 3: nothing is wasted.)
+// ---------------------------------------------------------------------------------
+template <int K, int GC>
+__global__ void __launch_bounds__(kWave, K >= 3 ? 1 : 2) span_spec_kernel(WaveLoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int i = (int)blockIdx.x;
+    if (i >= a.count) return;
+    double best_loss = INFINITY;
+    int best_cycles = -1;
+    wave_stage<K, GC, K, true>(a, a.first + i, lds, best_loss, best_cycles);
+}
+
+__global__ void __launch_bounds__(kWave) span_spec_merge_kernel(WaveLoopArgs a) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const bool live = i < a.count;
+    const int t = a.first + (live ? i : 0);
+    double best = INFINITY;
+    int cyc = -1;
+    bool done = false;
+    if (live)
+        for (int j = 0; j < kSpanLossStride; ++j) a.span_loss[(int64_t)t * kSpanLossStride + j] = NAN;  // "span not run"
+    for (int k = 1; k <= 3; ++k) {
+        unsigned long long e_all = 0, e_acc = 0, e_pre = 0;
+        int act = 0;
+        if (live && k >= a.k_min && k <= a.k_max) {
+            const int64_t row = (int64_t)(k - 1) * a.count + i;
+            const unsigned long long e0 = a.spec_ev[row * 3 + 0];
+            e_all = e0;
+            if (!done) {
+                const double sl = a.spec_loss[row];
+                if (cyc < 0 || sl < best) {
+                    best = sl;
+                    cyc = k;
+                }
+                a.span_loss[(int64_t)t * kSpanLossStride + (k - 1)] = best;
+                e_acc = a.spec_ev[row * 3 + 1];
+                e_pre = a.spec_ev[row * 3 + 2];
+                act = 1;
+                done = best < a.threshold;
+            } else {
+                e_pre = e0;  // the span loop had already stopped: all of this stage was speculation
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            e_all += __shfl_down(e_all, off);
+            e_acc += __shfl_down(e_acc, off);
+            e_pre += __shfl_down(e_pre, off);
+            act += __shfl_down(act, off);
+        }
+        if (threadIdx.x == 0 && k >= a.k_min && k <= a.k_max) {
+            StageCtl* c = a.ctl + k;
+            atomicAdd(&c->evals, e_all);
+            atomicAdd(&c->evals_accepted, e_acc);
+            atomicAdd(&c->evals_preempted, e_pre);
+            atomicAdd(&c->n_active, act);
+        }
+    }
+    if (!live) return;
+    a.best_loss[t] = best;
+    a.best_cycles[t] = cyc;
+    if (cyc >= 1) {
+        const double* src = a.spec_x + ((int64_t)(cyc - 1) * a.count + i) * a.nmax;
+        for (int j = 0; j < a.nmax; ++j) a.best_x[(int64_t)t * a.nmax + j] = src[j];
+    } else {
+        for (int j = 0; j < a.nmax; ++j) a.best_x[(int64_t)t * a.nmax + j] = 0.0;
     }
 }
 

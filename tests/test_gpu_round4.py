@@ -24,6 +24,9 @@ def _fold(c):
     return span_rules._fold(c)
 
 
+_SPEC_ON = os.environ.get("SLAM_SPECULATE", "1")[:1] != "0"  # (SLAM_SPECULATE=0: small batches through the one-wavefront loop only)
+
+
 @pytest.mark.parametrize("basis", ["cx", "sqiswap"])
 def test_hip_path_matches_the_finite_difference_reference_path_on_64_targets(basis):
     """north_star: "match the reference NumPy/SciPy path's converged loss and recovered Weyl coordinates to 1e-6 on identical Haar
@@ -270,7 +273,9 @@ def test_one_wavefront_per_target_span_loop_equals_the_staged_launches(basis, R)
     reduced as restarts finish); SLAM_FLAG_STAGED forces one optimizer + one bookkeeping launch per span.  Same items, same seeds, same
     quasi-Newton loop: losses, parameters, cycles and the per-span running best are equal bit for bit -- also with more restarts than
     quads (R = 40: wave-local refill) and fewer (R = 5) -- and the wave path is ONE kernel launch."""
-    N = 900 if R > 16 else 300  # (more than 16 restarts: the wave path is taken only when targets x restarts fill the chip)
+    # (more than 16 restarts: the wave path is taken only when targets x restarts fill the chip; at most 2 targets per CU: the
+    # speculative form -- one launch per span side by side + the merge, span_spec_kernel -- instead of the one-wavefront loop)
+    N = 900 if R > 16 else (300 if basis == "sqiswap" else 700)
     gate = {"sqiswap": G.RiSwapGate(0.5), "cx": G.CXGate(), "b": G.BerkeleyGate()}[basis].to_matrix()
     seqs = [[0], [0, 0], [0, 0, 0]]
     flags = _ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED
@@ -291,8 +296,14 @@ def test_one_wavefront_per_target_span_loop_equals_the_staged_launches(basis, R)
         (l0, x0, c0, s0, st0), (l1, x1, c1, s1, st1) = out["wave"], out["staged"]
         assert np.array_equal(l0, l1) and np.array_equal(c0, c1) and np.array_equal(x0, x1)
         assert np.array_equal(np.isnan(s0), np.isnan(s1)) and np.array_equal(np.nan_to_num(s0), np.nan_to_num(s1))
-        assert st0["kernel_launches"] == 1 and st1["kernel_launches"] == (2 if basis == "b" else 3)  # (B reaches everything in two)
+        assert st0["kernel_launches"] == (4 if (N <= 512 and _SPEC_ON) else 1) and st1["kernel_launches"] == (2 if basis == "b" else 3)  # (B reaches everything in two)
         assert st0["items"] == st1["items"] and st0["evals"][1] == st1["evals"][1]  # (k = 1: nothing is pre-empted)
+        if N <= 512 and _SPEC_ON:
+            # speculative spans: the k = 2 stage ran for every target as in the loop; of the k = 3 stage (run for ALL targets) only the
+            # share of the targets the loop would have taken there is booked as accepted, the rest as pre-empted
+            # (which later restarts an early exit cuts short depends on timing, so only the totals' order is compared)
+            assert st0["evals"][3] > st1["evals"][3] and st0["evals_preempted"][3] > st1["evals_preempted"][3]
+            assert st0["evals_preempted"][3] >= 0.5 * st0["evals"][3]  # sqrt(iSWAP): 79 % of the targets stop at k = 2
         assert np.all(l0 < 1e-8)
         # spans 2..3 only, and a batch too big for the wave path (falls back by itself)
         prm = _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=12, flags=flags)
@@ -326,7 +337,8 @@ def test_wave_loop_edge_cases_square_cost_dense_gate_single_target():
                 res.append(ctx.decompose_range(3, N, k0, k1, seqs, prm, 1e-10) + (ctx.stats()["kernel_launches"],))
             (l0, x0, c0, n0), (l1, x1, c1, n1) = res
             assert np.array_equal(l0, l1) and np.array_equal(x0, x1) and np.array_equal(c0, c1), name
-            assert n0 == (1 if name != "mixed classes" else n1), (name, n0, n1)
+            want = (k1 - k0 + 2) if (k1 > k0 and _SPEC_ON) else 1  # speculative spans: one launch per span + the merge
+            assert n0 == (want if name != "mixed classes" else n1), (name, n0, n1)
 
 
 def test_mixed_order_template_binds_the_cheapest_circuit_that_reaches_each_target():

@@ -16,7 +16,7 @@ ctx = _ffi.Context(0)
 ctx.set_gates(bench.gate_table(gname))
 ctx.sample_haar(7, 8192)
 seqs = [[0], [0, 0], [0, 0, 0]]
-for N in (1, 16, 256, 1024, 2048, 4096):
+for N in (1, 16, 256, 512, 1024, 2048, 4096):
     row = []
     for name, extra in (("wave", 0), ("staged", _ffi.FLAG_STAGED)):
         prm = _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=3, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED | extra)
