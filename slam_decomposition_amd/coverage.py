@@ -145,16 +145,28 @@ def inequalities(s: int):
 
 
 # ---- coordinates -------------------------------------------------------------------------------------------------------------------
+def _alcove_columns(coords, shift: float = 0.0):
+    """``alcove_coordinates`` as four contiguous column vectors (the batch form: everything is an elementwise pass over [N])."""
+    c = np.asarray(coords, dtype=np.float64).reshape(-1, 3)
+    x, y, z = (np.ascontiguousarray(c[:, j]) for j in range(3))
+    cols = [0.5 * (x + y - z) + shift, 0.5 * (x - y + z) + shift, 0.5 * (-x + y + z) + shift, 0.5 * (-x - y - z) + shift]
+    c0, c1, c2, c3 = (v - np.floor(v) for v in cols)  # in [0, 1); their sum is an integer s in 0..3
+    # decreasing order: a five-exchange sorting network on the columns
+    c0, c1 = np.maximum(c0, c1), np.minimum(c0, c1)
+    c2, c3 = np.maximum(c2, c3), np.minimum(c2, c3)
+    c0, c2 = np.maximum(c0, c2), np.minimum(c0, c2)
+    c1, c3 = np.maximum(c1, c3), np.minimum(c1, c3)
+    c1, c2 = np.maximum(c1, c2), np.minimum(c1, c2)
+    s = np.rint(c0 + c1 + c2 + c3).astype(np.int64)
+    # subtract 1 from the s largest entries: they become the smallest, in the same order -- a rotation of the row by s
+    e = [c0, c1, c2, c3, c0 - 1.0, c1 - 1.0, c2 - 1.0]
+    return [np.choose(s, e[j : j + 4]) for j in range(_N)]
+
+
 def alcove_coordinates(coords, shift: float = 0.0) -> np.ndarray:
     """Weyl coordinates (c1, c2, c3) [N, 3], units of pi  ->  alcove points [N, 4] (decreasing, sum 0, a_1 - a_4 <= 1) of
     ``i^{2 shift} CAN(c)``: ``shift`` 0 or 1/2 are the two points of the gate class."""
-    c = np.asarray(coords, dtype=np.float64).reshape(-1, 3)
-    a = 0.5 * np.stack([c[:, 0] + c[:, 1] - c[:, 2], c[:, 0] - c[:, 1] + c[:, 2], -c[:, 0] + c[:, 1] + c[:, 2], -c[:, 0] - c[:, 1] - c[:, 2]], axis=1)
-    a = np.mod(a + shift, 1.0)
-    a = -np.sort(-a, axis=1)
-    s = np.rint(a.sum(axis=1)).astype(np.int64)
-    a = a - (np.arange(_N)[None, :] < s[:, None])
-    return -np.sort(-a, axis=1)
+    return np.stack(_alcove_columns(coords, shift), axis=1)
 
 
 _PATTERNS = [K for r in (1, 2, 3) for K in itertools.combinations(range(1, _N + 1), r)]  # the 14 subsets K, fixed order
@@ -200,23 +212,51 @@ def region(gate_coords_list) -> np.ndarray:
     return bounds
 
 
-def contains(target_coords, gate_coords_list, tol: float = 1e-9) -> np.ndarray:
+def target_sums(target_coords):
+    """The targets' side of every half-space, for both alcove points of each target class: per point ``(columns, sums)`` -- the four
+    alcove coordinates and the 14 vectors ``_PATTERN_ROWS[p] @ gamma`` (plain column sums), each [N].  Computed once per batch and shared by the circuits it is tested against."""
+    t = np.asarray(target_coords, dtype=np.float64).reshape(-1, 3)
+    out = []
+    for shift in (0.0, 0.5):
+        cols = _alcove_columns(t, shift)
+        c = cols
+        sums = []
+        for K in _PATTERNS:
+            idx = [_N - k for k in K]
+            v = cols[idx[0]]
+            for j in idx[1:]:
+                v = v + cols[j]
+            sums.append(v)
+        out.append((c, sums))
+    return out
+
+
+def contains(target_coords, gate_coords_list, tol: float = 1e-9, sums=None) -> np.ndarray:
     """bool[N]: target t is reachable (up to local gates) by a circuit of the gates with Weyl coordinates ``gate_coords_list`` -- in any
     order, the double cosets of a Gelfand pair commute -- with arbitrary local gates in between.  ``tol`` (alcove units = units of pi)
-    widens (> 0) or shrinks (< 0) the region."""
+    widens (> 0) or shrinks (< 0) the region.  ``sums`` = ``target_sums(target_coords)`` when several circuits are tested."""
     g = np.asarray(gate_coords_list, dtype=np.float64).reshape(-1, 3)
-    t = np.asarray(target_coords, dtype=np.float64).reshape(-1, 3)
     if len(g) < 1:
         raise ValueError("a circuit needs at least one gate")
+    if sums is None:
+        sums = target_sums(target_coords)
+    n = len(sums[0][0][0])
+    out = np.zeros(n, dtype=bool)
     if len(g) == 1:
         a = alcove_coordinates(g)[0]
-        return (np.max(np.abs(alcove_coordinates(t) - a), axis=1) <= max(tol, 0.0) + 1e-12) | \
-               (np.max(np.abs(alcove_coordinates(t, 0.5) - a), axis=1) <= max(tol, 0.0) + 1e-12)
+        for c, _ in sums:
+            ok = np.ones(n, dtype=bool)
+            for j in range(_N):
+                ok &= np.abs(c[j] - a[j]) <= max(tol, 0.0) + 1e-12
+            out |= ok
+        return out
     bounds = region(g)
-    out = np.zeros(len(t), dtype=bool)
-    for shift in (0.0, 0.5):  # the target class has two alcove points; the gates' are fixed by their CAN matrices
-        c = alcove_coordinates(t, shift)
-        out |= np.all(bounds[None, :] - c @ _PATTERN_ROWS.T <= tol, axis=1)
+    for _, cols in sums:  # the target class has two alcove points; the gates' are fixed by their CAN matrices
+        ok = np.ones(n, dtype=bool)
+        for p, v in enumerate(cols):
+            if np.isfinite(bounds[p]):
+                ok &= v >= bounds[p] - tol
+        out |= ok
     return out
 
 
@@ -227,8 +267,10 @@ def minimal_prefix(target_coords, gate_coords_seq, k_max: int, tol: float = 1e-9
     if k_max > len(g):
         raise ValueError("gate sequence shorter than k_max")
     k_of = np.full(len(t), k_max + 1, dtype=np.int64)
+    sums = target_sums(t)
     for k in range(k_max, 0, -1):
-        k_of = np.where(contains(t, g[:k], tol), k, k_of)
-    ident = np.max(np.abs(alcove_coordinates(t)), axis=1) <= 1e-8
-    ident |= np.max(np.abs(alcove_coordinates(t, 0.5)), axis=1) <= 1e-8
+        k_of = np.where(contains(t, g[:k], tol, sums=sums), k, k_of)
+    ident = np.zeros(len(t), dtype=bool)
+    for c, _ in sums:
+        ident |= (np.abs(c[0]) <= 1e-8) & (np.abs(c[3]) <= 1e-8)  # decreasing, sum 0: all four vanish
     return np.where(ident, 0, k_of)

@@ -138,11 +138,17 @@ def span_lower_bound(target_coords, gate_coords_seq, k_max=None, slack: float = 
     gf = _fold(g[:1])[0]
     same = np.max(np.abs(np.abs(c) - np.abs(gf)), axis=1) < _TOL
     lb = np.full(n, k_max + 1, dtype=np.int64)
+    sums = None
     for k in range(k_max, 1, -1):
-        if k == 2:
-            ok = two_gate_region(g[0], g[1])(c[:, 0], c[:, 1], c[:, 2], _TOL + slack)
+        closed = _closed_two_gate_region(g[0], g[1]) if k == 2 else None
+        if k >= 3 and _reaches_everything(g[:k]):
+            ok = np.ones(n, dtype=bool)
+        elif closed is not None:
+            ok = closed(c[:, 0], c[:, 1], c[:, 2], _TOL + slack)
         else:
-            ok = coverage.contains(_unfold(c), g[:k], _TOL + slack)  # exact (it implies the strength test of round 3)
+            if sums is None:
+                sums = coverage.target_sums(_unfold(c))  # the targets' side of the half-spaces, once for all k
+            ok = coverage.contains(None, g[:k], _TOL + slack, sums=sums)  # exact (it implies the strength test of round 3)
         lb = np.where(ok, k, lb)
     lb = np.where(same, 1, lb)
     lb = np.where(local, 0, lb)
@@ -157,6 +163,15 @@ def two_gate_region(g1, g2):
     """Exact coverage of the two-gate product g_2 L g_1 (L any local unitary) in the folded chamber: a function
     ``(x, y, z arrays, tol) -> bool array`` -- the closed form for the pairs that have one here, ``coverage.contains`` for the rest.
     Symmetric in (g1, g2): transposition swaps the order and leaves the Weyl coordinates alone."""
+    closed = _closed_two_gate_region(g1, g2)
+    if closed is not None:
+        return closed
+    gg = np.array([np.ravel(g1), np.ravel(g2)], dtype=np.float64)
+    return lambda x, y, z, tol: coverage.contains(_unfold(np.stack([x, y, z], axis=1)), gg, tol)  # any other pair: coverage.py
+
+
+def _closed_two_gate_region(g1, g2):
+    """The pairs with a closed-form region (or None)."""
     a1, a2 = np.abs(_fold(g1)[0]), np.abs(_fold(g2)[0])
     same = bool(np.max(np.abs(a1 - a2)) < _TOL)
     if same:
@@ -170,11 +185,19 @@ def two_gate_region(g1, g2):
     pair = (_is(g1, FAMILIES["iswap"]) and _is(g2, FAMILIES["b"])) or (_is(g1, FAMILIES["b"]) and _is(g2, FAMILIES["iswap"]))
     if pair:
         return lambda x, y, z, tol: (x >= 0.25 - tol) & (np.abs(z) <= 0.25 + tol)
-    gg = np.array([np.ravel(g1), np.ravel(g2)], dtype=np.float64)
-    return lambda x, y, z, tol: coverage.contains(_unfold(np.stack([x, y, z], axis=1)), gg, tol)  # any other pair: coverage.py
+    return None
 
 
 _UNIVERSAL_IN_3 = ("cx", "iswap", "sqiswap", "b")
+
+
+def _reaches_everything(g) -> bool:
+    """Shortcut for three or more gates (``coverage.contains`` says the same, tests/test_coverage.py): two of them B (B L B is the
+    whole chamber), all of ONE class among CX / iSWAP / sqrt(iSWAP) / B, or any mixture of iSWAP and B."""
+    if len(g) < 3:
+        return False
+    classes = [next((f for f in _UNIVERSAL_IN_3 if _is(gi, FAMILIES[f])), None) for gi in g]
+    return classes.count("b") >= 2 or (None not in classes and (len(set(classes)) == 1 or set(classes) <= {"iswap", "b"}))
 MAX_EXACT_SPAN = 8  # (any length works -- coverage.region is linear in it; the kernels stop at 5)
 
 
@@ -200,9 +223,8 @@ def sequence_minimal_span(target_coords, gate_coords_seq, k_max: int, slack: flo
     same = np.max(np.abs(np.abs(c) - gf), axis=1) < _TOL
     k = np.full(len(c), k_max + 1, dtype=np.int64)
     for kk in range(k_max, 2, -1):
-        classes = [next((f for f in _UNIVERSAL_IN_3 if _is(gi, FAMILIES[f])), None) for gi in g[:kk]]
-        if None not in classes and len(set(classes)) == 1:
-            k[:] = kk  # three or more equal gates of these classes reach everything
+        if _reaches_everything(g[:kk]):
+            k[:] = kk
         else:
             k = np.where(coverage.contains(_unfold(c), g[:kk], tol), kk, k)
     if k_max >= 2:
@@ -231,4 +253,6 @@ def multiset_coverage(target_coords, gate_coords_list, slack: float = 4 * _TOL):
         return (np.max(np.abs(np.abs(c) - gf), axis=1) < _TOL) & ~local, True
     if k == 2:
         return two_gate_region(g[0], g[1])(x, y, z, tol) & ~local, True
+    if _reaches_everything(g):
+        return ~local, True
     return coverage.contains(_unfold(c), g, tol) & ~local, True
