@@ -577,24 +577,15 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=flags, items_per_quad=ipq)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
 
-    gate_coords = None
     if span_rules_mode:
-        from slam_decomposition_amd import span_rules
         from slam_decomposition_amd.weyl import c1c2c3 as host_c1c2c3
 
-        # one basis gate of a class with closed-form coverage regions: the exact template size per target; anything else
-        # (the mixed sequence of cfg4, the conversion-gain sweep of cfg5): a sound lower bound, the span loop starts there
-        gate_coords = host_c1c2c3(table[0])
-        span_exact = False
-        if len(table) == 1 and not sweep:
-            try:
-                span_rules.family_of(gate_coords)
-                span_exact = True
-            except NotImplementedError:
-                pass
-
     def one_step(s: int, c):
-        if span_rules_mode and not span_exact:
+        if span_rules_mode:
+            # use_polytopes=True (basis.py:95-100): every target starts at the template size its coverage set assigns -- exact for every
+            # gate sequence (coverage.py: the monodromy inequalities; the half-spaces of the three prefixes go to the device, which
+            # evaluates them on the resident targets: slam_predict_spans) -- and runs on from there like the span loop does.
+            # tol: the metric accepts loss < 1e-8, i.e. targets up to ~1e-4 in coordinates outside the exact reachable set
             first = 0 if sweep else s * n_per_step
             if sweep:
                 g = sweep_gate(basis_of(s))
@@ -602,8 +593,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
                 seq_coords = [host_c1c2c3(g)] * 3
             else:
                 seq_coords = [host_c1c2c3(table[i]) for i in gate_seqs[2]]
-            # slack: the metric accepts loss < 1e-8, i.e. targets up to ~1e-4 in coordinates outside the exact reachable set
-            lb = span_rules.span_lower_bound(c.targets_c1c2c3(first, n_per_step), seq_coords, 3, slack=5e-4)
+            lb = c.predict_spans(seq_coords, 3, first, n_per_step, tol=5e-4)
             ran = False
             for k in np.unique(lb):
                 k = int(k)
@@ -619,21 +609,6 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
             best_cycles[lb < 1] = 0
             best_loss[lb > 3] = np.inf  # not optimised in this step (their resident slots may hold an earlier step's result)
             best_cycles[lb > 3] = -1
-            return best_loss, best_cycles
-        if span_rules_mode:
-            first = s * n_per_step
-            spans = span_rules.minimal_span(c.targets_c1c2c3(first, n_per_step), gate_coords)
-            # targets that need no 2Q gate (span 0) are never optimised: their slots read (+inf, -1) from the library;
-            # a local target is solved by definition
-            for k in np.unique(spans):
-                k = int(k)
-                if k < 1:
-                    continue
-                c.decompose_list(first + np.nonzero(spans == k)[0], k, k, [gate_seqs[k - 1]], prm, threshold, k_layout=3)
-            best_loss, best_x, best_cycles = c.fetch_results_range(3, first, n_per_step)
-            local = spans < 1
-            best_loss[local] = 0.0
-            best_cycles[local] = 0
             return best_loss, best_cycles
         if sweep:
             c.set_gates(np.stack([sweep_gate(basis_of(s))]))

@@ -153,6 +153,22 @@ int slam_targets_c1c2c3(slam_ctx* ctx, int64_t first, int64_t count, int ndigits
 int slam_eval_c1c2c3(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, int64_t M, int ndigits, double* out);
 
 /*
+ * Span predictor on the device: for every resident target of [first, first + count) the smallest number k of leading gates of a
+ * template whose coverage set contains the target -- the lookup CircuitTemplate.get_spanning_range makes with use_polytopes=True
+ * (src/slam/basis.py:95-100 -> monodromy_range_from_target, src/slam/utils/polytopes/polytope_wrap.py:39-94).  The coverage sets
+ * come from the caller as half-spaces in the target's alcove coordinates (slam_decomposition_amd/coverage.py computes them from the
+ * gates' Weyl coordinates):
+ *   point   double[4]            alcove point of the first gate (k = 1: the target must be that class)
+ *   bounds  double[k_max][14]    row k - 1 (k >= 2; row 0 unused): bounds[p] <= sum of the target's alcove coordinates over the
+ *                                p-th subset ({4},{3},{2},{1},{4,3},{4,2},{4,1},{3,2},{3,1},{2,1},{4,3,2},{4,3,1},{4,2,1},{3,2,1} of the
+ *                                decreasing coordinates a_1..a_4); -inf = no constraint
+ *   tol                          widens the regions (units of pi)
+ * spans_out: int32[count]: 0 = local target, 1 .. k_max, k_max + 1 = out of reach of the whole template.  k_max <= 5.
+ */
+int slam_predict_spans(slam_ctx* ctx, int64_t first, int64_t count, int k_max, const double* point, const double* bounds, double tol,
+                       int32_t* spans_out);
+
+/*
  * Upload the table of 2Q basis-gate matrices (CircuitTemplate(base_gates=...),
  * src/slam/basis.py:52-69; matrices from src/slam/utils/gates/custom_gates.py).
  * gates: double[n_gates][4][4][2].
@@ -440,7 +456,7 @@ const char* slam_version(void);
  * slam_allreduce_min took its fifth argument, merged_capacity, in round 3 without a new symbol; a caller built against an older
  * header must check this before calling).  The Python binding refuses a library whose revision differs from the one it was
  * written for. */
-#define SLAM_ABI_VERSION 4
+#define SLAM_ABI_VERSION 5
 int slam_abi_version(void);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLAM_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslamhip.so")
 
-ABI_VERSION = 4  # include/slam_hip.h: SLAM_ABI_VERSION
+ABI_VERSION = 5  # include/slam_hip.h: SLAM_ABI_VERSION
 MAX_SPAN_EVAL = 5
 MAX_SPAN_MINIMIZE = 5
 
@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "slam_set_gates",
     "slam_c1c2c3",
     "slam_targets_c1c2c3",
+    "slam_predict_spans",
     "slam_eval_c1c2c3",
     "slam_sample_haar",
     "slam_get_targets",
@@ -171,6 +172,7 @@ def load_library() -> C.CDLL:
     lib.slam_set_gates.argtypes = [P, P, C.c_int32]
     lib.slam_c1c2c3.argtypes = [P, P, C.c_int64, C.c_int32, P]
     lib.slam_targets_c1c2c3.argtypes = [P, C.c_int64, C.c_int64, C.c_int32, P]
+    lib.slam_predict_spans.argtypes = [P, C.c_int64, C.c_int64, C.c_int32, P, P, C.c_double, P]
     lib.slam_eval_c1c2c3.argtypes = [P, C.c_int32, P, P, C.c_int64, C.c_int32, P]
     lib.slam_sample_haar.argtypes = [P, C.c_uint64, C.c_int64, C.c_int64]
     lib.slam_get_targets.argtypes = [P, C.c_int64, C.c_int64, P]
@@ -307,6 +309,24 @@ class Context:
         count = self.n_targets - first if count is None else count
         out = np.zeros((count, 3), dtype=np.float64)
         _check(self._lib.slam_targets_c1c2c3(self._h, int(first), int(count), int(ndigits), _ptr(out)))
+        return out
+
+    def predict_spans(self, gate_coords_seq, k_max: int, first: int = 0, count: Optional[int] = None, tol: float = 2e-8) -> np.ndarray:
+        """Template size every resident target of [first, first + count) needs with the gate sequence whose Weyl coordinates are
+        ``gate_coords_seq`` (0 local, 1..k_max, k_max + 1 out of reach): ``coverage.minimal_prefix`` evaluated on the device
+        (slam_predict_spans) -- the half-spaces of the sequence's prefixes are computed here, the targets never leave the GPU."""
+        from . import coverage
+
+        g = np.asarray(gate_coords_seq, dtype=np.float64).reshape(-1, 3)
+        if not 1 <= k_max <= min(len(g), MAX_SPAN_EVAL):
+            raise ValueError(f"k_max must be 1..{min(len(g), MAX_SPAN_EVAL)}")
+        count = self.n_targets - first if count is None else count
+        point = np.ascontiguousarray(coverage.alcove_coordinates(g[:1])[0])
+        bounds = np.full((k_max, len(coverage._PATTERNS)), -np.inf)
+        for k in range(2, k_max + 1):
+            bounds[k - 1] = coverage.region(g[:k])
+        out = np.zeros(count, dtype=np.int32)
+        _check(self._lib.slam_predict_spans(self._h, int(first), int(count), int(k_max), _ptr(point), _ptr(bounds), float(tol), _ptr(out)))
         return out
 
     def eval_c1c2c3(self, gate_seq: Sequence[int], x: np.ndarray, ndigits: int = 8) -> np.ndarray:

@@ -184,6 +184,17 @@ def _ring_mul(r: int, part: Tuple[int, ...], x: Tuple[int, ...]):
 
 
 def region(gate_coords_list) -> np.ndarray:
+    """``_region`` through a small cache (a basis sweep asks for the same few circuits at every step)."""
+    g = np.asarray(gate_coords_list, dtype=np.float64).reshape(-1, 3)
+    return _region_cached(tuple(np.round(g, 12).ravel().tolist())).copy()
+
+
+@lru_cache(maxsize=4096)
+def _region_cached(flat: Tuple[float, ...]) -> np.ndarray:
+    return _region(np.array(flat).reshape(-1, 3))
+
+
+def _region(gate_coords_list) -> np.ndarray:
     """The coverage region of a circuit of these gates as 14 half-spaces in the target's alcove coordinates ``gamma``: the target is
     inside iff ``bounds[p] <= _PATTERN_ROWS[p] @ gamma`` for all p.  ``bounds[p]`` = the largest ``sum_l sum_{I_l} alpha^(l) - d`` over
     the inequalities that end in subset K_p -- found by a dynamic programme over the gates (per r, the best value for every term

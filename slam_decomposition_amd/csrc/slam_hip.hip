@@ -1477,6 +1477,31 @@ int slam_targets_c1c2c3(slam_ctx* ctx, int64_t first, int64_t count, int ndigits
     return weyl_device(ctx, ctx->targets.as<double>() + first * 32, count, ndigits, out);
 }
 
+int slam_predict_spans(slam_ctx* ctx, int64_t first, int64_t count, int k_max, const double* point, const double* bounds, double tol,
+                       int32_t* spans_out) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    if (first < 0 || count < 0 || first + count > ctx->n_targets)
+        return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    if (k_max < 1 || k_max > SLAM_MAX_SPAN_EVAL) return fail(SLAM_ERR_INVALID, "k_max must be 1..%d (got %d)", SLAM_MAX_SPAN_EVAL, k_max);
+    if (!point || (k_max > 1 && !bounds)) return fail(SLAM_ERR_INVALID, "point / bounds is NULL");
+    if (count == 0) return SLAM_OK;
+    if (!spans_out) return fail(SLAM_ERR_INVALID, "spans_out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    SpanRegions r{};
+    r.k_max = k_max;
+    r.tol = tol;
+    for (int j = 0; j < 4; ++j) r.point[j] = point[j];
+    for (int k = 2; k <= k_max; ++k)
+        for (int p = 0; p < kSpanPatterns; ++p) r.bounds[k - 1][p] = bounds[(size_t)(k - 1) * kSpanPatterns + p];
+    HIP_TRY(ctx->ev_weyl.reserve((size_t)count * sizeof(int32_t)));
+    hipLaunchKernelGGL(span_predict_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream,
+                       ctx->targets.as<double>() + first * 32, count, r, ctx->ev_weyl.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(spans_out, ctx->ev_weyl.p, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
 int slam_eval_c1c2c3(slam_ctx* ctx, int k, const int32_t* gate_seq, const double* x, int64_t M, int ndigits, double* out) {
     if (!out && M > 0) return fail(SLAM_ERR_INVALID, "out is NULL");
     std::vector<int32_t> tof((size_t)(M > 0 ? M : 0), 0);  // the loss is not wanted: any resident target will do

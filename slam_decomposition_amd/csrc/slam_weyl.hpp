@@ -162,4 +162,60 @@ __global__ void c1c2c3_kernel(const double* __restrict__ U, int64_t M, int ndigi
     if (i < M) weyl_c1c2c3(U + i * 32, ndigits, out + i * 3);
 }
 
+// ---------------------------------------------------------------------------------
+// Span predictor (replaces monodromy_range_from_target, src/slam/utils/polytopes/polytope_wrap.py:39-94, for resident targets): the
+// smallest number of leading gates of a template whose coverage set contains the target.  The host (coverage.py) turns each prefix
+// g_1 .. g_k into 14 half-spaces in the target's alcove coordinates -- the inequalities of the multiplicative eigenvalue problem for
+// SU(4) collapse to one bound per subset K -- and this kernel evaluates them: Weyl coordinates of the target (weyl_c1c2c3, 8 digits as
+// on the host), both alcove points of its class, the 14 order-statistic sums, compare.  One thread per target, HBM-bound on the 256 B
+// of the target.
+// ---------------------------------------------------------------------------------
+constexpr int kSpanPatterns = 14;
+struct SpanRegions {
+    int32_t k_max;                 // 1 .. SLAM_MAX_SPAN_EVAL
+    double tol;                    // widens (> 0) the regions, alcove units (= units of pi)
+    double point[4];               // k = 1: the alcove point of the first gate
+    double bounds[5][kSpanPatterns];  // k = 2 .. : bounds[k - 1][p] <= sum_p(gamma)  (-inf: no constraint)
+};
+
+// alcove point (decreasing, sum 0, a_1 - a_4 <= 1) of i^{2 shift} CAN(c1, c2, c3): coverage._alcove_columns
+__device__ inline void alcove_point(double c1, double c2, double c3, double shift, double (&a)[4]) {
+    double v[4] = {0.5 * (c1 + c2 - c3) + shift, 0.5 * (c1 - c2 + c3) + shift, 0.5 * (-c1 + c2 + c3) + shift, 0.5 * (-c1 - c2 - c3) + shift};
+    for (int j = 0; j < 4; ++j) v[j] -= floor(v[j]);
+    double t;
+#define SLAM_CE(i, j) { t = fmax(v[i], v[j]); v[j] = fmin(v[i], v[j]); v[i] = t; }
+    SLAM_CE(0, 1) SLAM_CE(2, 3) SLAM_CE(0, 2) SLAM_CE(1, 3) SLAM_CE(1, 2)
+#undef SLAM_CE
+    const int s = (int)rint(v[0] + v[1] + v[2] + v[3]);
+    const double e[7] = {v[0], v[1], v[2], v[3], v[0] - 1.0, v[1] - 1.0, v[2] - 1.0};
+    for (int j = 0; j < 4; ++j) a[j] = e[j + s];
+}
+
+__global__ void span_predict_kernel(const double* __restrict__ U, int64_t M, SpanRegions r, int32_t* __restrict__ spans) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double c[3];
+    weyl_c1c2c3(U + i * 32, 8, c);
+    int best = r.k_max + 1;
+    bool local = false;
+    for (int sh = 0; sh < 2; ++sh) {
+        double a[4];
+        alcove_point(c[0], c[1], c[2], sh ? 0.5 : 0.0, a);
+        local = local || (fabs(a[0]) <= 1e-8 && fabs(a[3]) <= 1e-8);
+        // sums over the subsets K (coverage._PATTERNS order): gamma_{5 - k}, k in K  ->  zero-based a[4 - k]
+        const double g1 = a[3], g2 = a[2], g3 = a[1], g4 = a[0];  // g_k = gamma_{5 - k}
+        const double sums[kSpanPatterns] = {g1, g2, g3, g4, g1 + g2, g1 + g3, g1 + g4, g2 + g3, g2 + g4, g3 + g4,
+                                            g1 + g2 + g3, g1 + g2 + g4, g1 + g3 + g4, g2 + g3 + g4};
+        const double t1 = (r.tol > 0.0 ? r.tol : 0.0) + 1e-12;
+        if (fabs(a[0] - r.point[0]) <= t1 && fabs(a[1] - r.point[1]) <= t1 && fabs(a[2] - r.point[2]) <= t1 && fabs(a[3] - r.point[3]) <= t1)
+            best = 1;
+        for (int k = 2; k <= r.k_max && k < best; ++k) {
+            bool ok = true;
+            for (int p = 0; p < kSpanPatterns; ++p) ok = ok && (sums[p] >= r.bounds[k - 1][p] - r.tol);
+            if (ok) best = k;
+        }
+    }
+    spans[i] = local ? 0 : best;
+}
+
 }  // namespace slamdev

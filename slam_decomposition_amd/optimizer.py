@@ -400,10 +400,9 @@ class TemplateOptimizer:
             ctx.decompose_list(np.nonzero(spans == k)[0], k, k_hi, [self.basis.gate_sequence(kk) for kk in range(k, k_hi + 1)], prm,
                                self.success_threshold, k_layout=k_top)
         best_loss, best_x, best_cycles = ctx.fetch_results_range(k_top, 0, len(targets))
-        self._span_losses = ctx.fetch_span_losses(0, len(targets))
+        self._span_losses = ctx.fetch_span_losses(0, len(targets)) if self._want_span_losses else None
         self._set_stats([ctx.stats()])
-        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(len(targets))]
-        return best_loss, xs, best_cycles
+        return best_loss, best_x, best_cycles  # (padded rows [n, 6 (k_top + 1)]: cut at 6 (cycles + 1) on access)
 
     def _run_batch_v2(self, targets: np.ndarray, spanning_range):
         """``_run`` for a CircuitTemplateV2 (optimizer.py:233-303 with method "L-BFGS-B" when the template has bounds, "BFGS"
@@ -724,7 +723,15 @@ class TemplateOptimizer:
         ctx0 = runtime.get_context(self.devices[0])
         need_coords = log_on or (self.basis.use_polytopes and not self._v2)
         fast = (not need_coords and not self.use_callback and not self._v2 and not self.basis.use_polytopes and self._host_method is None)
-        if not fast and isinstance(stacked, _ResidentTargets):
+        # use_polytopes with targets that were generated on the device: the template-size lookup runs there too (slam_predict_spans
+        # evaluates the coverage half-spaces of coverage.py on the resident targets) -- neither targets nor coordinates come back
+        poly_resident = (self.basis.use_polytopes and not self._v2 and not log_on and not self.use_callback and self._host_method is None
+                         and not getattr(self.basis, "mixed_order", False) and isinstance(stacked, _ResidentTargets)
+                         and len(self.devices) == 1 and getattr(self.basis, "span_rules_exact", False)
+                         and int(self.basis.maximum_span_guess) <= _ffi.MAX_SPAN_EVAL)
+        if poly_resident:
+            need_coords = False
+        elif not fast and isinstance(stacked, _ResidentTargets):
             stacked = stacked.as_array()
         # target_invariant (basis_abc.py:80-84) for the whole batch, on the device
         coords_arr = ctx0.c1c2c3(stacked) if need_coords else None
@@ -745,6 +752,13 @@ class TemplateOptimizer:
             else:
                 spans_of = [list(self.basis.get_spanning_range(stacked[0]))] * n
             best_loss, best_xs, best_cycles = self._run_batch_callback(stacked, spans_of)
+        elif poly_resident:
+            kmax = int(self.basis.maximum_span_guess)
+            self._device_sampler.fill(ctx0)
+            spans = ctx0.predict_spans([self.basis._gate_coords_all[i] for i in self.basis.gate_sequence(kmax)], kmax, 0, n).astype(np.int64)
+            if np.any(spans > kmax):
+                raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
+            best_loss, best_xs, best_cycles = self._run_batch_by_span(stacked, spans)
         elif getattr(self.basis, "mixed_order", False):
             best_loss, best_xs, best_cycles = self._run_batch_mixed_order(stacked, coords_arr)
             spans_of = [None] * n  # (the log lines come from _entries_tried)

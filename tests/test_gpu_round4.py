@@ -467,3 +467,62 @@ def test_exact_coverage_of_conversion_gain_gates_equals_the_brute_force_span_loo
     # the sweep covers the regimes: a weak gate reaches almost nothing with three applications, strong ones everything, most in two
     fr = [s[0] for s in stats.values()]
     assert min(fr) < 0.05 and max(fr) > 0.99 and any(0.2 < v < 0.95 for v in fr), stats
+
+
+def test_device_span_predictor_equals_the_host_coverage_test():
+    """slam_predict_spans (the coverage half-spaces evaluated on the resident targets) against coverage.minimal_prefix on the host, for
+    closed-form classes, general conversion-gain gates and a mixed sequence, with special targets (identity, the gates themselves,
+    CNOT, SWAP) among 20 000 Haar ones; then TemplateOptimizer(use_polytopes=True) on a DeviceHaarBatch -- the path that uses it --
+    against the host-side lookup on the same targets."""
+    import bench
+    from slam_decomposition_amd import coverage
+    from slam_decomposition_amd.basis import CircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+    from slam_decomposition_amd.sampler import DeviceHaarBatch
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    n = 20000
+    cases = {
+        "cx": [G.CXGate().to_matrix()] * 3,
+        "sqiswap": [G.RiSwapGate(0.5).to_matrix()] * 3,
+        "iswap,b,iswap": [G.RiSwapGate(1.0).to_matrix(), G.BerkeleyGate().to_matrix(), G.RiSwapGate(1.0).to_matrix()],
+        "cg52 x 5": [bench.sweep_gate(52)] * 5,
+        "cg100,cg27,sqiswap": [bench.sweep_gate(100), bench.sweep_gate(27), G.RiSwapGate(0.5).to_matrix()],
+    }
+    with _ffi.Context(0) as ctx:
+        ctx.sample_haar(31337, n)
+        T = ctx.get_targets(0, n)
+        special = [np.eye(4), G.CXGate().to_matrix(), G.SwapGate().to_matrix(), G.RiSwapGate(0.5).to_matrix(), bench.sweep_gate(52), bench.sweep_gate(100),
+                   np.kron(o.u3(0.3, 0.2, 0.1), o.u3(1.0, 0.5, 0.2))]
+        T[: len(special)] = np.stack(special)
+        ctx.set_targets(T)
+        coords = ctx.targets_c1c2c3(0, n)
+        for name, mats in cases.items():
+            g = [c1c2c3(m) for m in mats]
+            for tol in (2e-8, 5e-4):
+                dev = ctx.predict_spans(g, len(g), 0, n, tol=tol)
+                host = coverage.minimal_prefix(coords, g, len(g), tol=tol)
+                diff = np.nonzero(dev != host)[0]
+                # (a target within rounding of a face may fall either way: the two sides add the same numbers in a different order)
+                assert len(diff) <= 2 and np.all(diff >= len(special)), (name, tol, diff[:5], dev[diff[:5]], host[diff[:5]])
+            assert dev[0] == 0 and dev[6] == 0  # identity, a local gate
+        w = ctx.predict_spans([c1c2c3(cases["cx"][0])] * 3, 3, 100, 50)  # a window
+        assert np.array_equal(w, coverage.minimal_prefix(coords[100:150], [c1c2c3(cases["cx"][0])] * 3, 3, tol=2e-8))
+        with pytest.raises(_ffi.SlamHipError):
+            ctx.predict_spans([c1c2c3(cases["cx"][0])] * 3, 3, n - 10, 50)
+    # the API path: device-generated targets, use_polytopes=True -> spans predicted on the device, nothing copied back
+    basis = CircuitTemplate(base_gates=[G.ConversionGainGate(0, 0, 0.3 * np.pi, 0.12 * np.pi, 1)], maximum_span_guess=3, use_polytopes=True)
+    opt = TemplateOptimizer(basis, BasicCost(), training_restarts=16, seed=4, override_fail=True)
+    sampler = DeviceHaarBatch(seed=77, n_samples=3000)
+    loss, _, data = opt.approximate_from_distribution(sampler)
+    assert sampler._cache is None  # (the batch was not copied back)
+    spans_host = basis.minimal_spans(runtime_coords(sampler))
+    cyc = np.array([d.cycles for d in data])
+    assert np.mean(cyc == spans_host) > 0.999 and np.mean(np.asarray(loss) < 1e-8) > 0.995
+
+
+def runtime_coords(sampler):
+    from slam_decomposition_amd import runtime
+
+    return runtime.get_context(0).c1c2c3(sampler.as_array())
