@@ -22,7 +22,12 @@ not available; the membership test itself is short once the inequalities are kno
   cohomology rings of Gr(1, 4) = P^3, Gr(3, 4) and Gr(2, 4) are tiny tables (below; the Gr(2, 4) table is checked for associativity at
   import), and the invariant is the coefficient of ``q^d [point]`` in the product of the classes.  s = 2 gives 72 inequalities.
 
-Checked (tests/test_coverage.py, no GPU): every inequality holds -- and is attained to 1e-4 -- on random products in SU(4) and on
+Pinned against the reference's own data (tests/test_coverage.py::test_regions_equal_the_coverage_sets_the_reference_ships): the
+coverage sets it ships precomputed (src/slam/data/polytopes/polytope_coverage_[...].pkl, monodromy's output for 17 ConversionGainGate
+bases, circuits of up to 26 gates; their inequality rows are the fixture tests/golden/reference_coverage_polytopes.json) contain
+exactly the targets ``contains`` says, entry by entry -- the reference's monodromy coordinates are the first three alcove coordinates.
+
+Also checked (tests/test_coverage.py, no GPU): every inequality holds -- and is attained to 1e-4 -- on random products in SU(4) and on
 random ``CAN . L . CAN (. L . CAN)`` circuits; the regions reproduce every closed-form rule of ``span_rules`` (CX / iSWAP /
 sqrt(iSWAP) / B classes, ``iSWAP . L . B``, XY-type pairs) with no mismatch; sampled circuits fill the predicted regions.  On the GPU
 (tests/test_gpu_round4.py): the template size predicted for conversion-gain gates of BASELINE configs[4] equals the size the

@@ -155,3 +155,67 @@ def test_sampled_circuits_lie_inside_and_fill_the_region(gates):
     cells = np.floor(np.stack([pts[:, 0] / h, pts[:, 1] / h, (pts[:, 2] + 0.5) / h], 1)).astype(int)
     empty = [tuple(c) for c, i in zip(cells, inside) if i and tuple(c) not in occupied]
     assert inside.sum() > 20 and len(empty) <= 0.06 * inside.sum(), (inside.sum(), len(empty))
+
+
+def test_regions_equal_the_coverage_sets_the_reference_ships():
+    """The pin: tests/golden/reference_coverage_polytopes.json holds the coverage sets the reference ships as data
+    (src/slam/data/polytopes/polytope_coverage_[...].pkl -- monodromy's output, precomputed by the reference's authors for 16 gain-only
+    ConversionGainGates and one with both drives, circuits of up to 26 gates; extracted by tools/make_reference_coverage_fixture.py, which
+    reads the numbers without importing monodromy or the reference).  A target's membership in every one of the 116 entries, evaluated
+    from the reference's inequality rows in its monodromy coordinates, must equal ``coverage.contains`` for the same gate list -- for
+    every target that is not within 1e-6 of a face."""
+    import json
+    import os
+
+    from slam_decomposition_amd.gates import ConversionGainGate
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_coverage_polytopes.json")
+    ref = json.load(open(path))
+    assert len(ref) == 17
+    rng = np.random.default_rng(0)
+    t = _chamber(30000, rng)
+    # the reference's monodromy coordinates of a target in the chamber (c3 >= 0) are the first three alcove coordinates
+    mono = cov.alcove_coordinates(t)[:, :3]
+    num = lambda x: x[0] / x[1] if isinstance(x, list) else x  # noqa: E731  (Fractions are stored as [numerator, denominator])
+
+    def ref_inside(entry, tol):
+        out = np.zeros(len(mono), bool)
+        for cp in entry["convex_subpolytopes"]:
+            ok = np.ones(len(mono), bool)
+            for row in cp["inequalities"]:
+                r = [num(x) for x in row]
+                ok &= r[0] + mono @ np.array(r[1:]) >= -tol
+            for row in cp["equalities"]:
+                r = [num(x) for x in row]
+                ok &= np.abs(r[0] + mono @ np.array(r[1:])) <= 1e-9
+            out |= ok
+        return out
+
+    checked = 0
+    for name, v in ref.items():
+        gc, gg, dur = v["gates"][0]
+        gate = ConversionGainGate(0, 0, gc, gg, dur)
+        g = c1c2c3(gate.to_matrix())
+        assert v["gate_keys"] == [str(gate)]  # the reference's gate key (custom_gates.py:185-191) is ours
+        for e in v["coverage"]:
+            k = len(e["operations"])
+            assert e["operations"] == [str(gate)] * k
+            assert abs(e["cost"] - k * gate.cost()) < 1e-7 * max(k, 1)  # cost = sum of gate.cost() (polytope_wrap.py:175-176; 8-digit gate keys)
+            if k == 0:
+                continue  # the identity polytope (skipped by the reference's lookup too, polytope_wrap.py:82-84)
+            if k == 1:
+                # the gate's own class: both alcove points, as equalities
+                pts = {tuple(np.round(cov.alcove_coordinates(g, sh)[0][:3], 7)) for sh in (0.0, 0.5)}
+                got = set()
+                for cp in e["convex_subpolytopes"]:
+                    A = np.array([[num(x) for x in row[1:]] for row in cp["equalities"]])
+                    b = -np.array([num(row[0]) for row in cp["equalities"]])
+                    got.add(tuple(np.round(np.linalg.solve(A, b), 7)))
+                assert got <= pts and len(got) >= 1, (name, got, pts)
+                continue
+            mine = cov.contains(t, [g] * k, tol=0.0)
+            clear = cov.contains(t, [g] * k, tol=1e-6) == cov.contains(t, [g] * k, tol=-1e-6)
+            theirs = ref_inside(e, 0.0)
+            assert np.array_equal(mine[clear], theirs[clear]), (name, k, int((mine != theirs)[clear].sum()))
+            checked += 1
+    assert checked == 99
