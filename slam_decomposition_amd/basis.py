@@ -244,7 +244,9 @@ class MixedOrderBasisCircuitTemplate(CircuitTemplate):
     (too few restarts) stays open for the costlier entries that contain it too.
 
     Kept from the reference: the constructor checks and their errors, ``gc < gg`` ordering and unit duration of the gates,
-    ``gate_hash`` / ``coverage`` / ``scores`` / ``set_polytope`` / ``unit_cost`` / ``build(n, scaled_gate)``.  Deviation:
+    ``gate_hash`` / ``coverage`` / ``scores`` / ``set_polytope`` / ``unit_cost`` / ``build(n, scaled_gate)``.  The reference's coverage sets
+    grow until they fill the chamber (26 applications of a pi/32 gate in scripts/haar_improvements.ipynb); here they stop at
+    ``maximum_span_guess`` gates (default 5 = the longest template the optimizer kernels take), beyond which the lookup raises.  Deviation:
     ``get_spanning_range`` returns ``range(k, k + 1)`` with k the number of gates of the bound entry; the reference returns the
     entry's INDEX in the sorted list (polytope_wrap.py:94), which equals k for one basis gate and trips ``build``'s
     ``assert n_repetitions == len(gate_list)`` (basis.py:358) for several."""
@@ -252,7 +254,7 @@ class MixedOrderBasisCircuitTemplate(CircuitTemplate):
     mixed_order = True
 
     def __init__(self, base_gates, chatty_build=True, cost_1q=0, bare_cost=True, coverage_saved_memory=True,
-                 use_smush_polytope=False, maximum_span_guess=3, device=0, **kwargs):
+                 use_smush_polytope=False, maximum_span_guess=5, device=0, **kwargs):
         import itertools
 
         from .gates import ConversionGainGate

@@ -351,7 +351,7 @@ def test_mixed_order_template_binds_the_cheapest_circuit_that_reaches_each_targe
     from slam_decomposition_amd.optimizer import TemplateOptimizer
 
     pi = np.pi
-    basis = MixedOrderBasisCircuitTemplate([G.ConversionGainGate(0, 0, pi / 4, 0, 1), G.ConversionGainGate(0, 0, pi / 2, 0, 1)])
+    basis = MixedOrderBasisCircuitTemplate([G.ConversionGainGate(0, 0, pi / 4, 0, 1), G.ConversionGainGate(0, 0, pi / 2, 0, 1)], maximum_span_guess=3)
     n = 400
     with _ffi.Context(0) as ctx:
         ctx.sample_haar(4242, n - 4)
@@ -526,3 +526,32 @@ def runtime_coords(sampler):
     from slam_decomposition_amd import runtime
 
     return runtime.get_context(0).c1c2c3(sampler.as_array())
+
+
+def test_mixed_order_weak_gate_on_cphase_targets_like_the_reference_notebook():
+    """scripts/haar_improvements.ipynb cell 1 at a size the kernels take: a weak gain-only ConversionGainGate as the one basis gate of a
+    MixedOrderBasisCircuitTemplate, CPhase(pi / 2 / t) targets.  Every target is solved at exactly the template size the coverage set
+    assigns (one gate fewer fails in a brute-force run), the sizes fall as the phase shrinks, and a target beyond five gates raises the
+    lookup's error."""
+    from slam_decomposition_amd.basis import CircuitTemplate, MixedOrderBasisCircuitTemplate
+    from slam_decomposition_amd.cost_function import BasicCost
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+
+    gate = G.ConversionGainGate(0, 0, 0, np.pi / 16, 1)  # Weyl coordinates (1/16, 1/16, 0): CPhase(pi/2) = (1/4, 0, 0) takes four
+    basis = MixedOrderBasisCircuitTemplate([gate], chatty_build=False, use_smush_polytope=0)
+    cphase = lambda th: np.diag([1, 1, 1, np.exp(1j * th)]).astype(np.complex128)  # noqa: E731  (qiskit CPhaseGate)
+    sizes = []
+    for t in range(1, 9):
+        U = cphase(np.pi / 2 / t)
+        opt = TemplateOptimizer(basis, BasicCost(), training_restarts=16, seed=t)
+        d = opt.approximate_target_U(U)
+        assert d.success_label == 1 and d.cycles == len(basis.circuit_polytope.operations) == basis.cycles
+        assert abs(basis.unit_cost(d.cycles) - d.cycles * gate.cost()) < 1e-12
+        sizes.append(d.cycles)
+        if d.cycles > 1:  # one gate fewer does not reach it
+            brute = CircuitTemplate(base_gates=[gate], maximum_span_guess=d.cycles - 1)
+            b = TemplateOptimizer(brute, BasicCost(), training_restarts=16, seed=t, override_fail=True).approximate_target_U(U)
+            assert b.success_label == 0 and b.loss_result > 1e-6
+    assert sizes == sorted(sizes, reverse=True) and sizes[0] >= 3 and sizes[-1] <= 2, sizes
+    with pytest.raises(ValueError, match="did not find a polytope"):
+        TemplateOptimizer(basis, BasicCost()).approximate_target_U(G.SwapGate().to_matrix())  # 24 applications of this gate

@@ -264,7 +264,7 @@ def test_mixed_order_template_constructor_and_coverage_set():
     with pytest.raises(ValueError, match="need unique gate strings"):
         MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 4, 0, 1), ConversionGainGate(0, 0, 0, pi / 4, 1)])  # equal after gc < gg
     # sqrt(iSWAP) given with t = 2 and half the strength, iSWAP: durations become 1, gc <= gg, costs 0.5 and 1
-    b = MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 8, 0, 2), ConversionGainGate(0, 0, pi / 2, 0, 1)])
+    b = MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 8, 0, 2), ConversionGainGate(0, 0, pi / 2, 0, 1)], maximum_span_guess=3)
     assert not b.homogenous and b.use_polytopes and b.spanning_range is None and b.scores is None
     for g in b.base_gates:
         assert g.params[4] == 1 and g.params[2] <= g.params[3]
@@ -298,7 +298,7 @@ def test_mixed_order_template_constructor_and_coverage_set():
     with pytest.raises(ValueError, match="hacky substitute"):
         b.build(2, scaled_gate=ConversionGainGate(0, 0, 0, pi / 4, 1))
     h = MixedOrderBasisCircuitTemplate([ConversionGainGate(0, 0, pi / 4, 0, 1)])
-    assert h.homogenous and h.span_rules_exact and [len(e) for e in h.coverage] == [1, 2, 3]
+    assert h.homogenous and h.span_rules_exact and [len(e) for e in h.coverage] == [1, 2, 3, 4, 5]
     h.set_polytope(h.coverage[1])
     h.build(2, scaled_gate=ConversionGainGate(0, 0, 0, pi / 8, 1))
     assert h.gate_sequence() == [0, 0] and abs(h.base_gates[0].params[3] - pi / 8) < 1e-15
