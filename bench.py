@@ -73,6 +73,9 @@ SWEEP_BASES_PER_GPU = 16
 SWEEP_CPU_BASIS = 64  # m = 9/32, p = 0: the basis the CPU baseline of cfg5 runs
 
 
+PER_SPAN_WARM_STEPS = 3  # untimed steps before the single-stream per-span pass
+
+
 def sweep_gate(b: int) -> np.ndarray:
     """Basis b of the 128-gate parametric-Hamiltonian sweep (SURVEY.md §8(d) cfg 5, shaped like build_gates(),
     utils/gates/bare_candidates.py:47-69): gc = p m pi, gg = (1 - p) m pi, 16 values of m in (0, 0.5] x 8 of p in [0, 1]."""
@@ -795,7 +798,8 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
             else:
                 c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm, threshold, fetch=False)
 
-        solo_step(0)
+        for s in range(PER_SPAN_WARM_STEPS):  # untimed: the chip's clocks settle under this load (the first launches after an idle
+            solo_step(s % total_steps)        # period run 2-3 % slower: profiles/r4_solo_probe.txt)
         rows = []
         for s in range(args.per_span_steps):
             c.reset_stats()
@@ -821,6 +825,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         tot_fl = sum(r["evals"][k] * f_eval(k) for r in rows for k in (1, 2, 3))
         per_span["all"] = {"hip_event_ms_per_step": tot_ms / len(rows),
                            "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if tot_ms > 0 else None,
+                           "warm_steps": PER_SPAN_WARM_STEPS,
                            "mode": "one batch in flight, steps enqueued back to back on one stream, no result fetch in between"}
 
     # parity sample: the HIP path's answers for the targets the CPU baseline solves (same indices of the resident array, same
@@ -897,7 +902,7 @@ def main():
     ap.add_argument("--no-multi", action="store_true", help="cfg5: one library call per basis, 16 in flight (round 3) instead of slam_decompose_multi")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets of the CPU baseline sample (default 4 x host cores)")
-    ap.add_argument("--per-span-steps", type=int, default=3, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
+    ap.add_argument("--per-span-steps", type=int, default=5, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 / v2 measurements")
     ap.add_argument("--v2-only", action="store_true", help="dev: run only the secondary.v2 measurement (CircuitTemplateV2) and print it")
     ap.add_argument("--api-only", action="store_true", help="dev: run only the secondary.api measurement (TemplateOptimizer.approximate_from_distribution) and print it")

@@ -14,13 +14,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 COMMON="--workload $WL --no-cpu-baseline --no-secondary"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -- python3 bench.py --steps 20 --warmup 5 $COMMON --per-span-steps 3 > $OUT/headline_bench_under_trace.json 2> $OUT/trace_headline.err || { tail -5 $OUT/trace_headline.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -- python3 bench.py --steps 20 --warmup 5 $COMMON > $OUT/headline_bench_under_trace.json 2> $OUT/trace_headline.err || { tail -5 $OUT/trace_headline.err; exit 1; }
 cp $OUT/trace_headline/*/*_kernel_stats.csv $OUT/headline_kernel_stats.csv
 # profile-derived versions of the line's roofline figures (union of the optimizer launches' intervals in a timed repetition; the
 # single-stream launches at the end): VERDICT r3 item 1a
 python3 tools/r4_trace_summary.py $(ls $OUT/trace_headline/*/*_kernel_trace.csv | head -1) $OUT/headline_bench_under_trace.json $OUT/trace_summary.json > /dev/null
 python3 tools/trace_concurrency.py $(ls $OUT/trace_headline/*/*_kernel_trace.csv | head -1) > $OUT/headline_concurrency.txt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_single -- python3 bench.py --streams 1 --steps 6 --warmup 2 --repeats 1 $COMMON --per-span-steps 3 > $OUT/single_stream_bench_under_trace.json 2> $OUT/trace_single.err || { tail -5 $OUT/trace_single.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_single -- python3 bench.py --streams 1 --steps 6 --warmup 2 --repeats 1 $COMMON > $OUT/single_stream_bench_under_trace.json 2> $OUT/trace_single.err || { tail -5 $OUT/trace_single.err; exit 1; }
 cp $OUT/trace_single/*/*_kernel_stats.csv $OUT/single_stream_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_v2 -- python3 bench.py --v2-only > $OUT/v2_bench_under_trace.json 2> $OUT/trace_v2.err || { tail -5 $OUT/trace_v2.err; exit 1; }
 cp $OUT/trace_v2/*/*_kernel_stats.csv $OUT/v2_kernel_stats.csv

@@ -7,7 +7,7 @@ The trace is cut into BURSTS (maximal stretches with at least one kernel running
   * a timed repetition of the driver's command = a burst with steps x 3 optimizer launches (several batches in flight): the union of
     its optimizer-kernel intervals is the time the chip spent on them; `frac_union` = the line's algorithmic flops / that union --
     to be compared with `roofline.frac` (flops / wall clock of the timed region);
-  * the single-stream pass (bench.py `per_span`) = the burst with (1 + per_span_steps) x 3 launches, one batch in flight, back to
+  * the single-stream pass (bench.py `per_span`) = the burst with (warm_steps + per_span_steps) x 3 launches, one batch in flight, back to
     back: per span the mean duration of the last per_span_steps launches -- to be compared with `per_span[k].hip_event_ms`, and
     `frac_kernel` (dominant kernel, k = 1) recomputed from the trace's duration and the line's evaluations per launch.
 """
@@ -88,12 +88,13 @@ def main():
     ps = rl.get("per_span")
     if ps:
         n_solo = ps["1"]["launches"]
+        n_warm = int(ps.get("all", {}).get("warm_steps", 1))
         for b in bursts:
             ks = [x for x in b if x[2] in (1, 2, 3)]
-            if len(ks) == 3 * (n_solo + 1) and len(ks) != 3 * steps:
+            if len(ks) == 3 * (n_solo + n_warm) and len(ks) != 3 * steps:
                 solo = {}
                 for k in (1, 2, 3):
-                    dur = [(e - a) * 1e-6 for a, e, kk, _ in ks if kk == k][1:]  # the first launch of the pass is its untimed warm step
+                    dur = [(e - a) * 1e-6 for a, e, kk, _ in ks if kk == k][n_warm:]  # the first launches of the pass are its untimed warm steps
                     ms = sum(dur) / len(dur)
                     ev = ps[str(k)]["evals_per_launch"]
                     solo[str(k)] = {"trace_ms": round(ms, 4), "line_hip_event_ms": round(ps[str(k)]["hip_event_ms"], 4),
