@@ -1004,8 +1004,8 @@ def main():
                 "targets_per_step_per_gpu": m["n_per_step"],
                 "restarts": m["restarts"],
                 "span_max": 3,
-                "span_selection": ("analytic span rules (use_polytopes mode; exact template size for a single known basis gate, else a lower bound "
-                                   "from which the brute-force loop starts)") if args.span_rules else "brute force 1..3 (reference default)",
+                "span_selection": ("use_polytopes mode: every target starts at the template size its exact coverage set assigns (coverage.py: "
+                                   "the monodromy inequalities; looked up on the device, slam_predict_spans)") if args.span_rules else "brute force 1..3 (reference default)",
                 "success_threshold": m["threshold"],
                 "restart_early_exit": "first restart to finish below stop_loss wins (timing-dependent)" if args.fast_exit
                 else "ordered: lowest-index successful restart wins (reference semantics, bitwise reproducible)",
