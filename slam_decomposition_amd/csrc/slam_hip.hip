@@ -137,6 +137,13 @@ struct slam_ctx {
     hipStream_t spec_stream[2] = {nullptr, nullptr};
     hipEvent_t spec_fork = nullptr, spec_join[2] = {nullptr, nullptr};
     bool spec_attr_set[4][kGateClasses] = {};
+    // overlapped spans (decompose_overlapped): one helper context per span (own stream, own stage buffers; targets borrowed)
+    slam_ctx* helper[SLAM_MAX_SPAN_EVAL + 1] = {};
+    hipEvent_t ov_fork = nullptr, ov_join[SLAM_MAX_SPAN_EVAL + 1] = {};
+    DevBuf slot_ev;                 // (helper side) per-slot evaluation counts of its stage
+    bool slot_ev_on = false;        // (helper side) single-stage reductions write slot_ev instead of the stage's counters
+    uint64_t gates_version = 1;     // bumped by slam_set_gates
+    uint64_t helper_gates_version = 0;  // (helper side) the owner's gates_version its gate table is a copy of
     // slam_decompose_multi (this context leads the call): the sub-problems' argument blocks / epilogue arguments per span, staged
     // through pinned memory
     DevBuf mq_args;
@@ -161,6 +168,15 @@ struct slam_ctx {
         spec_loss.release();
         spec_x.release();
         spec_ev.release();
+        slot_ev.release();
+        if (ov_fork) (void)hipEventDestroy(ov_fork);
+        for (hipEvent_t e : ov_join) if (e) (void)hipEventDestroy(e);
+        for (slam_ctx* h : helper) {
+            if (!h) continue;
+            h->targets.p = nullptr;  // borrowed from this context
+            h->targets.cap = 0;
+            delete h;
+        }
         if (spec_fork) (void)hipEventDestroy(spec_fork);
         for (int j = 0; j < 2; ++j) {
             if (spec_join[j]) (void)hipEventDestroy(spec_join[j]);
@@ -182,6 +198,8 @@ int drained(slam_ctx* c, int rc) {
         (void)hipStreamSynchronize(c->stream);
         for (hipStream_t st : c->spec_stream)
             if (st) (void)hipStreamSynchronize(st);
+        for (slam_ctx* h : c->helper)
+            if (h && h->stream) (void)hipStreamSynchronize(h->stream);
         (void)hipGetLastError();
         for (auto& st : c->staged) st.valid = false;
         g_err = keep;
@@ -415,6 +433,7 @@ struct SpanLoopStep {
 
 ReduceArgs build_reduce_args(slam_ctx* c, int k, const int32_t* d_active, const slam_opt_params* prm, double exit_loss, bool merge) {
     ReduceArgs r{};
+    r.slot_ev = (!merge && c->slot_ev_on) ? c->slot_ev.as<unsigned long long>() : nullptr;
     r.item_rec = c->item_rec.as<ItemRec>();
     r.item_x = c->item_x.as<double>();
     r.exit_loss = exit_loss;
@@ -625,7 +644,7 @@ int launch_span_wave(slam_ctx* c, const WaveLoopArgs& a, int64_t count) {
     return SLAM_OK;
 }
 
-// speculative spans: one launch per span, each on its own stream, then the merge (span_spec_kernel / span_spec_merge_kernel)
+// speculative spans: one launch per span, each on its own stream, then the merge (span_spec_kernel / span_merge_kernel)
 template <int K, int GC>
 int launch_span_spec(slam_ctx* c, const WaveLoopArgs& a, int64_t count, hipStream_t stream) {
     const size_t lds = sizeof(double) * (size_t)(lds_doubles<K, GC>() + kWlLdsDoubles);
@@ -762,7 +781,27 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
                 ++side;
             }
         }
-        hipLaunchKernelGGL(span_spec_merge_kernel, dim3((unsigned)((count + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, a);
+        SpanMergeArgs mg{};
+        mg.k_min = k_min;
+        mg.k_max = k_max;
+        mg.first = (int32_t)first;
+        mg.count = (int32_t)count;
+        mg.nmax = c->result_nmax;
+        mg.threshold = success_threshold;
+        for (int k = k_min; k <= k_max; ++k) {
+            mg.loss[k] = a.spec_loss + (size_t)(k - 1) * count;
+            mg.x[k] = a.spec_x + (size_t)(k - 1) * count * c->result_nmax;
+            mg.xstride[k] = c->result_nmax;
+            mg.xn[k] = 6 * (k + 1);
+            mg.ev[k] = a.spec_ev + (size_t)(k - 1) * count * 3;
+            mg.src_ctl[k] = nullptr;  // (the stage kernels add their rounds themselves)
+        }
+        mg.ctl = a.ctl;
+        mg.best_loss = a.best_loss;
+        mg.best_x = a.best_x;
+        mg.best_cycles = a.best_cycles;
+        mg.span_loss = a.span_loss;
+        hipLaunchKernelGGL(span_merge_kernel, dim3((unsigned)((count + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, mg);
         HIP_TRY(hipGetLastError());
         n_launch = (k_max - k_min + 1) + 1;
     } else {
@@ -793,6 +832,144 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
     c->stats.kernel_launches += n_launch;
     for (int k = k_min; k <= k_max; ++k) {
         if (c->h_ctl[k].n_active <= 0 && c->h_ctl[k].evals == 0) continue;
+        c->stats.evals[k] += (int64_t)c->h_ctl[k].evals;
+        c->stats.evals_accepted[k] += (int64_t)c->h_ctl[k].evals_accepted;
+        c->stats.evals_preempted[k] += (int64_t)c->h_ctl[k].evals_preempted;
+        c->stats.wave_rounds[k] += (int64_t)c->h_ctl[k].rounds;
+        c->stats.items[k] += (int64_t)c->h_ctl[k].n_active * prm->restarts;
+    }
+    return SLAM_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------------------------
+// Medium batches: the spans of the loop side by side.  The stages of a target do not use each other's results, only the decision
+// whether they are needed (optimizer.py:301-303), and their start points are keyed by span -- so every span runs for ALL targets of
+// the window at once, each as the ordinary per-span pipeline (stage inputs, optimizer kernel, per-target reduction: what
+// slam_minimize_stage runs) on a helper context with its own stream and stage buffers, and span_merge_kernel then applies the loop's
+// bookkeeping in span order.  Results are those of the staged launches bit for bit; the work of stages the loop would not have reached
+// is wasted (booked as pre-empted evaluations), which is why this form is taken only while one call cannot fill the chip for long
+// (targets x restarts <= kOverlapMaxItems; measured, tools/r4_overlap_probe.py: CNOT 4096 x 16 2.84 -> 1.86 ms, 20 480 x 16 5.1 -> 4.9,
+// sqrt(iSWAP) 65 536 x 32 18.1 -> 16.5) or when the caller asks for it (SLAM_FLAG_OVERLAP).
+// -----------------------------------------------------------------------------------------------------------------------
+constexpr int64_t kOverlapMaxItems = 1 << 18;
+
+__global__ void iota_kernel(int32_t* out, int32_t first, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = first + (int32_t)i;
+}
+
+int decompose_overlapped(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* prm,
+                         double success_threshold, FetchReq* fetch, bool* taken) {
+    *taken = false;
+    if (prm->flags & SLAM_FLAG_STAGED) return SLAM_OK;
+    static const bool env_staged = std::getenv("SLAM_STAGED") != nullptr;
+    static const bool env_off = []{ const char* e = std::getenv("SLAM_OVERLAP"); return e && e[0] == '0'; }();
+    if (env_staged || env_off) return SLAM_OK;
+    if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED)) return SLAM_OK;
+    if (k_max <= k_min || k_max > 3 || c->trace_cap > 0) return SLAM_OK;
+    if (!(prm->flags & SLAM_FLAG_OVERLAP) && count * (int64_t)prm->restarts > kOverlapMaxItems) return SLAM_OK;
+    // helper contexts (one per span), created on first use; their targets are this context's (borrowed for the call)
+    for (int k = k_min; k <= k_max; ++k) {
+        if (!c->helper[k]) {
+            int rc = slam_ctx_create(c->device, &c->helper[k]);
+            if (rc) return rc;
+            HIP_TRY(hipEventCreateWithFlags(&c->ov_join[k], hipEventDisableTiming));
+        }
+    }
+    if (!c->ov_fork) HIP_TRY(hipEventCreateWithFlags(&c->ov_fork, hipEventDisableTiming));
+    struct Unborrow {
+        slam_ctx* c;
+        ~Unborrow() {
+            for (slam_ctx* h : c->helper)
+                if (h) {
+                    h->targets.p = nullptr;
+                    h->targets.cap = 0;
+                    h->n_targets = 0;
+                }
+        }
+    } unborrow{c};
+    *taken = true;
+    HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), c->stream));
+    HIP_TRY(hipEventRecord(c->ev_a[k_min], c->stream));
+    HIP_TRY(hipEventRecord(c->ov_fork, c->stream));
+    SpanMergeArgs mg{};
+    const int32_t* gs = gate_seqs;
+    // the spans are enqueued longest first (k_max ... k_min): each on its helper's stream
+    const int32_t* seq_of[SLAM_MAX_SPAN_EVAL + 1] = {};
+    for (int k = k_min; k <= k_max; ++k) {
+        seq_of[k] = gs;
+        gs += k;
+    }
+    for (int k = k_max; k >= k_min; --k) {
+        slam_ctx* h = c->helper[k];
+        h->targets.p = c->targets.p;
+        h->targets.cap = c->targets.cap;
+        h->n_targets = c->n_targets;
+        if (h->helper_gates_version != c->gates_version) {
+            h->gates_host = c->gates_host;
+            h->n_gates = c->n_gates;
+            for (auto& st : h->staged) st.valid = false;
+            h->helper_gates_version = c->gates_version;
+        }
+        h->cost_kind = c->cost_kind;
+        h->reserve_waves = c->reserve_waves;
+        h->stage_exit_loss = success_threshold;  // ordered early exit at the loop's threshold (optimizer.py:287)
+        h->slot_ev_on = true;
+        HIP_TRY(h->active.reserve((size_t)count * sizeof(int32_t)));
+        HIP_TRY(h->slot_ev.reserve((size_t)count * 3 * sizeof(unsigned long long)));
+        int rc = reserve_stage_buffers(h, count, k, prm);
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(h->stream, c->ov_fork, 0));
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, h->active.as<int32_t>(), (int32_t)first, count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), h->stream));
+        hipLaunchKernelGGL(set_n_active_kernel, dim3(1), dim3(1), 0, h->stream, stage_ctl(h, k), (int32_t)count);
+        HIP_TRY(hipGetLastError());
+        rc = enqueue_stage(h, k, seq_of[k], h->active.as<int32_t>(), count, nullptr, prm, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ov_join[k], h->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ov_join[k], 0));
+        mg.loss[k] = h->stage_loss.as<double>();
+        mg.x[k] = h->stage_x.as<double>();
+        mg.xstride[k] = 6 * (k + 1);
+        mg.xn[k] = 6 * (k + 1);
+        mg.ev[k] = h->slot_ev.as<unsigned long long>();
+        mg.src_ctl[k] = stage_ctl(h, k);
+    }
+    mg.k_min = k_min;
+    mg.k_max = k_max;
+    mg.first = (int32_t)first;
+    mg.count = (int32_t)count;
+    mg.nmax = c->result_nmax;
+    mg.threshold = success_threshold;
+    mg.ctl = c->counters.as<StageCtl>();
+    mg.best_loss = c->best_loss.as<double>();
+    mg.best_x = c->best_x.as<double>();
+    mg.best_cycles = c->best_cycles.as<int32_t>();
+    mg.span_loss = c->span_loss.as<double>();
+    hipLaunchKernelGGL(span_merge_kernel, dim3((unsigned)((count + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, mg);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_b[k_min], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    int rc = SLAM_OK;
+    if (fetch) {
+        rc = enqueue_fetch_n(c, c->result_nmax, first, count, *fetch);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_ctl, c->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_done, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_done));
+    if (fetch) finish_fetch(c, *fetch);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    c->stats.total_ms = ms;
+    float kms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&kms, c->ev_a[k_min], c->ev_b[k_min]));
+    c->stats.kernel_ms += kms;
+    c->stats.kernel_ms_span[k_min] += kms;  // (the spans ran side by side: the time of the whole is booked on the first one)
+    c->stats.kernel_launches += 2 * (k_max - k_min + 1) + 1;
+    for (int k = k_min; k <= k_max; ++k) {
         c->stats.evals[k] += (int64_t)c->h_ctl[k].evals;
         c->stats.evals_accepted[k] += (int64_t)c->h_ctl[k].evals_accepted;
         c->stats.evals_preempted[k] += (int64_t)c->h_ctl[k].evals_preempted;
@@ -841,6 +1018,8 @@ int decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_m
     if (!h_list && k_layout == k_max) {
         bool taken = false;
         rc = decompose_wave_loop(c, first, count, k_min, k_max, gate_seqs, prm, success_threshold, fetch, &taken);
+        if (rc || taken) return rc;
+        rc = decompose_overlapped(c, first, count, k_min, k_max, gate_seqs, prm, success_threshold, fetch, &taken);
         if (rc || taken) return rc;
     }
     const int64_t N = count;
@@ -1209,6 +1388,7 @@ int slam_set_gates(slam_ctx* ctx, const double* gates, int32_t n_gates) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->gates_host.assign(gates, gates + (size_t)n_gates * 32);
     ctx->n_gates = n_gates;
+    ++ctx->gates_version;
     for (auto& st : ctx->staged) st.valid = false;
     return SLAM_OK;
 }

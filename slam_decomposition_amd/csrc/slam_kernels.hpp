@@ -801,7 +801,7 @@ __device__ __forceinline__ void wave_stage(const WaveLoopArgs& a, int t, double*
     }
     const double stage_loss = wl.win_r >= 0 ? wl.win_loss : (double)INFINITY;
     if constexpr (SPEC) {
-        // a stage run ahead of the span loop's decision: its result and counters go to the staging rows; span_spec_merge_kernel
+        // a stage run ahead of the span loop's decision: its result and counters go to the staging rows; span_merge_kernel
         // applies the loop's bookkeeping (and books the evaluations of stages the loop would not have run as pre-empted)
         const int64_t row = (int64_t)(K - 1) * a.count + (t - a.first);
         if (lane == 0) {
@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(kWave, 1) span_wave_kernel(WaveLoopArgs a) {
 // Speculative spans (small batches that leave the chip mostly empty): the stages of the span loop do not depend on each other's
 // RESULTS -- only on whether they are needed (optimizer.py:301-303 breaks at the first span below the threshold) -- so all spans of
 // all targets start at once, one wavefront per (target, span), one launch per span on its own stream (the k = 1, 2 kernels keep their
-// own register budget: two wavefronts per SIMD beside one of k = 3), and span_spec_merge_kernel then walks every target's stage
+// own register budget: two wavefronts per SIMD beside one of k = 3), and span_merge_kernel then walks every target's stage
 // results in span order exactly as the loop would: running best with strict "<" (optimizer.py:281-284), stop at the first success.
 // Same items, same Philox start points (keyed by span), same winner rule per stage => the per-span launches' results bit for bit; a
 // lone batch takes the longest single stage instead of the sum of three.  Stages the loop would not have run are wasted work: their
@@ -876,7 +876,28 @@ __global__ void __launch_bounds__(kWave, K >= 3 ? 1 : 2) span_spec_kernel(WaveLo
     wave_stage<K, GC, K, true>(a, a.first + i, lds, best_loss, best_cycles);
 }
 
-__global__ void __launch_bounds__(kWave) span_spec_merge_kernel(WaveLoopArgs a) {
+// The span loop's bookkeeping over stage results that were produced side by side (speculative spans of small batches:
+// span_spec_kernel; overlapped spans of medium ones: one per-span optimizer launch + reduction per helper context).  Per target, in
+// span order: running best with strict "<" (optimizer.py:281-284), "Cycle (k =...)" value, stop at the first success (:301-303); the
+// evaluations of stages the loop would not have run are booked as pre-empted.
+struct SpanMergeArgs {
+    int32_t k_min, k_max;
+    int32_t first, count;            // target window; stage k's row of target first + i is i
+    int32_t nmax;
+    double threshold;
+    const double* loss[4];           // [k]: stage k's winner loss per target (INFINITY: no finite restart)
+    const double* x[4];              // [k]: its parameters, row stride xstride[k]
+    int32_t xstride[4], xn[4];       // xn[k]: valid parameters per row (6 (k + 1))
+    const unsigned long long* ev[4]; // [k]: (all, accepted, pre-empted) evaluations per target
+    const StageCtl* src_ctl[4];      // [k]: the producing stage's control block (rounds), or nullptr
+    StageCtl* ctl;                   // the call's control blocks [k]
+    double* best_loss;
+    double* best_x;
+    int32_t* best_cycles;
+    double* span_loss;
+};
+
+__global__ void __launch_bounds__(kWave) span_merge_kernel(SpanMergeArgs a) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const bool live = i < a.count;
     const int t = a.first + (live ? i : 0);
@@ -886,21 +907,21 @@ __global__ void __launch_bounds__(kWave) span_spec_merge_kernel(WaveLoopArgs a) 
     if (live)
         for (int j = 0; j < kSpanLossStride; ++j) a.span_loss[(int64_t)t * kSpanLossStride + j] = NAN;  // "span not run"
     for (int k = 1; k <= 3; ++k) {
+        const bool in = k >= a.k_min && k <= a.k_max;
         unsigned long long e_all = 0, e_acc = 0, e_pre = 0;
         int act = 0;
-        if (live && k >= a.k_min && k <= a.k_max) {
-            const int64_t row = (int64_t)(k - 1) * a.count + i;
-            const unsigned long long e0 = a.spec_ev[row * 3 + 0];
+        if (live && in) {
+            const unsigned long long e0 = a.ev[k][(int64_t)i * 3 + 0];
             e_all = e0;
             if (!done) {
-                const double sl = a.spec_loss[row];
+                const double sl = a.loss[k][i];
                 if (cyc < 0 || sl < best) {
                     best = sl;
                     cyc = k;
                 }
                 a.span_loss[(int64_t)t * kSpanLossStride + (k - 1)] = best;
-                e_acc = a.spec_ev[row * 3 + 1];
-                e_pre = a.spec_ev[row * 3 + 2];
+                e_acc = a.ev[k][(int64_t)i * 3 + 1];
+                e_pre = a.ev[k][(int64_t)i * 3 + 2];
                 act = 1;
                 done = best < a.threshold;
             } else {
@@ -913,23 +934,21 @@ __global__ void __launch_bounds__(kWave) span_spec_merge_kernel(WaveLoopArgs a) 
             e_pre += __shfl_down(e_pre, off);
             act += __shfl_down(act, off);
         }
-        if (threadIdx.x == 0 && k >= a.k_min && k <= a.k_max) {
+        if (threadIdx.x == 0 && in) {
             StageCtl* c = a.ctl + k;
             atomicAdd(&c->evals, e_all);
             atomicAdd(&c->evals_accepted, e_acc);
             atomicAdd(&c->evals_preempted, e_pre);
             atomicAdd(&c->n_active, act);
+            if (blockIdx.x == 0 && a.src_ctl[k]) atomicAdd(&c->rounds, a.src_ctl[k]->rounds);
         }
     }
     if (!live) return;
     a.best_loss[t] = best;
     a.best_cycles[t] = cyc;
-    if (cyc >= 1) {
-        const double* src = a.spec_x + ((int64_t)(cyc - 1) * a.count + i) * a.nmax;
-        for (int j = 0; j < a.nmax; ++j) a.best_x[(int64_t)t * a.nmax + j] = src[j];
-    } else {
-        for (int j = 0; j < a.nmax; ++j) a.best_x[(int64_t)t * a.nmax + j] = 0.0;
-    }
+    const int nv = cyc >= 1 ? a.xn[cyc] : 0;
+    const double* src = cyc >= 1 ? a.x[cyc] + (int64_t)i * a.xstride[cyc] : nullptr;
+    for (int j = 0; j < a.nmax; ++j) a.best_x[(int64_t)t * a.nmax + j] = j < nv ? src[j] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------
@@ -956,6 +975,8 @@ struct ReduceArgs {
     double* best_x;            // [n_targets][nmax]
     int32_t* best_cycles;      // [n_targets]
     double* span_loss;         // [n_targets][kSpanLossStride]: running best after span k at [k - 1] ("Cycle (k =...), Best Loss")
+    // overlapped spans: the slot's evaluation counts (all, accepted, pre-empted) go here instead of into ctl -- the merge books them
+    unsigned long long* slot_ev;  // [n_active][3] or nullptr
 };
 
 struct EvalCounts {
@@ -1040,7 +1061,16 @@ __device__ __forceinline__ void publish_eval_counts(StageCtl* ctl, EvalCounts ev
 __global__ void reduce_merge_kernel(ReduceArgs a) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     EvalCounts ev;
-    if (s < a.ctl->n_active) reduce_merge_slot(a, s, ev);
+    const bool live = s < a.ctl->n_active;
+    if (live) reduce_merge_slot(a, s, ev);
+    if (a.slot_ev) {
+        if (live) {
+            a.slot_ev[s * 3 + 0] = ev.all;
+            a.slot_ev[s * 3 + 1] = ev.accepted;
+            a.slot_ev[s * 3 + 2] = ev.preempted;
+        }
+        return;
+    }
     publish_eval_counts(a.ctl, ev, threadIdx.x);
 }
 

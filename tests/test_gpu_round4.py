@@ -338,7 +338,9 @@ def test_wave_loop_edge_cases_square_cost_dense_gate_single_target():
             (l0, x0, c0, n0), (l1, x1, c1, n1) = res
             assert np.array_equal(l0, l1) and np.array_equal(x0, x1) and np.array_equal(c0, c1), name
             want = (k1 - k0 + 2) if (k1 > k0 and _SPEC_ON) else 1  # speculative spans: one launch per span + the merge
-            assert n0 == (want if name != "mixed classes" else n1), (name, n0, n1)
+            if name == "mixed classes":  # not for the wave kernels: the overlapped spans of medium batches take it (2 launches per span + merge)
+                want = 2 * (k1 - k0 + 1) + 1 if os.environ.get("SLAM_OVERLAP", "1")[:1] != "0" else n1
+            assert n0 == want, (name, n0, n1)
 
 
 def test_mixed_order_template_binds_the_cheapest_circuit_that_reaches_each_target():
@@ -555,3 +557,41 @@ def test_mixed_order_weak_gate_on_cphase_targets_like_the_reference_notebook():
     assert sizes == sorted(sizes, reverse=True) and sizes[0] >= 3 and sizes[-1] <= 2, sizes
     with pytest.raises(ValueError, match="did not find a polytope"):
         TemplateOptimizer(basis, BasicCost()).approximate_target_U(G.SwapGate().to_matrix())  # 24 applications of this gate
+
+
+@pytest.mark.parametrize("basis,N,R,extra", [("cx", 3000, 16, 0), ("sqiswap", 2500, 32, 0), ("b", 1500, 24, 0), ("sqiswap", 12000, 32, "overlap")])
+def test_overlapped_spans_equal_the_staged_launches(basis, N, R, extra):
+    """Medium batches (more than the one-wavefront loop takes, at most 2^18 work items per span -- or any size with SLAM_FLAG_OVERLAP):
+    the spans of the loop run side by side for all targets, each as the ordinary per-span pipeline on a helper context, and the
+    loop's bookkeeping is applied afterwards in span order (span_merge_kernel).  Losses, parameters, cycles and the per-span running
+    best equal the span-by-span launches bit for bit; the stages the loop would not have reached show up as pre-empted evaluations."""
+    gate = {"sqiswap": G.RiSwapGate(0.5), "cx": G.CXGate(), "b": G.BerkeleyGate()}[basis].to_matrix()
+    seqs = [[0], [0, 0], [0, 0, 0]]
+    flags = _ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED
+    with _ffi.Context(0) as ctx:
+        ctx.sample_haar(909, N + 300)
+        ctx.set_gates(gate[None])
+        out = {}
+        for name, fl in (("overlap", flags | (_ffi.FLAG_OVERLAP if extra == "overlap" else 0)), ("staged", flags | _ffi.FLAG_STAGED)):
+            prm = _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=21, flags=fl)
+            ctx.reset_stats()
+            res = ctx.decompose_range(100, N, 1, 3, seqs, prm, 1e-10)
+            out[name] = res + (ctx.fetch_span_losses(100, N), ctx.stats())
+        (l0, x0, c0, s0, st0), (l1, x1, c1, s1, st1) = out["overlap"], out["staged"]
+        assert np.array_equal(l0, l1) and np.array_equal(c0, c1) and np.array_equal(x0, x1)
+        assert np.array_equal(np.isnan(s0), np.isnan(s1)) and np.array_equal(np.nan_to_num(s0), np.nan_to_num(s1))
+        assert st0["kernel_launches"] == 7 and st1["kernel_launches"] == (2 if basis == "b" else 3)
+        assert st0["items"] == st1["items"] and st0["evals"][1] == st1["evals"][1]  # same targets per stage; k = 1: nothing pre-empted
+        # every stage ran for ALL targets: more evaluations at the later spans than the loop needs, the surplus booked as pre-empted
+        if basis != "cx":  # (CNOT: every target needs all three spans -- nothing is wasted)
+            assert st0["evals"][3] > st1["evals"][3] and st0["evals_preempted"][3] > st1["evals_preempted"][3]
+        else:
+            assert st0["evals"][2] == st1["evals"][2]  # (all restarts of every target run at k = 2 on either path: none succeeds)
+        assert np.all(l0 < 1e-8)
+        # a window of two spans, and a second call on the same context (helpers reused, another gate table)
+        ctx.set_gates(G.RiSwapGate(0.5).to_matrix()[None] if basis != "sqiswap" else G.CXGate().to_matrix()[None])
+        prm = _ffi.OptParams(restarts=8, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=5, flags=flags | (_ffi.FLAG_OVERLAP if extra == "overlap" else 0))
+        a = ctx.decompose_range(0, min(2000, N), 2, 3, seqs[1:], prm, 1e-10)
+        prm.flags = flags | _ffi.FLAG_STAGED
+        b = ctx.decompose_range(0, min(2000, N), 2, 3, seqs[1:], prm, 1e-10)
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
