@@ -577,6 +577,8 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     gate_seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
     ipq = args.items_per_quad if (main and args.items_per_quad >= 0) else (3 if (small and group == 1 and n_streams > 1) else 0)
     flags = _ffi.FLAG_EARLY_EXIT | (0 if args.fast_exit else _ffi.FLAG_ORDERED)
+    if n_streams > 1:
+        flags |= _ffi.FLAG_NO_OVERLAP  # several calls in flight fill the chip: no speculative stages beside them
     prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=flags, items_per_quad=ipq)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
 

@@ -67,13 +67,16 @@ extern "C" {
                                    class) runs through the one-wavefront-per-target kernel: a single launch in
                                    which every target goes from span to span on its own -- same items, same seeds, same
                                    results bit for bit, no stage barrier (round 4).  It also forces the span-by-span order
-                                   where calls of at most two targets per CU (speculative spans) and calls of at most 2^18
+                                   where calls of at most two targets per CU (speculative spans) and calls of at most 2^17
                                    work items per span (overlapped spans) would run their spans side by side. */
 #define SLAM_FLAG_OVERLAP 8u    /* span loops: run the spans side by side for ALL targets of the call whatever its size -- one
                                    optimizer launch per span on its own stream, the loop's bookkeeping afterwards in span order.
                                    Same results bit for bit; the stages the loop would not have reached are wasted work, so this
                                    pays when the early spans cannot succeed anyway (a CNOT basis: no generic target before three
                                    gates) and the call is alone on the device.  Needs EARLY_EXIT | ORDERED, spans <= 3. */
+#define SLAM_FLAG_NO_OVERLAP 16u /* span loops: never run the spans of a MEDIUM call (at most 2^17 work items per span) side by side,
+                                   which the library does by itself otherwise -- for callers that keep several calls in flight on
+                                   the device: the chip is full then and the speculative stages only add work. */
 
 typedef struct slam_ctx slam_ctx;
 

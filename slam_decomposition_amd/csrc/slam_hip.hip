@@ -848,10 +848,10 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
 // slam_minimize_stage runs) on a helper context with its own stream and stage buffers, and span_merge_kernel then applies the loop's
 // bookkeeping in span order.  Results are those of the staged launches bit for bit; the work of stages the loop would not have reached
 // is wasted (booked as pre-empted evaluations), which is why this form is taken only while one call cannot fill the chip for long
-// (targets x restarts <= kOverlapMaxItems; measured, tools/r4_overlap_probe.py: CNOT 4096 x 16 2.84 -> 1.86 ms, 20 480 x 16 5.1 -> 4.9,
+// (targets x restarts <= kOverlapMaxItems and no SLAM_FLAG_NO_OVERLAP; measured, tools/r4_overlap_probe.py: CNOT 4096 x 16 2.84 -> 1.86 ms, 20 480 x 16 5.1 -> 4.9,
 // sqrt(iSWAP) 65 536 x 32 18.1 -> 16.5) or when the caller asks for it (SLAM_FLAG_OVERLAP).
 // -----------------------------------------------------------------------------------------------------------------------
-constexpr int64_t kOverlapMaxItems = 1 << 18;
+constexpr int64_t kOverlapMaxItems = 1 << 17;  // four times what the chip holds at once (2048 wavefronts x 16 items)
 
 __global__ void iota_kernel(int32_t* out, int32_t first, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -867,7 +867,7 @@ int decompose_overlapped(slam_ctx* c, int64_t first, int64_t count, int k_min, i
     if (env_staged || env_off) return SLAM_OK;
     if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED)) return SLAM_OK;
     if (k_max <= k_min || k_max > 3 || c->trace_cap > 0) return SLAM_OK;
-    if (!(prm->flags & SLAM_FLAG_OVERLAP) && count * (int64_t)prm->restarts > kOverlapMaxItems) return SLAM_OK;
+    if (!(prm->flags & SLAM_FLAG_OVERLAP) && ((prm->flags & SLAM_FLAG_NO_OVERLAP) || count * (int64_t)prm->restarts > kOverlapMaxItems)) return SLAM_OK;
     // helper contexts (one per span), created on first use; their targets are this context's (borrowed for the call)
     for (int k = k_min; k <= k_max; ++k) {
         if (!c->helper[k]) {

@@ -152,7 +152,7 @@ class TemplateOptimizer:
             # one blocking call at a time on the device: the spans of the loop side by side whatever the batch size (bit-equal;
             # 65 536 x 32 sqrt(iSWAP): 18.1 -> 16.8 ms); several shards in flight fill the chip by themselves
             flags=_ffi.FLAG_EARLY_EXIT | (_ffi.FLAG_ORDERED if self.deterministic else 0)
-            | (_ffi.FLAG_OVERLAP if (self.deterministic and len(self.devices) == 1 and self.auto_shards <= 1) else 0),
+            | (_ffi.FLAG_OVERLAP if (self.deterministic and len(self.devices) == 1 and self.auto_shards <= 1) else _ffi.FLAG_NO_OVERLAP),
         )
 
     def _run_batch(self, targets: np.ndarray, spanning_range: Sequence[int]):

@@ -561,7 +561,7 @@ def test_mixed_order_weak_gate_on_cphase_targets_like_the_reference_notebook():
 
 @pytest.mark.parametrize("basis,N,R,extra", [("cx", 3000, 16, 0), ("sqiswap", 2500, 32, 0), ("b", 1500, 24, 0), ("sqiswap", 12000, 32, "overlap")])
 def test_overlapped_spans_equal_the_staged_launches(basis, N, R, extra):
-    """Medium batches (more than the one-wavefront loop takes, at most 2^18 work items per span -- or any size with SLAM_FLAG_OVERLAP):
+    """Medium batches (more than the one-wavefront loop takes, at most 2^17 work items per span -- or any size with SLAM_FLAG_OVERLAP):
     the spans of the loop run side by side for all targets, each as the ordinary per-span pipeline on a helper context, and the
     loop's bookkeeping is applied afterwards in span order (span_merge_kernel).  Losses, parameters, cycles and the per-span running
     best equal the span-by-span launches bit for bit; the stages the loop would not have reached show up as pre-empted evaluations."""
