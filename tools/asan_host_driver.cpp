@@ -41,6 +41,7 @@ int main() {
     EXPECT(slam_get_targets(nullptr, 0, 1, d) == SLAM_ERR_INVALID);
     EXPECT(slam_c1c2c3(nullptr, d, 1, 8, d) == SLAM_ERR_INVALID);
     EXPECT(slam_targets_c1c2c3(nullptr, 0, 1, 8, d) == SLAM_ERR_INVALID);
+    EXPECT(slam_predict_spans(nullptr, 0, 1, 3, d, d, 0.0, i32) == SLAM_ERR_INVALID);
     EXPECT(slam_eval_c1c2c3(nullptr, 1, i32, d, 1, 8, d) == SLAM_ERR_INVALID);
     EXPECT(slam_set_gates(nullptr, d, 1) == SLAM_ERR_INVALID);
     EXPECT(slam_eval_loss_grad(nullptr, 1, i32, d, i32, 1, d, d) == SLAM_ERR_INVALID);
