@@ -595,3 +595,46 @@ def test_overlapped_spans_equal_the_staged_launches(basis, N, R, extra):
         prm.flags = flags | _ffi.FLAG_STAGED
         b = ctx.decompose_range(0, min(2000, N), 2, 3, seqs[1:], prm, 1e-10)
         assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+def test_randomized_calls_equal_the_staged_launches_whatever_path_they_take():
+    """40 random calls -- basis, window, restarts, span range, cost function, flags -- through whatever form the library picks (speculative
+    spans, the one-wavefront loop, overlapped spans, or the staged launches themselves) against SLAM_FLAG_STAGED: results bit for bit."""
+    rng = np.random.default_rng(20261004)
+    gates = {"cx": G.CXGate().to_matrix(), "sqiswap": G.RiSwapGate(0.5).to_matrix(), "b": G.BerkeleyGate().to_matrix(),
+             "cg": G.ConversionGainGate(0, 0, 0.3 * np.pi, 0.12 * np.pi, 1).to_matrix(), "iswap": G.RiSwapGate(1.0).to_matrix()}
+    paths = set()
+    with _ffi.Context(0) as c1, _ffi.Context(0) as c2, _ffi.Context(0) as c3:
+        by_kmax = {1: c1, 2: c2, 3: c3}  # (a context's resident results have ONE row width)
+        for c in by_kmax.values():
+            c.sample_haar(4711, 7000)
+        for case in range(40):
+            names = list(rng.choice(list(gates), size=int(rng.integers(1, 3)), replace=False))
+            table = np.stack([gates[n] for n in names])
+            k0 = int(rng.integers(1, 4))
+            k1 = int(rng.integers(k0, 4))
+            ctx = by_kmax[k1]
+            seqs = [[i % len(table) for i in range(k)] for k in range(k0, k1 + 1)]
+            N = int(rng.choice([1, 3, 17, 200, 513, 900, 1025, 2500, 6000]))
+            first = int(rng.integers(0, 7000 - N + 1))
+            R = int(rng.choice([1, 2, 5, 16, 17, 32]))
+            if N * R > 120000:
+                R = 16
+            cost = int(rng.choice([_ffi.COST_BASIC, _ffi.COST_SQUARE]))
+            extra = int(rng.choice([0, 0, _ffi.FLAG_OVERLAP, _ffi.FLAG_NO_OVERLAP]))
+            ctx.set_gates(table)
+            ctx.set_cost(cost)
+            res = []
+            for fl in (extra, _ffi.FLAG_STAGED):
+                prm = _ffi.OptParams(restarts=R, maxiter=400, gtol=1e-9, stop_loss=1e-13, seed=1000 + case,
+                                     flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED | fl)
+                ctx.reset_stats()
+                out = ctx.decompose_range(first, N, k0, k1, seqs, prm, 1e-10)
+                res.append(out + (ctx.fetch_span_losses(first, N), ctx.stats()["kernel_launches"]))
+            (l0, x0, c0, s0, n0), (l1, x1, c1, s1, n1) = res
+            tag = (names, N, R, k0, k1, cost, extra)
+            assert np.array_equal(l0, l1) and np.array_equal(x0, x1) and np.array_equal(c0, c1), tag
+            assert np.array_equal(np.isnan(s0), np.isnan(s1)) and np.array_equal(np.nan_to_num(s0), np.nan_to_num(s1)), tag
+            nk = k1 - k0 + 1
+            paths.add("staged" if n0 == n1 and n0 != 1 else ("wave" if n0 == 1 else ("spec" if n0 == nk + 1 else ("overlap" if n0 == 2 * nk + 1 else "?"))))
+    assert "?" not in paths and {"overlap", "staged"} <= paths and ("spec" in paths or "wave" in paths), paths
