@@ -494,12 +494,28 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
         d = one.approximate_target_U(U)
         lat.append(time.perf_counter() - t0)
     lat = sorted(lat[4:])
+    # the same call with use_polytopes=True (basis.py:95-100): every target only at the template size its coverage set assigns -- the
+    # lookup runs on the device too (slam_predict_spans), nothing but the results comes back
+    pbasis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3, use_polytopes=True, device=device)
+    ptimes, psolved = [], 0
+    for r in range(reps + 1):
+        popt = TemplateOptimizer(pbasis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True)
+        t0 = time.perf_counter()
+        ploss, _, pdata = popt.approximate_from_distribution(DeviceHaarBatch(seed=TARGET_SEED0 + 9_000_000 + r, n_samples=n_targets, device=device))
+        dt = time.perf_counter() - t0
+        if r:
+            ptimes.append(dt)
+            psolved = int((np.asarray(ploss) < SUCCESS_LOSS).sum())
+    ptimes.sort()
+    pmed = ptimes[(len(ptimes) - 1) // 2]
     return {"workload": f"TemplateOptimizer.approximate_from_distribution(DeviceHaarBatch(n_samples={n_targets})), sqrt(iSWAP) span<=3, {restarts} restarts, one blocking call",
             "value": solved / med, "unit": "decompositions/s", "wall_ms": 1e3 * med, "wall_ms_all": [round(1e3 * t, 3) for t in times],
             "solved_fraction": solved / n_targets, "kernel_ms": opt.last_stats["kernel_ms"],
             "approximate_target_U_ms": {"median": round(1e3 * lat[len(lat) // 2], 4), "min": round(1e3 * lat[0], 4), "restarts": 5,
                                         "what": "one Haar target per call, wall time of the Python call (speculative spans: all three template sizes side by side)",
-                                        "last_loss": float(d.loss_result), "last_cycles": int(d.cycles)}}
+                                        "last_loss": float(d.loss_result), "last_cycles": int(d.cycles)},
+            "use_polytopes": {"value": psolved / pmed, "unit": "decompositions/s", "wall_ms": 1e3 * pmed, "solved_fraction": psolved / n_targets,
+                              "what": "the same call with CircuitTemplate(use_polytopes=True): template sizes from the exact coverage sets, looked up on the device"}}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -929,7 +945,8 @@ def main():
     if args.api_only:
         for sh in (0, 2, 4):  # 0: the default (auto_shards = 4 same-device shards for big batches)
             r = run_api(0, shards=sh)
-            print(json.dumps({"shards": sh, "value": r["value"], "wall_ms_all": r["wall_ms_all"], "kernel_ms": r["kernel_ms"]}), flush=True)
+            print(json.dumps({"shards": sh, "value": r["value"], "wall_ms_all": r["wall_ms_all"], "kernel_ms": r["kernel_ms"],
+                              "approximate_target_U_ms": r["approximate_target_U_ms"]["median"], "use_polytopes": r["use_polytopes"]}), flush=True)
         return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):
