@@ -219,3 +219,34 @@ def test_regions_equal_the_coverage_sets_the_reference_ships():
             assert np.array_equal(mine[clear], theirs[clear]), (name, k, int((mine != theirs)[clear].sum()))
             checked += 1
     assert checked == 99
+
+
+def test_haar_volumes_of_the_regions_equal_the_volumes_the_reference_recorded():
+    """A second pin, on the measure: src/slam/data/extended_results.json holds the Haar volume monodromy computed for the coverage set of
+    k applications of six ConversionGainGates (parallel_drive_volume.py:340-348: sqrt(iSWAP) x 2 = 0.79012, sqrt(B) x 3 = 0.99581,
+    sqrt(CNOT) x 4 = 0.95988, x 5 = 0.999863, ...; fixture tests/golden/reference_haar_volumes.json).  Here: 300 000 Haar-random
+    unitaries (SciPy), the fraction ``coverage.contains`` puts inside each region -- within 4 standard errors of the recorded volume."""
+    import json
+    import os
+
+    from slam_decomposition_amd.gates import ConversionGainGate
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_haar_volumes.json")))
+    rng = np.random.default_rng(11)
+    n = 300000
+    a = _logspec_gamma(_su(4, n, rng))  # alcove points of Haar-random gates
+    coords = np.stack([a[:, 0] + a[:, 1], a[:, 0] + a[:, 2], a[:, 1] + a[:, 2]], axis=1)  # a canonical triple of the same class
+    sums = cov.target_sums(coords)
+    checked = 0
+    for name, v in ref.items():
+        g = c1c2c3(ConversionGainGate(0, 0, v["gc"], v["gg"], v["t"]).to_matrix())
+        for k, vol in v["base_vol"].items():
+            k = int(k)
+            if k == 1:
+                assert vol == 0.0  # (a single gate's class: measure zero)
+                continue
+            frac = float(cov.contains(None, [g] * k, tol=0.0, sums=sums).mean())
+            se = max(np.sqrt(max(vol * (1 - vol), 1e-9) / n), 1e-5)
+            assert abs(frac - vol) <= 4 * se + 2e-5, (name, k, frac, vol)
+            checked += 1
+    assert checked == 15

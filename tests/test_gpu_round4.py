@@ -638,3 +638,29 @@ def test_randomized_calls_equal_the_staged_launches_whatever_path_they_take():
             nk = k1 - k0 + 1
             paths.add("staged" if n0 == n1 and n0 != 1 else ("wave" if n0 == 1 else ("spec" if n0 == nk + 1 else ("overlap" if n0 == 2 * nk + 1 else "?"))))
     assert "?" not in paths and {"overlap", "staged"} <= paths and ("spec" in paths or "wave" in paths), paths
+
+
+def test_device_sampler_and_predictor_reproduce_the_recorded_haar_volumes():
+    """The measure on the device: 2^22 targets from the device Haar sampler through slam_predict_spans -- the fraction that needs at
+    most k gates must be the Haar volume the reference recorded for k applications of the gate (extended_results.json via
+    tests/golden/reference_haar_volumes.json: sqrt(iSWAP) x 2 = 0.790117, sqrt(B) x 3 = 0.995810, sqrt(CNOT) x 4 = 0.959883, ...), within
+    five standard errors (2.5e-4 at most) -- a joint check of the sampler's distribution, the device lookup and coverage.py."""
+    import json
+
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_haar_volumes.json")))
+    n = 1 << 22
+    with _ffi.Context(0) as ctx:
+        ctx.sample_haar(20261004, n)
+        for name, v in ref.items():
+            g = c1c2c3(G.ConversionGainGate(0, 0, v["gc"], v["gg"], v["t"]).to_matrix())
+            kmax = min(max(int(k) for k in v["base_vol"]), 5)
+            spans = ctx.predict_spans([g] * kmax, kmax, 0, n, tol=0.0)
+            for k, vol in v["base_vol"].items():
+                k = int(k)
+                if k > kmax:
+                    continue
+                frac = float(np.mean((spans <= k) & (spans >= 1)))
+                se = np.sqrt(max(vol * (1 - vol), 1e-9) / n)
+                assert abs(frac - vol) <= 5 * se + 1e-5, (name, k, frac, vol)

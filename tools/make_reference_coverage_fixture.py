@@ -88,5 +88,29 @@ def main():
         print(name, [(len(e["operations"]), e["cost"], len(e["convex_subpolytopes"])) for e in v["coverage"]])
 
 
+def haar_volumes():
+    """tests/golden/reference_haar_volumes.json: the Haar volumes of k-gate coverage sets the reference recorded
+    (src/slam/data/extended_results.json, written by utils/gates/parallel_drive_volume.py:340-348,407,447-451: ``base_vol`` = monodromy's
+    Haar integral of the coverage polytope of k applications of ConversionGainGate(0, 0, gc, gg, t)), with the gates' definitions
+    (parallel_drive_volume.py:91-96)."""
+    import math
+
+    src = "/root/reference/src/slam/data/extended_results.json"
+    rec = json.load(open(src))
+    gates = {  # name: (gc, gg, t)   parallel_drive_volume.py:91-96
+        "iSwap": (math.pi / 2, 0.0, 1.0), "sqiSwap": (math.pi / 2, 0.0, 0.5), "CNOT": (math.pi / 4, math.pi / 4, 1.0),
+        "sqCNOT": (math.pi / 4, math.pi / 4, 0.5), "B": (3 * math.pi / 8, math.pi / 8, 1.0), "sqB": (3 * math.pi / 8, math.pi / 8, 0.5),
+    }
+    out = {}
+    for name, per_k in rec.items():
+        gc, gg, t = gates[name]
+        out[name] = {"gc": gc, "gg": gg, "t": t, "base_vol": {k: float(v[0]) for k, v in per_k.items()}}
+    path = os.path.join(os.path.dirname(OUT), "reference_haar_volumes.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"{len(out)} gates -> {path}")
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    main()
+    haar_volumes()
