@@ -250,3 +250,33 @@ def test_haar_volumes_of_the_regions_equal_the_volumes_the_reference_recorded():
             assert abs(frac - vol) <= 4 * se + 2e-5, (name, k, frac, vol)
             checked += 1
     assert checked == 15
+
+
+def test_candidate_gate_scores_from_the_coverage_regions():
+    """candidates.py -- the sweep BASELINE configs[4] is shaped like (bare_candidates.py:47-126: every candidate gate gets a Haar score
+    and the sizes at which CNOT and SWAP are reached, from its coverage set).  For the six gates whose volumes the reference recorded
+    (extended_results.json): full coverage at the size the reference's table of those gates gives (parallel_drive_volume.py:91-96:
+    iSwap 3, sqiSwap 3, CNOT 3, sqCNOT 6, B 2, sqB 4), Haar score = sum_k k (vol_k - vol_{k-1}) of the RECORDED volumes within the
+    sample's error, CNOT / SWAP sizes; and the candidate grid itself."""
+    import json
+    import os
+
+    from slam_decomposition_amd import candidates as cd
+    from slam_decomposition_amd.gates import ConversionGainGate
+
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_haar_volumes.json")))
+    names = list(ref)
+    res = cd.score_gates([ConversionGainGate(0, 0, ref[n]["gc"], ref[n]["gg"], ref[n]["t"]) for n in names], n_samples=120000, seed=3)
+    want_cnot_swap = {"iSwap": (2, 3), "sqiSwap": (2, 3), "CNOT": (1, 3), "sqCNOT": (2, 6), "B": (2, 2), "sqB": (2, 4)}
+    for n, r in zip(names, res):
+        vols = {int(k): v for k, v in ref[n]["base_vol"].items()}
+        assert max(r["volumes"]) == max(vols), (n, r["volumes"])  # full coverage at the reference's size
+        score = sum(k * (vols[k] - vols.get(k - 1, 0.0)) for k in sorted(vols))
+        assert abs(r["haar_score"] - score) < 0.01, (n, r["haar_score"], score)
+        assert (r["cnot_score"], r["swap_score"]) == want_cnot_swap[n], (n, r["cnot_score"], r["swap_score"])
+    gates, coords = cd.build_gates()
+    assert len(gates) == sum(len(c) for c in coords) and len(coords) == 17 and coords[0] == [[0.0, 0.0, 0.0]]
+    assert cd.gate_scores(gates[0], n_samples=1000)["haar_score"] is None  # the identity reaches nothing
+    # a weak candidate (gain-only, pi/32): many applications -- CNOT at 16 (16 x 1/32 = 1/2), SWAP later, the Haar score below both
+    weak = cd.gate_scores(gates[1], n_samples=20000)
+    assert weak["cnot_score"] == 16 and weak["haar_score"] < weak["cnot_score"] < weak["swap_score"] and weak["volumes"][max(weak["volumes"])] == 1.0
