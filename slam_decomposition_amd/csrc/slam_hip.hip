@@ -666,13 +666,27 @@ int launch_span_spec_gc(slam_ctx* c, int gc, const WaveLoopArgs& a, int64_t coun
     return launch_span_spec<K, GC_DENSE>(c, a, count, stream);
 }
 
+constexpr int64_t kOverlapMaxItems = 1 << 17;  // four times what the chip holds at once (2048 wavefronts x 16 items)
+
+// would decompose_overlapped (below) take this call?
+bool overlap_eligible(const slam_ctx* c, int64_t count, int k_min, int k_max, const slam_opt_params* prm) {
+    static const bool env_staged = std::getenv("SLAM_STAGED") != nullptr;
+    static const bool env_off = []{ const char* e = std::getenv("SLAM_OVERLAP"); return e && e[0] == '0'; }();
+    if ((prm->flags & SLAM_FLAG_STAGED) || env_staged || env_off) return false;
+    if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED)) return false;
+    if (k_max <= k_min || k_max > 3 || c->trace_cap > 0) return false;
+    if (prm->flags & SLAM_FLAG_OVERLAP) return true;
+    return !(prm->flags & SLAM_FLAG_NO_OVERLAP) && count * (int64_t)prm->restarts <= kOverlapMaxItems;
+}
+
 // returns SLAM_OK and *taken = true when the call was served by the wave-loop kernel; *taken = false: not eligible (nothing enqueued)
 int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* prm,
                         double success_threshold, FetchReq* fetch, bool* taken) {
     *taken = false;
     if (prm->flags & SLAM_FLAG_STAGED) return SLAM_OK;
     static const bool env_staged = std::getenv("SLAM_STAGED") != nullptr;  // (test runs: the whole suite through the per-span launches)
-    if (env_staged) return SLAM_OK;
+    static const bool env_no_wave = []{ const char* e = std::getenv("SLAM_WAVE_LOOP"); return e && e[0] == '0'; }();  // (A/B runs)
+    if (env_staged || env_no_wave) return SLAM_OK;
     if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED)) return SLAM_OK;
     if (k_max > 3 || c->trace_cap > 0) return SLAM_OK;
     if (count > (int64_t)kWaveLoopTargetsPerSimd * 4 * c->compute_units) return SLAM_OK;
@@ -680,6 +694,10 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
     // items over the whole chip, are faster (measured, CNOT, profiles/r4_wave_probe.txt: R = 32: 1024 targets 1.34 vs 1.63 ms, 16
     // targets 1.00 vs 0.81; R = 64: 1024 targets 2.01 vs 2.41, 256 targets 1.96 vs 1.44; R = 128: 1024 targets 3.52 vs 3.25)
     if (prm->restarts > 16 && !(prm->restarts <= 64 && count * (int64_t)prm->restarts >= 32768)) return SLAM_OK;
+    // ... and with more than 16 restarts the spans side by side on the whole chip (decompose_overlapped) beat it where they may run
+    // (tools/r4_wave_vs_overlap.py, 1024 targets: R = 32 1.29 -> 1.15 ms CNOT, 1.47 -> 1.31 sqrt(iSWAP); R = 64 2.01 -> 1.67, 2.26 -> 1.57;
+    // with 16 restarts the wave kernels win: 0.90 vs 1.08, 512 targets 0.67 vs 0.75)
+    if (prm->restarts > 16 && overlap_eligible(c, count, k_min, k_max, prm)) return SLAM_OK;
     int gc = -1;
     {
         const int32_t* gs = gate_seqs;
@@ -851,8 +869,6 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
 // (targets x restarts <= kOverlapMaxItems and no SLAM_FLAG_NO_OVERLAP; measured, tools/r4_overlap_probe.py: CNOT 4096 x 16 2.84 -> 1.86 ms, 20 480 x 16 5.1 -> 4.9,
 // sqrt(iSWAP) 65 536 x 32 18.1 -> 16.5) or when the caller asks for it (SLAM_FLAG_OVERLAP).
 // -----------------------------------------------------------------------------------------------------------------------
-constexpr int64_t kOverlapMaxItems = 1 << 17;  // four times what the chip holds at once (2048 wavefronts x 16 items)
-
 __global__ void iota_kernel(int32_t* out, int32_t first, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = first + (int32_t)i;
@@ -861,13 +877,7 @@ __global__ void iota_kernel(int32_t* out, int32_t first, int64_t n) {
 int decompose_overlapped(slam_ctx* c, int64_t first, int64_t count, int k_min, int k_max, const int32_t* gate_seqs, const slam_opt_params* prm,
                          double success_threshold, FetchReq* fetch, bool* taken) {
     *taken = false;
-    if (prm->flags & SLAM_FLAG_STAGED) return SLAM_OK;
-    static const bool env_staged = std::getenv("SLAM_STAGED") != nullptr;
-    static const bool env_off = []{ const char* e = std::getenv("SLAM_OVERLAP"); return e && e[0] == '0'; }();
-    if (env_staged || env_off) return SLAM_OK;
-    if (!(prm->flags & SLAM_FLAG_EARLY_EXIT) || !(prm->flags & SLAM_FLAG_ORDERED)) return SLAM_OK;
-    if (k_max <= k_min || k_max > 3 || c->trace_cap > 0) return SLAM_OK;
-    if (!(prm->flags & SLAM_FLAG_OVERLAP) && ((prm->flags & SLAM_FLAG_NO_OVERLAP) || count * (int64_t)prm->restarts > kOverlapMaxItems)) return SLAM_OK;
+    if (!overlap_eligible(c, count, k_min, k_max, prm)) return SLAM_OK;
     // helper contexts (one per span), created on first use; their targets are this context's (borrowed for the call)
     for (int k = k_min; k <= k_max; ++k) {
         if (!c->helper[k]) {
