@@ -518,6 +518,33 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
                               "what": "the same call with CircuitTemplate(use_polytopes=True): template sizes from the exact coverage sets, looked up on the device"}}
 
 
+def run_medium_call(local_rank: int, n_targets: int = 4096, restarts: int = 16, reps: int = 9):
+    """secondary.medium_call: ONE call of a medium batch (CNOT, 4096 x 16: beyond the wave kernels, far from filling the chip for long),
+    alone on the device -- the spans of its loop side by side (overlapped spans, the library's own choice at this size) against the
+    span-by-span launches (SLAM_FLAG_STAGED); same results bit for bit (tests/test_gpu_round4.py)."""
+    from slam_decomposition_amd import _ffi
+
+    ctx = _ffi.Context(local_rank % max(1, _ffi.device_count()))
+    ctx.set_gates(gate_table("cx"))
+    ctx.sample_haar(TARGET_SEED0 + 77, n_targets)
+    seqs = [[0], [0, 0], [0, 0, 0]]
+    out = {}
+    for name, extra in (("overlapped_spans", 0), ("span_by_span", _ffi.FLAG_STAGED)):
+        prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED | extra)
+        ts = []
+        for r in range(reps + 2):
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            loss, _, _ = ctx.decompose_range(0, n_targets, 1, 3, seqs, prm, 1e-10)
+            ts.append(time.perf_counter() - t0)
+        st = ctx.stats()
+        med = sorted(ts[2:])[reps // 2]
+        out[name] = {"wall_ms": round(1e3 * med, 4), "kernel_launches": st["kernel_launches"], "solved_fraction": float((loss < SUCCESS_LOSS).mean()),
+                     "roofline_frac": sum(st["evals"][k] * f_eval(k) for k in (1, 2, 3)) / med / 1e12 / PEAK_FP64_VALU_TFLOPS}
+    ctx.close()
+    return {"workload": f"CNOT span<=3, {n_targets} Haar targets x {restarts} restarts, one blocking call alone on the device", **out}
+
+
 # ------------------------------------------------------------------------------------------------
 def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool, group_arg: int = 0):
     """Run `warmup` untimed + `steps` timed steps of one workload; returns the dict of measurements."""
@@ -987,6 +1014,7 @@ def main():
         if rank == 0 and not os.environ.get("SLAM_BENCH_TEST_STUB"):
             secondary["v2"] = run_v2(rank, local_rank)
             secondary["api"] = run_api(local_rank)
+            secondary["medium_call"] = run_medium_call(local_rank)
 
     rank_devices = gather_strings(comm, rank, world, f"{m['dev_name'].strip()} cu={m['cus']} dev={local_rank}")
     if rank == 0:
