@@ -76,6 +76,21 @@ SWEEP_CPU_BASIS = 64  # m = 9/32, p = 0: the basis the CPU baseline of cfg5 runs
 PER_SPAN_WARM_STEPS = 3  # untimed steps before the single-stream per-span pass
 
 
+def _batches_in_flight(items_per_stage: int, span_rules: bool) -> int:
+    """Library calls kept in flight per GPU.  Measured on MI355X (sqrt(iSWAP) x 32 restarts, equal total work, tools/r4_strong_regime.sh;
+    decompositions/s relative to 65 536 targets x 5 in flight): 8192 targets -- the per-GPU batch of `--scaling strong` on 8 GPUs --
+    x 8 / 12 / 16 in flight 0.80 / 0.84 / 0.88, 16 384 x 8 / 12 0.93 / 0.95, 32 768 x 5 / 8 0.96 / 0.98."""
+    if span_rules:
+        return 8
+    if items_per_stage <= (1 << 18):
+        return 16
+    if items_per_stage <= (1 << 19):
+        return 12
+    if items_per_stage <= (1 << 20):
+        return 8
+    return 5
+
+
 def sweep_gate(b: int) -> np.ndarray:
     """Basis b of the 128-gate parametric-Hamiltonian sweep (SURVEY.md §8(d) cfg 5, shaped like build_gates(),
     utils/gates/bare_candidates.py:47-69): gc = p m pi, gg = (1 - p) m pi, 16 values of m in (0, 0.5] x 8 of p in [0, 1]."""
@@ -590,7 +605,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     mq = sweep and not (main and args.span_rules) and not (main and args.no_multi)
     if mq:
         group = min(args.group if (main and args.group) else 8, SWEEP_BASES_PER_GPU, steps)
-    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else (8 if (n_per_step * restarts < (1 << 20) or (main and args.span_rules)) else 5)))
+    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else _batches_in_flight(n_per_step * restarts, main and args.span_rules)))
     n_streams = max(1, min(n_streams, (steps + group - 1) // group))
     ctxs = [_ffi.Context(device) for _ in range(n_streams * (group if mq else 1))]
     dev_name, cus, _ = ctxs[0].device_info()
@@ -926,7 +941,7 @@ def main():
     ap.add_argument("--streams", type=int, default=None,
                     help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 5 otherwise "
                          "(measured on cfg3: 3 -> 2.95e6, 4 -> 3.0e6, 5 -> 3.19e6, 6 -> 3.20e6 decompositions/s; batches below 2^20 items per span, "
-                         "e.g. the cfg4 shard: 8 -- round 4, tools/r4_cfg4_sweep.sh: 5 -> 1.03e7, 8 -> 1.16e7)")
+                         "e.g. the cfg4 shard: 8 -- round 4, tools/r4_cfg4_sweep.sh: 5 -> 1.03e7, 8 -> 1.16e7; by batch size up to 16: _batches_in_flight)")
     ap.add_argument("--group", type=int, default=0,
                     help="small batches: consecutive steps handed to the library as one call = one device-side work queue per span "
                          "(default 20 for cfg2-sized batches, 1 otherwise)")
