@@ -368,7 +368,7 @@ def make_comm(rank: int, world: int, local_rank: int):
     return comm
 
 
-def run_v2(rank: int, local_rank: int, steps: int = 128, warmup: int = 16, n_targets: int = 4096, restarts: int = 16, n_streams: int = 4, group: int = 16,
+def run_v2(rank: int, local_rank: int, steps: int = 512, warmup: int = 32, n_targets: int = 4096, restarts: int = 16, n_streams: int = 8, group: int = 32,
            base_gate=None, gate_desc: str = "RiSwapGate"):
     """secondary.v2: CircuitTemplateV2(base_gates=[RiSwapGate]) -- every gate instance with its own free alpha -- SquareCost,
     spans 1..3, `n_targets` Haar targets x `restarts` restarts per step.  The span loop is the one TemplateOptimizer runs for a
