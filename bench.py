@@ -376,8 +376,9 @@ def run_v2(rank: int, local_rank: int, steps: int = 512, warmup: int = 32, n_tar
     step.  Like the configs[1]-sized steps of the fixed-gate path, `group` consecutive steps (windows of one resident array) go
     to the library as ONE call -- one device-side work queue per span over all their items -- on `n_streams` host threads /
     contexts / streams (measured, MI355X: one step per call 2.5e6 decompositions/s / 0.19 of peak, 8 per call 6.4e6 / 0.31; round 4,
-    tools/r4_v2_sweep.sh: 64 steps at 8 per call x 4 in flight 6.2e6 / 0.31, 128 steps at 16 x 4 7.6e6 / 0.36 (the default now), 8 x 8
-    6.8e6 / 0.33, 32 x 2 7.3e6 / 0.34, 256 steps at 32 x 4 7.7e6 / 0.345)."""
+    tools/r4_v2_sweep.sh: 64 steps at 8 per call x 4 in flight 6.2e6 / 0.31, 128 steps at 16 x 4 7.6e6 / 0.36, 8 x 8
+    6.8e6 / 0.33, 32 x 2 7.3e6 / 0.34, 256 steps at 32 x 4 7.7e6 / 0.345; tools/r4_v2_sweep2.sh: 512 steps at 16 x 8 8.1e6 / 0.37, at 32 x 8
+    8.3e6 / 0.37 (the default now: a 0.25 s region with eight calls per stream instead of two))."""
     from slam_decomposition_amd import _ffi
     from slam_decomposition_amd.basisv2 import CircuitTemplateV2
     from slam_decomposition_amd.gates import RiSwapGate
