@@ -499,6 +499,26 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
             assert len(data) == n_targets and data[n_targets - 1].cycles in (2, 3)
     times.sort()
     med = times[(len(times) - 1) // 2]
+    # the same method on a sampler of FIVE windows (327 680 targets): successive 65 536-target windows on helper contexts, five in
+    # flight (TemplateOptimizer._run_batch_windows) -- the drop-in method at the rate of the bench's own batches in flight
+    big_n = 5 * n_targets
+    btimes, bsolved = [], 0
+    for r in range(reps + 1):
+        bopt = TemplateOptimizer(basis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True)
+        t0 = time.perf_counter()
+        bloss, _, bdata = bopt.approximate_from_distribution(DeviceHaarBatch(seed=TARGET_SEED0 + 9_500_000 + r, n_samples=big_n, device=device))
+        dt = time.perf_counter() - t0
+        if r:
+            btimes.append(dt)
+            bsolved = int((np.asarray(bloss) < SUCCESS_LOSS).sum())
+            assert len(bdata) == big_n and bdata[big_n - 1].cycles in (2, 3)
+    btimes.sort()
+    bmed = btimes[(len(btimes) - 1) // 2]
+    api_large = {"workload": f"TemplateOptimizer.approximate_from_distribution(DeviceHaarBatch(n_samples={big_n})), sqrt(iSWAP) span<=3, {restarts} restarts: "
+                             f"one call, {bopt.windows_in_flight} windows of {bopt.WINDOW_TARGETS} targets in flight",
+                 "value": bsolved / bmed, "unit": "decompositions/s", "wall_ms": 1e3 * bmed, "wall_ms_all": [round(1e3 * t, 3) for t in btimes],
+                 "solved_fraction": bsolved / big_n, "windows": len(bopt.last_stats_per_device)}
+    del bdata, bloss
     # the reference's atomic call (optimizer.py:65-119): ONE target, the reference's default 5 restarts, spans 1..3 -- latency
     from slam_decomposition_amd.sampler import random_unitary
 
@@ -531,7 +551,7 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
                                         "what": "one Haar target per call, wall time of the Python call (speculative spans: all three template sizes side by side)",
                                         "last_loss": float(d.loss_result), "last_cycles": int(d.cycles)},
             "use_polytopes": {"value": psolved / pmed, "unit": "decompositions/s", "wall_ms": 1e3 * pmed, "solved_fraction": psolved / n_targets,
-                              "what": "the same call with CircuitTemplate(use_polytopes=True): template sizes from the exact coverage sets, looked up on the device"}}
+                              "what": "the same call with CircuitTemplate(use_polytopes=True): template sizes from the exact coverage sets, looked up on the device"}}, api_large
 
 
 def run_medium_call(local_rank: int, n_targets: int = 4096, restarts: int = 16, reps: int = 9):
@@ -986,10 +1006,9 @@ def main():
         print(json.dumps(run_v2(0, 0, **kw)), flush=True)  # (dev: SLAM_V2_STEPS / _GROUP / _STREAMS / _TARGETS override the defaults)
         return
     if args.api_only:
-        for sh in (0, 2, 4):  # 0: the default (auto_shards = 4 same-device shards for big batches)
-            r = run_api(0, shards=sh)
-            print(json.dumps({"shards": sh, "value": r["value"], "wall_ms_all": r["wall_ms_all"], "kernel_ms": r["kernel_ms"],
-                              "approximate_target_U_ms": r["approximate_target_U_ms"]["median"], "use_polytopes": r["use_polytopes"]}), flush=True)
+        r, big = run_api(0)
+        print(json.dumps({"value": r["value"], "wall_ms_all": r["wall_ms_all"], "kernel_ms": r["kernel_ms"],
+                          "approximate_target_U_ms": r["approximate_target_U_ms"]["median"], "use_polytopes": r["use_polytopes"], "api_large": big}), flush=True)
         return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):
@@ -1029,7 +1048,7 @@ def main():
                                                    "kernel_launches_per_step": s3["st"]["kernel_launches"] / 40}
         if rank == 0 and not os.environ.get("SLAM_BENCH_TEST_STUB"):
             secondary["v2"] = run_v2(rank, local_rank)
-            secondary["api"] = run_api(local_rank)
+            secondary["api"], secondary["api_large"] = run_api(local_rank)
             secondary["medium_call"] = run_medium_call(local_rank)
 
     rank_devices = gather_strings(comm, rank, world, f"{m['dev_name'].strip()} cu={m['cus']} dev={local_rank}")

@@ -78,6 +78,11 @@ extern "C" {
                                    which the library does by itself otherwise -- for callers that keep several calls in flight on
                                    the device: the chip is full then and the speculative stages only add work. */
 
+#define SLAM_FLAG_NO_EXTERIOR 32u /* fixed-gate templates: CircuitTemplate(no_exterior_1q=True), src/slam/basis.py:57,154,165 -- the
+                                   template is G_k K_{k-1} ... K_1 G_1: the six parameters of layer 0 and of layer k are pinned at zero
+                                   (U3(0, 0, 0) = 1; start values and gradient components zeroed), so the optimisation runs over the
+                                   6 (k - 1) interior parameters; x rows keep the 6 (k + 1) layout with zeros in the pinned places. */
+
 typedef struct slam_ctx slam_ctx;
 
 typedef struct slam_opt_params {
@@ -107,7 +112,11 @@ typedef struct slam_stats {
     int64_t evals[SLAM_MAX_SPAN_EVAL + 1]; /* fused loss+grad evaluations per span k (index k) */
     int64_t items[SLAM_MAX_SPAN_EVAL + 1]; /* (target, seed) work items per span k */
     double total_ms;          /* HIP-event time of the last slam_decompose / slam_minimize_stage */
-    double kernel_ms_span[SLAM_MAX_SPAN_EVAL + 1]; /* kernel_ms split per span k */
+    double kernel_ms_span[SLAM_MAX_SPAN_EVAL + 1]; /* per span k (index k >= 1): HIP-event time of span k's optimizer launches.  Span-by-span
+                                                      calls: they add up to kernel_ms.  Calls that run their spans side by side
+                                                      (speculative / overlapped spans): each span's own launch -- overlapping in time, so
+                                                      their sum exceeds kernel_ms.  Index 0: time of launches that cover SEVERAL spans (the
+                                                      one-wavefront-per-target loop), for which no per-span split exists. */
     int64_t wave_rounds[SLAM_MAX_SPAN_EVAL + 1];   /* lock-step evaluation rounds summed over wavefronts, per span:
                                                       evals / (16 * wave_rounds) = fraction of quads that held an item */
     /* split of evals[k]: evaluations whose point was accepted (a restart's initial point or an Armijo-accepted

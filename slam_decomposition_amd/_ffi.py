@@ -26,6 +26,7 @@ FLAG_ORDERED = 2  # with EARLY_EXIT: the lowest-index successful restart wins (r
 FLAG_STAGED = 4  # span loops: never use the one-wavefront-per-target kernel (small batches)
 FLAG_OVERLAP = 8  # SLAM_FLAG_OVERLAP: the spans of a loop side by side whatever the call's size
 FLAG_NO_OVERLAP = 16  # SLAM_FLAG_NO_OVERLAP: not even for medium calls (several calls in flight on the device)
+FLAG_NO_EXTERIOR = 32  # SLAM_FLAG_NO_EXTERIOR: CircuitTemplate(no_exterior_1q=True) -- layers 0 and k pinned at the identity
 MAX_MAXITER = 4000
 V2_MAX_SPAN = 5
 OP_SUM, OP_MAX, OP_MIN = 0, 2, 3

@@ -35,8 +35,6 @@ class CircuitTemplate(VariationalTemplate):
             edge_params = [[(0, 1)]]
         if n_qubits != 2:
             raise NotImplementedError("the HIP template optimizer handles 2-qubit templates only")
-        if no_exterior_1q:
-            raise NotImplementedError("no_exterior_1q=True is not implemented on the HIP path")
         for el in edge_params:
             for e in el:
                 if tuple(e) != (0, 1):
@@ -101,7 +99,23 @@ class CircuitTemplate(VariationalTemplate):
 
     @property
     def n_params(self) -> int:
-        return 6 * (self.cycles + 1)
+        # basis.py:154,165: without the exterior 1Q gates the template is G_k K_{k-1} ... K_1 G_1 -- 6 (k - 1) parameters
+        return 6 * (self.cycles - 1) if self.no_exterior_1q else 6 * (self.cycles + 1)
+
+    def param_slice(self, cycles: int) -> slice:
+        """Where the template's parameters sit in a device row of 6 (k + 1) values (layer-major): all of it, or -- with
+        ``no_exterior_1q`` -- the interior layers 1 .. k - 1 (the device pins layers 0 and k at zero: SLAM_FLAG_NO_EXTERIOR)."""
+        return slice(6, 6 * cycles) if self.no_exterior_1q else slice(0, 6 * (cycles + 1))
+
+    def device_vector(self, Xk, cycles=None) -> np.ndarray:
+        """``Xk`` ([n_params] or [M, n_params]) in the device's 6 (k + 1) layout (zeros in the pinned exterior layers)."""
+        k = self.cycles if cycles is None else int(cycles)
+        Xk = np.atleast_2d(np.asarray(Xk, dtype=np.float64))
+        if not self.no_exterior_1q:
+            return Xk
+        full = np.zeros((Xk.shape[0], 6 * (k + 1)))
+        full[:, 6 : 6 * k] = Xk
+        return full
 
     def get_spanning_range(self, target_u):
         """basis.py:95-100: the brute-force range, or -- with polytopes -- only the template size the target
@@ -153,7 +167,7 @@ class CircuitTemplate(VariationalTemplate):
         ctx.set_gates(self.gate_matrices)
         if ctx.n_targets == 0:
             ctx.set_targets(np.eye(4, dtype=np.complex128)[None])
-        w, _ = ctx.eval_unitary(self.gate_sequence(), Xk)
+        w, _ = ctx.eval_unitary(self.gate_sequence(), self.device_vector(Xk))
         return w[0]
 
     def parameter_guess(self, t=0):
@@ -173,6 +187,13 @@ class CircuitTemplate(VariationalTemplate):
             raise ValueError(f"expected {self.n_params} parameters, got {len(Xk)}")
         out = []
         seq = self.gate_sequence()
+        if self.no_exterior_1q:
+            for j in range(1, self.cycles + 1):
+                out.append(("gate", self.base_gates[seq[j - 1]], (0, 1)))
+                if j < self.cycles:
+                    out.append(("u", 0, tuple(Xk[6 * (j - 1) : 6 * (j - 1) + 3])))
+                    out.append(("u", 1, tuple(Xk[6 * (j - 1) + 3 : 6 * j])))
+            return out
         for j in range(self.cycles + 1):
             if j > 0:
                 out.append(("gate", self.base_gates[seq[j - 1]], (0, 1)))

@@ -56,6 +56,42 @@ class DataDictEntry:
     cycles: int
 
 
+class RowBlocks:
+    """The rows of several equally wide 2-D blocks seen as one [n, width] array without copying them together: row ``i`` of the
+    whole is a row of the block that holds it.  What ``TargetDataList`` needs of an array -- ``len``, ``ndim``, ``shape``, ``[i]`` --
+    plus ``as_array()`` for readers that want the real thing."""
+
+    ndim = 2
+
+    def __init__(self, blocks):
+        self._blocks = [np.asarray(b) for b in blocks]
+        self._starts = np.cumsum([0] + [len(b) for b in self._blocks])
+        widths = {b.shape[1] for b in self._blocks}
+        if len(widths) > 1:
+            raise ValueError("RowBlocks: blocks of different widths")
+
+    def __len__(self):
+        return int(self._starts[-1])
+
+    @property
+    def shape(self):
+        return (len(self), self._blocks[0].shape[1] if self._blocks else 0)
+
+    def __getitem__(self, i):
+        if isinstance(i, tuple):
+            return self[i[0]][i[1:] if len(i) > 2 else i[1]]
+        j = int(i)
+        if j < 0:
+            j += len(self)
+        if not 0 <= j < len(self):
+            raise IndexError("row index out of range")
+        b = int(np.searchsorted(self._starts, j, side="right")) - 1
+        return self._blocks[b][j - int(self._starts[b])]
+
+    def as_array(self) -> np.ndarray:
+        return np.concatenate(self._blocks) if self._blocks else np.zeros((0, 0))
+
+
 class TargetDataList(Sequence):
     """``target_data`` of a big batch: the list of ``DataDictEntry`` that ``approximate_from_distribution`` returns
     (optimizer.py:180-186), materialised on access.  Holds the batch's result arrays -- labels, losses, the padded
@@ -81,7 +117,8 @@ class TargetDataList(Sequence):
             c = int(self._cycles[i])
             row = self._x[i]
             if self._width_of is not None:
-                row = row[: self._width_of(c)]
+                w = self._width_of(c)
+                row = row[w] if isinstance(w, slice) else row[:w]
             e = DataDictEntry(int(self._labels[i]), float(self._losses[i]), row, c)
             self._cache[i] = e
         return e

@@ -326,7 +326,8 @@ int build_minimize_args(slam_ctx* c, const StageLaunch& sl, MinimizeArgs<K>& a) 
     a.exit_loss = sl.exit_loss;
     a.seed = prm->seed;
     a.target_base = prm->target_base;
-    a.flags = prm->flags & (SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED);  // (the upper bits are internal: kFlagTrace)
+    a.flags = prm->flags & (SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED);  // (the upper bits are internal: kFlagTrace, kFlagNoExterior)
+    if (prm->flags & SLAM_FLAG_NO_EXTERIOR) a.flags |= kFlagNoExterior;
     a.items_per_quad = prm->items_per_quad;
     a.cost_kind = c->cost_kind;
     a.solved = c->solved.as<int32_t>();
@@ -762,7 +763,7 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
     // -- 256 + 304 registers -- and the two forms tie: 0.94 / 0.89 ms CNOT, 1.14 / 1.18 ms sqrt(iSWAP), where k = 3 is mostly wasted)
     const bool spec = k_max > k_min && !env_no_spec && count <= 2 * (int64_t)c->compute_units;
     int n_launch = 1;
-    HIP_TRY(hipEventRecord(c->ev_a[k_min], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_a[0], c->stream));  // bracket 0: the whole call's optimizer work (kernel_ms)
     int rc;
     if (spec) {
         HIP_TRY(c->spec_loss.reserve(sizeof(double) * 3 * (size_t)count));
@@ -787,12 +788,14 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
                 st = c->spec_stream[side];
                 HIP_TRY(hipStreamWaitEvent(st, c->spec_fork, 0));
             }
+            HIP_TRY(hipEventRecord(c->ev_a[k], st));  // span k's own launch (the spans overlap in time: kernel_ms_span[k])
             switch (k) {
                 case 1: rc = launch_span_spec_gc<1>(c, gc, a, count, st); break;
                 case 2: rc = launch_span_spec_gc<2>(c, gc, a, count, st); break;
                 default: rc = launch_span_spec_gc<3>(c, gc, a, count, st); break;
             }
             if (rc) return rc;
+            HIP_TRY(hipEventRecord(c->ev_b[k], st));
             if (k != k_max) {
                 HIP_TRY(hipEventRecord(c->spec_join[side], st));
                 HIP_TRY(hipStreamWaitEvent(c->stream, c->spec_join[side], 0));
@@ -830,7 +833,7 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
         else rc = launch_span_wave<GC_DENSE>(c, a, count);
         if (rc) return rc;
     }
-    HIP_TRY(hipEventRecord(c->ev_b[k_min], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_b[0], c->stream));
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     if (fetch) {
         rc = enqueue_fetch_n(c, c->result_nmax, first, count, *fetch);
@@ -844,9 +847,18 @@ int decompose_wave_loop(slam_ctx* c, int64_t first, int64_t count, int k_min, in
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
     c->stats.total_ms = ms;
     float kms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&kms, c->ev_a[k_min], c->ev_b[k_min]));
+    HIP_TRY(hipEventElapsedTime(&kms, c->ev_a[0], c->ev_b[0]));
     c->stats.kernel_ms += kms;
-    c->stats.kernel_ms_span[k_min] += kms;  // (one launch for all spans: its time is booked on the first one)
+    if (spec) {
+        // one launch per span, side by side: every span's own bracket (they overlap: their sum exceeds kernel_ms)
+        for (int k = k_min; k <= k_max; ++k) {
+            float sk = 0.f;
+            HIP_TRY(hipEventElapsedTime(&sk, c->ev_a[k], c->ev_b[k]));
+            c->stats.kernel_ms_span[k] += sk;
+        }
+    } else {
+        c->stats.kernel_ms_span[0] += kms;  // ONE launch for all spans: no per-span split exists -- booked under index 0
+    }
     c->stats.kernel_launches += n_launch;
     for (int k = k_min; k <= k_max; ++k) {
         if (c->h_ctl[k].n_active <= 0 && c->h_ctl[k].evals == 0) continue;
@@ -901,7 +913,7 @@ int decompose_overlapped(slam_ctx* c, int64_t first, int64_t count, int k_min, i
     *taken = true;
     HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), c->stream));
-    HIP_TRY(hipEventRecord(c->ev_a[k_min], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_a[0], c->stream));  // bracket 0: the whole call's optimizer work (kernel_ms)
     HIP_TRY(hipEventRecord(c->ov_fork, c->stream));
     SpanMergeArgs mg{};
     const int32_t* gs = gate_seqs;
@@ -960,7 +972,7 @@ int decompose_overlapped(slam_ctx* c, int64_t first, int64_t count, int k_min, i
     mg.span_loss = c->span_loss.as<double>();
     hipLaunchKernelGGL(span_merge_kernel, dim3((unsigned)((count + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, mg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_b[k_min], c->stream));
+    HIP_TRY(hipEventRecord(c->ev_b[0], c->stream));
     HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
     int rc = SLAM_OK;
     if (fetch) {
@@ -975,9 +987,15 @@ int decompose_overlapped(slam_ctx* c, int64_t first, int64_t count, int k_min, i
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
     c->stats.total_ms = ms;
     float kms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&kms, c->ev_a[k_min], c->ev_b[k_min]));
+    HIP_TRY(hipEventElapsedTime(&kms, c->ev_a[0], c->ev_b[0]));
     c->stats.kernel_ms += kms;
-    c->stats.kernel_ms_span[k_min] += kms;  // (the spans ran side by side: the time of the whole is booked on the first one)
+    for (int k = k_min; k <= k_max; ++k) {
+        // every span's own optimizer launch, bracketed on its helper's stream by enqueue_stage (the spans overlap in time: the sum of
+        // kernel_ms_span exceeds kernel_ms -- ADVICE r4: the whole used to be booked on the first span)
+        float sk = 0.f;
+        HIP_TRY(hipEventElapsedTime(&sk, c->helper[k]->ev_a[k], c->helper[k]->ev_b[k]));
+        c->stats.kernel_ms_span[k] += sk;
+    }
     c->stats.kernel_launches += 2 * (k_max - k_min + 1) + 1;
     for (int k = k_min; k <= k_max; ++k) {
         c->stats.evals[k] += (int64_t)c->h_ctl[k].evals;
@@ -1875,6 +1893,8 @@ struct V2Stage {
     const slam_opt_params* prm;
 };
 
+constexpr int kV2HmemWavesPerCu = 8;  // wavefronts per CU whose inverse Hessian lives in device memory (v2_hmem slices)
+
 template <int K, int QN, int GQ, bool FREE>
 int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
     const size_t lds = v2_lds_bytes<K, QN>();
@@ -1930,7 +1950,9 @@ int v2_launch_minimize_gq(slam_ctx* c, const V2Stage& sgt) {
     // persistent wavefronts: never more than can be resident; every quad pulls items from the stage's queue
     const int64_t M = (int64_t)sgt.n_active * sgt.prm->restarts;
     int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
-    const int64_t cap = (int64_t)per_cu * c->compute_units;
+    // (in-memory metric: at most kV2HmemWavesPerCu wavefronts per CU -- the bound v2_decompose_body sizes v2_hmem with up front, so the
+    // per-stage reserve below can never grow the buffer in the middle of a chain: ADVICE r4)
+    const int64_t cap = (int64_t)(v2_h_in_memory<K, QN>() && per_cu > kV2HmemWavesPerCu ? kV2HmemWavesPerCu : per_cu) * c->compute_units;
     if (blocks > cap) blocks = cap;
     if constexpr (v2_h_in_memory<K, QN>()) {
         HIP_TRY(c->v2_hmem.reserve((size_t)blocks * v2_h_floats_per_wave<K, QN>() * sizeof(float)));
@@ -2184,9 +2206,9 @@ int v2_decompose_body(slam_ctx* c, int64_t first, int64_t count, int k_min, int 
             const int na = (6 * (k + 1) + c->v2_qn * k + 3) / 4;
             if (na <= 8) continue;
             int64_t blocks = (M + kQuadsPerWave - 1) / kQuadsPerWave;
-            const int64_t cap = (int64_t)8 * c->compute_units;  // never more wavefronts than a CU can hold
+            const int64_t cap = (int64_t)kV2HmemWavesPerCu * c->compute_units;  // the launch's own bound (v2_launch_minimize_gq)
             if (blocks > cap) blocks = cap;
-            const size_t bytes = (size_t)blocks * (size_t)(na * (na + 1) / 2 * 4 * kWave) * sizeof(float);
+            const size_t bytes = (size_t)blocks * (size_t)(na * (na + 1) / 2 * 4 * kWave) * sizeof(float);  // == v2_h_floats_per_wave<K, QN>()
             need = bytes > need ? bytes : need;
         }
         if (need) HIP_TRY(c->v2_hmem.reserve(need));

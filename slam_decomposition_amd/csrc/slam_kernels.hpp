@@ -73,6 +73,11 @@ static_assert(sizeof(StageCtl) == 64, "StageCtl layout");
 
 // internal bit of MinimizeArgs::flags (beside SLAM_FLAG_*): the launch records per-iteration traces
 constexpr uint32_t kFlagTrace = 0x100u;
+// SLAM_FLAG_NO_EXTERIOR (CircuitTemplate(no_exterior_1q=True), basis.py:154,165): the template is G_k K_{k-1} ... K_1 G_1 -- layers 0 and
+// K are identities.  Their 12 parameters are pinned at zero (U3(0, 0, 0) = 1): start values and gradient components are zeroed, and a
+// quasi-Newton iteration from the identity metric then never moves them (their rows of the metric stay unit rows: s_i = y_i = 0), so the
+// run IS the run of the 6 (k - 1)-parameter problem, addition of zeros aside.
+constexpr uint32_t kFlagNoExterior = 0x200u;
 
 template <int K>
 struct MinimizeArgs {
@@ -481,6 +486,13 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
                             lds_fence();
                         }
                     }
+                    if ((args.flags & kFlagNoExterior) && get) {
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            const int i = 4 * a + q;
+                            x[a] = (i < 6 || i >= 6 * K) ? 0.0 : x[a];
+                        }
+                    }
                 }
             }
             if (__any(taken)) h_set_identity_where<NA>(H, q, taken);
@@ -520,6 +532,13 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
         // stays finite without per-element guards (0 * NaN would otherwise leak into H through w and v)
 #pragma unroll
         for (int a = 0; a < NA; ++a) gt[a] = finite ? gt[a] : 0.0;
+        if (args.flags & kFlagNoExterior) {  // wave-uniform
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int i = 4 * a + q;
+                gt[a] = (i < 6 || i >= 6 * K) ? 0.0 : gt[a];
+            }
+        }
         const bool armijo = finite && (ft <= f + kArmijoC1 * alpha * gp);
         const bool acc = active && (fresh ? finite : armijo);
         const bool step = acc && !fresh;  // a real quasi-Newton step (not the initial evaluation)

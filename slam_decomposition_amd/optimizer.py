@@ -27,7 +27,7 @@ import numpy as np
 from . import _ffi, runtime
 from .basis import CircuitTemplate
 from .basisv2 import CircuitTemplateV2
-from .basis_abc import DataDictEntry, TargetDataList, VariationalTemplate
+from .basis_abc import DataDictEntry, RowBlocks, TargetDataList, VariationalTemplate
 from .cost_function import BasicCost, SquareCost, UnitaryCostFunction
 from .sampler import SampleFunction
 
@@ -60,6 +60,7 @@ class TemplateOptimizer:
         stop_loss=None,
         deterministic=True,
         auto_shards=1,
+        windows_in_flight=None,
     ):
         self.basis = basis
         self.objective = objective
@@ -100,6 +101,10 @@ class TemplateOptimizer:
                                       "templates without callback; host-driven, device objective), L-BFGS-B / SLSQP for V2 templates")
         if getattr(basis, "mixed_order", False) and (use_callback or self._host_method is not None):
             raise NotImplementedError("MixedOrderBasisCircuitTemplate: use_callback / override_method are not implemented")
+        self._no_exterior = bool(getattr(basis, "no_exterior_1q", False)) and not self._v2
+        if self._no_exterior and (use_callback or self._host_method is not None or getattr(basis, "mixed_order", False)):
+            raise NotImplementedError("CircuitTemplate(no_exterior_1q=True): use_callback / override_method / mixed-order templates "
+                                      "are not implemented")
         if self.training_restarts <= 0:
             raise ValueError("training_restarts must be positive")
         self.device = basis.device if device is None else device
@@ -111,6 +116,8 @@ class TemplateOptimizer:
         self.seed = seed
         self.deterministic = bool(deterministic)
         self.auto_shards = int(auto_shards)
+        if windows_in_flight is not None:
+            self.windows_in_flight = int(windows_in_flight)
         self.gtol = float(gtol)
         if stop_loss is None:
             stop_loss = min(DEFAULT_STOP_LOSS, 0.1 * self.success_threshold)
@@ -149,11 +156,36 @@ class TemplateOptimizer:
             gtol=self.gtol,
             stop_loss=self.stop_loss,
             seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
-            # one blocking call at a time on the device: the spans of the loop side by side whatever the batch size (bit-equal;
-            # 65 536 x 32 sqrt(iSWAP): 18.1 -> 16.8 ms); several shards in flight fill the chip by themselves
+            # one blocking call at a time on the device leaves the library's own choice (medium calls: spans side by side; big
+            # calls: _overlap_pays below decides from the batch's coverage); several shards in flight fill the chip by themselves
             flags=_ffi.FLAG_EARLY_EXIT | (_ffi.FLAG_ORDERED if self.deterministic else 0)
-            | (_ffi.FLAG_OVERLAP if (self.deterministic and len(self.devices) == 1 and self.auto_shards <= 1) else _ffi.FLAG_NO_OVERLAP),
+            | (0 if (self.deterministic and len(self.devices) == 1 and self.auto_shards <= 1) else _ffi.FLAG_NO_OVERLAP)
+            | (_ffi.FLAG_NO_EXTERIOR if self._no_exterior else 0),  # basis.py:154,165: layers 0 and k pinned at the identity
         )
+
+    # a span loop side by side for ALL targets (SLAM_FLAG_OVERLAP) runs the LAST span for every target of the call: it pays when
+    # that span is needed by a good share of them anyway (CNOT: all; sqrt(iSWAP): 21 % -- 18.1 -> 16.8 ms for 65 536 x 32) and is
+    # pure waste when the basis covers the chamber earlier (B: every Haar target at two gates -- the most expensive stage for nothing)
+    OVERLAP_MIN_TOP_SHARE = 0.15
+    OVERLAP_AUTO_ITEMS = 1 << 17  # up to here the library overlaps by itself (slam_hip.h: SLAM_FLAG_OVERLAP)
+
+    def _overlap_pays(self, ctx, count: int, ks) -> bool:
+        """Big single call, resident targets: the share of THIS batch that needs the loop's last span, from the exact coverage
+        regions of the gate sequence evaluated on the device (``slam_predict_spans``; 0.2 ms for 65 536 targets)."""
+        if not (self.deterministic and len(self.devices) == 1 and self.auto_shards <= 1):
+            return False
+        if count * int(self.training_restarts) <= self.OVERLAP_AUTO_ITEMS or len(ks) < 2 or ks[0] != 1 or ks[-1] > 3:
+            return False
+        try:
+            coords = getattr(self.basis, "_gate_coords_all", None)
+            if coords is None:
+                from .weyl import c1c2c3
+
+                coords = self.basis._gate_coords_all = [c1c2c3(m) for m in self.basis.gate_matrices]
+            spans = ctx.predict_spans([coords[i] for i in self.basis.gate_sequence(ks[-1])], ks[-1], 0, count)
+        except (NotImplementedError, ValueError):
+            return False
+        return float(np.mean(spans >= ks[-1])) >= self.OVERLAP_MIN_TOP_SHARE
 
     def _run_batch(self, targets: np.ndarray, spanning_range: Sequence[int]):
         """``_run`` (optimizer.py:188-313) for all targets at once.  Returns
@@ -179,6 +211,8 @@ class TemplateOptimizer:
         prm = self._opt_params()
         n = len(targets)
 
+        if len(self.devices) == 1 and self.auto_shards <= 1 and n > self.WINDOW_TARGETS and self.windows_in_flight > 1:
+            return self._run_batch_windows(n, targets, ks, gate_seqs, prm)
         devices = self.devices
         if len(devices) == 1 and self.auto_shards > 1 and n >= self.AUTO_SHARD_MIN_TARGETS:
             # opt-in (auto_shards > 1): a big batch on one GPU as target shards side by side (one cached context + stream + host
@@ -200,8 +234,9 @@ class TemplateOptimizer:
                 ctx.set_gates(self.basis.gate_matrices)
                 ctx.set_cost(self._cost_kind)
                 ctx.reset_stats()
+                flags = prm.flags | (_ffi.FLAG_OVERLAP if (single and self._overlap_pays(ctx, count, ks)) else 0)
                 sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
-                                    flags=prm.flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
+                                    flags=flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
                                     target_base=first)
                 out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
                 # the running best loss per span feeds the "Cycle (k =...)" log lines only (optimizer.py:297)
@@ -242,6 +277,73 @@ class TemplateOptimizer:
         # per target the first 6 (cycles + 1) parameters of its row: the padded block goes back as it is (rows are cut when an
         # entry is looked at: 65 536 per-row slices cost more than the span loop on the GPU)
         return best_loss, best_x, best_cycles
+
+    # ------------------------------------------------------------------------------------------
+    # A sampler larger than one window: SUCCESSIVE windows of WINDOW_TARGETS targets in flight on the one GPU, each on its own
+    # cached context (stream + stage buffers + host thread), as bench.py runs its batches.  What several calls in flight buy is
+    # the overlap of one window's stage tails, its k = 3 stage and its launch gaps with the next window's work;
+    # target shards of the SAME window do not get it (round 4, negative).  Seeds are keyed on the global target index and the
+    # ordered early exit makes a target's result independent of what runs beside it, so the result equals the single call's bit
+    # for bit.  Reference: the sequential loop over the sampler, optimizer.py:180-186.
+    WINDOW_TARGETS = 65536
+    windows_in_flight = 5
+
+    def _run_batch_windows(self, n, targets, ks, gate_seqs, prm):
+        import threading
+
+        W = int(self.WINDOW_TARGETS)
+        n_win = (n + W - 1) // W
+        n_thr = min(int(self.windows_in_flight), n_win)
+        device = self.devices[0]
+        flags = (prm.flags & ~_ffi.FLAG_OVERLAP) | _ffi.FLAG_NO_OVERLAP  # several calls in flight fill the chip by themselves
+        parts = [None] * n_win
+        stats = [None] * n_win
+        errors = []
+        next_win = [0]
+        lock = threading.Lock()
+
+        def work(slot):
+            try:
+                ctx = runtime.get_context(device, slot)
+                ctx.set_gates(self.basis.gate_matrices)
+                ctx.set_cost(self._cost_kind)
+                while True:
+                    with lock:
+                        w = next_win[0]
+                        next_win[0] += 1
+                    if w >= n_win or errors:
+                        return
+                    first = w * W
+                    count = min(W, n - first)
+                    if self._device_sampler is not None:
+                        self._device_sampler.fill(ctx, first, count)
+                    else:
+                        ctx.set_targets(targets[first : first + count])
+                    ctx.reset_stats()
+                    sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
+                                        flags=flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
+                                        target_base=first)
+                    out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
+                    sl = ctx.fetch_span_losses(0, count) if self._want_span_losses else None
+                    parts[w] = out + (sl,)
+                    stats[w] = ctx.stats()
+            except Exception as exc:  # surfaced below
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(slot,)) for slot in range(n_thr)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        best_loss = np.concatenate([p[0] for p in parts])
+        best_cycles = np.concatenate([p[2] for p in parts])
+        self._span_losses = np.concatenate([p[3] for p in parts]) if self._want_span_losses else None
+        self._set_stats(stats)
+        # the parameter blocks stay per window (63 MB for 327 680 x 24 parameters would be copied once more): rows are looked up
+        # through RowBlocks when an entry of target_data is built
+        return best_loss, RowBlocks([p[1] for p in parts]), best_cycles
 
     def _run_batch_host_method(self, targets: np.ndarray, spanning_range):
         """``_run`` (optimizer.py:233-303) with ``override_method="Nelder-Mead"`` (:266-268): the simplex iterations of all
@@ -330,7 +432,7 @@ class TemplateOptimizer:
             best_loss[better], best_x[better], best_cycles[better] = loss[better], x[better], k
             self._span_losses[todo, k - 1] = best_loss[todo]
         self._set_stats([ctx.stats()])
-        xs = [best_x[t, : 6 * (int(best_cycles[t]) + 1)].copy() for t in range(n)]
+        xs = [best_x[t, self.basis.param_slice(int(best_cycles[t]))].copy() for t in range(n)]
         return best_loss, xs, best_cycles
 
     def _run_batch_mixed_order(self, targets: np.ndarray, coords: np.ndarray):
@@ -659,6 +761,13 @@ class TemplateOptimizer:
             logging.info(f"Fail: {target_coordinates}, Found: {found_coordinates}")
         return DataDictEntry(success_label, best_result, best_Xk, best_cycles)
 
+    def _row_slice(self, cycles: int) -> slice:
+        """The entry's ``Xk`` inside a padded device row [6 (k_max + 1)]: the first 6 (cycles + 1) values, or -- no_exterior_1q --
+        the interior layers (basis.param_slice)."""
+        if self._v2:
+            return slice(0, 6 * (cycles + 1))
+        return self.basis.param_slice(cycles)
+
     def _found_coordinates(self, best_xs, best_cycles) -> np.ndarray:
         """c1c2c3 of the found circuits (optimizer.py:85,103): one batched CircuitTemplate.eval on the GPU
         per distinct span, the Weyl coordinates of the template unitaries on the device too (``slam_eval_c1c2c3``)."""
@@ -684,7 +793,7 @@ class TemplateOptimizer:
             return found
         for k in np.unique(best_cycles):
             idx = np.nonzero(best_cycles == k)[0]
-            X = np.stack([best_xs[i] for i in idx])
+            X = self.basis.device_vector(np.stack([best_xs[i] for i in idx]), int(k))
             # template unitary and its Weyl coordinates on the device: three doubles per circuit come back
             found[idx] = ctx.eval_c1c2c3(self.basis.gate_sequence(int(k)), X)
         return found
@@ -784,7 +893,9 @@ class TemplateOptimizer:
         if getattr(self.basis, "mixed_order", False):
             self.basis.set_polytope(self.circuit_polytopes[-1])
         self.basis.build(n_repetitions=int(best_cycles[-1]))  # the reference leaves the template at the last size
-        padded = isinstance(best_xs, np.ndarray) and best_xs.ndim == 2  # [n, 6 (k_max + 1)] rows, cut at 6 (cycles + 1) on access
+        if isinstance(best_xs, RowBlocks) and (log_on or self.use_callback):
+            best_xs = best_xs.as_array()
+        padded = isinstance(best_xs, (np.ndarray, RowBlocks)) and best_xs.ndim == 2  # [n, 6 (k_max + 1)] rows, cut at 6 (cycles + 1) on access
         if not log_on and not self.use_callback:
             # same bookkeeping as the per-target path below, without the log lines: every target up to (and including)
             # the first one that fails without override_fail is recorded, then the reference's ValueError (optimizer.py:89-93)
@@ -796,9 +907,9 @@ class TemplateOptimizer:
             if fail:
                 raise ValueError(_FAIL_MSG)
             # list of DataDictEntry (optimizer.py:113), entries built when they are looked at
-            return TargetDataList(ok, best_loss, best_xs, best_cycles, (lambda c: 6 * (c + 1)) if padded else None)
+            return TargetDataList(ok, best_loss, best_xs, best_cycles, self._row_slice if padded else None)
         if padded:
-            best_xs = [best_xs[i, : 6 * (int(best_cycles[i]) + 1)] for i in range(n)]
+            best_xs = [best_xs[i, self._row_slice(int(best_cycles[i]))] for i in range(n)]
         found = self._found_coordinates(best_xs, best_cycles) if log_on else np.zeros((n, 3))
         coords = coords_arr if coords_arr is not None else np.zeros((n, 3))
         out = []

@@ -302,3 +302,37 @@ def test_mixed_order_template_constructor_and_coverage_set():
     h.set_polytope(h.coverage[1])
     h.build(2, scaled_gate=ConversionGainGate(0, 0, 0, pi / 8, 1))
     assert h.gate_sequence() == [0, 0] and abs(h.base_gates[0].params[3] - pi / 8) < 1e-15
+
+
+def test_no_exterior_template_structure_and_row_blocks():
+    """CircuitTemplate(no_exterior_1q=True) (src/slam/basis.py:57,154,165): G_k K_{k-1} ... K_1 G_1 has 6 (k - 1) parameters, which
+    sit in the interior of a device row; RowBlocks: the rows of several windows' blocks seen as one array (no copy)."""
+    from slam_decomposition_amd.basis_abc import RowBlocks, TargetDataList
+
+    b = CircuitTemplate(base_gates=[RiSwapGate(0.5)], no_exterior_1q=True, maximum_span_guess=3)
+    b.build(3)
+    assert b.n_params == 12 and b.param_slice(3) == slice(6, 18)
+    x = np.arange(12.0) + 1
+    full = b.device_vector(x)
+    assert full.shape == (1, 24) and np.all(full[0, :6] == 0) and np.all(full[0, 18:] == 0) and np.array_equal(full[0, 6:18], x)
+    gl = b.to_gate_list(x)
+    assert [g[0] for g in gl] == ["gate", "u", "u", "gate", "u", "u", "gate"]
+    assert gl[1] == ("u", 0, (1.0, 2.0, 3.0)) and gl[5] == ("u", 1, (10.0, 11.0, 12.0))
+    full_t = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
+    full_t.build(2)
+    assert full_t.n_params == 18 and full_t.param_slice(2) == slice(0, 18) and full_t.device_vector(np.zeros(18)).shape == (1, 18)
+
+    blocks = [np.arange(12.0).reshape(3, 4), np.arange(12.0, 20.0).reshape(2, 4)]
+    rb = RowBlocks(blocks)
+    assert len(rb) == 5 and rb.shape == (5, 4) and rb.ndim == 2
+    assert np.array_equal(rb[3], blocks[1][0]) and np.array_equal(rb[-1], blocks[1][1]) and np.array_equal(rb[2, 1:3], blocks[0][2, 1:3])
+    assert np.array_equal(rb.as_array(), np.concatenate(blocks))
+    with pytest.raises(IndexError):
+        rb[5]
+    with pytest.raises(ValueError):
+        RowBlocks([np.zeros((1, 2)), np.zeros((1, 3))])
+    # a lazy target_data over blocks, entries cut by a slice (no_exterior) or a width
+    td = TargetDataList(np.ones(5, int), np.zeros(5), rb, np.array([1, 1, 1, 1, 1]), lambda c: slice(1, 3))
+    assert np.array_equal(td[4].Xk, blocks[1][1][1:3]) and td[0].cycles == 1
+    td2 = TargetDataList(np.ones(5, int), np.zeros(5), rb, np.array([1, 1, 1, 1, 1]), lambda c: 2)
+    assert np.array_equal(td2[3].Xk, blocks[1][0][:2])
