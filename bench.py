@@ -181,12 +181,24 @@ def weyl_distance(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return np.minimum(d, np.abs(am - b).max(axis=-1))
 
 
-def parity_sample(res, gpu):
+def parity_sample(res, gpu, gpu_threshold=1e-10):
     """north_star: "match the reference path's converged loss and recovered Weyl coordinates to 1e-6 on identical Haar targets".
     `res` = the CPU baseline's per-target results (SciPy BFGS + finite differences on the oracle: the reference's path,
-    optimizer.py:270-278), `gpu` = (best_loss, best_cycles, found coordinates) of the HIP path for the SAME target indices and
-    Philox start points.  A target counts as solved below SUCCESS_LOSS on either side."""
-    g_loss, g_cyc, g_coords, t_coords = gpu
+    optimizer.py:270-278), `gpu` = (best_loss, best_cycles, found coordinates, target coordinates, running best loss per span) of the
+    HIP path for the SAME target indices and Philox start points.  A target counts as solved below SUCCESS_LOSS on either side.
+
+    Four separate verdicts (one `pass` over a widened bound said less than it seemed to):
+      * cycles        equal template sizes.  The reference path stops a span loop at the METRIC's level (loss < 1e-8), the HIP path at the
+                      reference's own SUCCESS_THRESHOLD (1e-10): a target whose HIP loss after span k lies in [1e-10, 1e-8) is solved
+                      at k by the metric's criterion on both sides, and the HIP path goes on to k + 1 -- such targets (identified by the
+                      HIP path's own span losses, not by a constant allowance) count as equal at the metric's level;
+      * loss_1e6      |loss difference| <= 1e-6 on targets solved by both;
+      * gpu_vs_target_1e6   Weyl coordinates of the HIP path's circuits within 1e-6 of the TARGET's;
+      * path_vs_path  HIP circuits against the reference path's circuits: within 1e-6 + 4 sqrt(reference loss) -- the reference path's
+                      own circuits sit ~ sqrt(loss) ~ 3e-5 off the target at its finite-difference floor, so 1e-6 path against path is
+                      not attainable by ANY implementation; the bound used is stated, not 1e-6."""
+    g_loss, g_cyc, g_coords, t_coords = gpu[:4]
+    g_span = gpu[4] if len(gpu) > 4 else None
     n = min(len(res), len(g_loss))
     c_loss = np.array([r[0] for r in res[:n]])
     c_cyc = np.array([r[1] for r in res[:n]])
@@ -194,23 +206,36 @@ def parity_sample(res, gpu):
     c_ok, g_ok = c_loss < SUCCESS_LOSS, g_loss[:n] < SUCCESS_LOSS
     both = c_ok & g_ok
     neither = ~c_ok & ~g_ok  # out of the template's reach for both (basis sweep): different local minima are not a mismatch
-    cycles_equal = int((both & (c_cyc == g_cyc[:n])).sum() + neither.sum())
+    strict = both & (c_cyc == g_cyc[:n])
+    # solved at the reference's size by the metric's criterion, continued only because of the stricter internal threshold
+    in_gap = np.zeros(n, dtype=bool)
+    if g_span is not None:
+        for t in np.nonzero(both & (g_cyc[:n] == c_cyc + 1))[0]:
+            v = g_span[t, int(c_cyc[t]) - 1]
+            in_gap[t] = bool(gpu_threshold <= v < SUCCESS_LOSS)
+    cycles_equal = int(strict.sum() + neither.sum())
+    cycles_metric = int((strict | in_gap).sum() + neither.sum())
     dl = float(np.abs(c_loss - g_loss[:n])[both].max()) if both.any() else 0.0
-    # coordinates of the found circuits against the TARGET's: the HIP path must recover them to 1e-6; the reference path's own circuits
-    # sit ~ sqrt(loss) ~ 3e-5 off (its finite-difference floor: loss ~ 1e-9), so path against path the bound is 1e-6 + 4 sqrt(CPU loss)
     d_gt = weyl_distance(g_coords[:n][both], t_coords[:n][both]) if both.any() else np.zeros(0)
     d_ct = weyl_distance(c_coords[both], t_coords[:n][both]) if both.any() else np.zeros(0)
     d_gc = weyl_distance(c_coords[both], g_coords[:n][both]) if both.any() else np.zeros(0)
-    coords_ok = bool(np.all(d_gt <= 1e-6) and np.all(d_gc <= 1e-6 + 4.0 * np.sqrt(c_loss[both])))
-    ok = cycles_equal >= n - 2 and dl <= 1e-6 and coords_ok
+    pvp_bound = 1e-6 + 4.0 * np.sqrt(c_loss[both])
+    v_cycles = cycles_metric == n
+    v_loss = dl <= 1e-6
+    v_target = bool(np.all(d_gt <= 1e-6))
+    v_pvp = bool(np.all(d_gc <= pvp_bound))
     mx = lambda v: float(v.max()) if len(v) else 0.0
-    return {"n": n, "cycles_equal": cycles_equal, "solved_cpu": int(c_ok.sum()), "solved_gpu": int(g_ok.sum()), "both_unsolved": int(neither.sum()),
+    return {"n": n, "cycles_equal": cycles_equal, "cycles_equal_at_metric_level": cycles_metric, "in_threshold_gap": int(in_gap.sum()),
+            "solved_cpu": int(c_ok.sum()), "solved_gpu": int(g_ok.sum()), "both_unsolved": int(neither.sum()),
             "max_abs_loss_diff": dl, "max_coord_diff_gpu_vs_target": mx(d_gt), "max_coord_diff_cpu_vs_target": mx(d_ct),
-            "max_coord_diff_gpu_vs_cpu": mx(d_gc), "tolerance": 1e-6, "pass": bool(ok),
+            "max_coord_diff_gpu_vs_cpu": mx(d_gc),
+            "cycles": bool(v_cycles), "loss_1e6": bool(v_loss), "gpu_vs_target_1e6": v_target,
+            "path_vs_path": {"pass": v_pvp, "bound": "1e-6 + 4 sqrt(reference-path loss)", "max_bound": mx(pvp_bound)},
+            "pass": bool(v_cycles and v_loss and v_target and v_pvp),
             "what": "reference path (SciPy BFGS, finite differences, sequential restarts on the NumPy oracle) vs the HIP path on the same target "
-                    "indices and the same Philox start points; coordinates = c1c2c3 of the found circuits, units of pi; required: equal cycles "
-                    "(n - 2 at least), |loss difference| <= 1e-6, HIP coordinates within 1e-6 of the target's, path against path within "
-                    "1e-6 + 4 sqrt(reference loss) (the reference path's own accuracy)"}
+                    "indices and the same Philox start points; coordinates = c1c2c3 of the found circuits, units of pi.  `pass` = cycles (equal "
+                    "template sizes; a target the HIP path solved at the reference's size with a loss in [1e-10, 1e-8) and then continued counts "
+                    "as equal at the metric's level) and loss_1e6 and gpu_vs_target_1e6 and path_vs_path (whose bound is NOT 1e-6: see it)"}
 
 
 def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool, gpu_sample=None):
@@ -584,7 +609,7 @@ def run_medium_call(local_rank: int, n_targets: int = 4096, restarts: int = 16, 
 # ------------------------------------------------------------------------------------------------
 def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool, group_arg: int = 0):
     """Run `warmup` untimed + `steps` timed steps of one workload; returns the dict of measurements."""
-    from slam_decomposition_amd import _ffi
+    from slam_decomposition_amd import _ffi, parallel
 
     gname, n_per_step, restarts, desc = WORKLOADS[workload]
     if main and args.targets:
@@ -715,7 +740,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     def run_steps(step_ids, results, first_step):
         # steps are dealt round-robin to n_streams host threads, each with its own context / HIP stream,
         # so the tail of one batch (a stage lasts as long as its slowest work item) overlaps the next batch
-        groups = [step_ids[i : i + group] for i in range(0, len(step_ids), group)]
+        groups = parallel.step_groups(step_ids, group)
 
         def worker(w):
             for g in groups[w::n_streams]:
@@ -756,10 +781,8 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
             if resident_merge:
                 # device to device: each context's resident best_loss windows -> this rank's slice of the job vector
                 comm.raw.merge_begin(world * n_loc)
-                for w in range(n_streams):
-                    for g in groups[w::n_streams]:
-                        for s in g:
-                            comm.raw.merge_add(ctxs[w], s * n_per_step, n_per_step, rank * n_loc + (s - first_step) * n_per_step)
+                for w, local_first, cnt, global_first in parallel.merge_slices(step_ids, first_step, n_per_step, rank, world, n_streams, group):
+                    comm.raw.merge_add(ctxs[w], local_first, cnt, global_first)
                 t_c = time.perf_counter()
                 results["merged_solved"], _ = comm.raw.allreduce_min_merged(SUCCESS_LOSS)
                 results["collective_ms"] = 1e3 * (time.perf_counter() - t_c)
@@ -851,14 +874,20 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
         assert int(cnt[0]) == solved_all, "merged best-loss vector disagrees with the per-rank counts"
         # what a first N > 1 run needs to diagnose itself: every rank's own time for the median repetition's timed region
         # (steps + collective, before the closing barrier), its solved count, the collective's duration, its evaluations
-        flat = np.zeros(world * 4)
-        flat[4 * rank : 4 * rank + 4] = [res["own_ms"], float(solved), res.get("collective_ms", 0.0), float(sum(st["evals"][k] for k in (1, 2, 3)))]
+        cores, quota = usable_cores()
+        flat = np.zeros(world * 6)
+        flat[6 * rank : 6 * rank + 6] = [res["own_ms"], float(solved), res.get("collective_ms", 0.0), float(sum(st["evals"][k] for k in (1, 2, 3))),
+                                         float(threading.active_count()), float(quota if quota is not None else cores)]
         comm.allreduce_sum(flat)
-        diag = flat.reshape(world, 4)
+        diag = flat.reshape(world, 6)
         rank_diag = {"own_ms": [round(float(v), 3) for v in diag[:, 0]], "solved": [int(v) for v in diag[:, 1]],
                      "collective_ms": [round(float(v), 3) for v in diag[:, 2]], "evals": [int(v) for v in diag[:, 3]],
+                     "host_threads": [len(ctxs) // (group if mq else 1) + 1] * world, "live_threads_at_report": [int(v) for v in diag[:, 4]],
+                     "cpu_share": [round(float(v), 2) for v in diag[:, 5]],
                      "note": "per rank, median repetition: wall time of its own steps + the final collective (before the closing barrier), "
-                             "targets it solved, duration of the collective as it saw it, loss+gradient evaluations"}
+                             "targets it solved, duration of the collective as it saw it, loss+gradient evaluations; host_threads = worker "
+                             "threads (one per call in flight) + the main one, cpu_share = the cores this rank's cgroup / affinity grants: "
+                             "N ranks x host_threads on one node must fit the node's cores or the calls in flight starve each other"}
     else:
         solved_all = solved
 
@@ -925,7 +954,7 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
                 continue
             sel = np.nonzero(g_cyc == k)[0]
             g_coords[sel] = c.eval_c1c2c3(gate_seqs[k - 1], np.ascontiguousarray(g_x[sel, : 6 * (k + 1)]), ndigits=-1)
-        gpu_sample = (g_loss, g_cyc, g_coords, c.targets_c1c2c3(0, n_s, ndigits=-1))
+        gpu_sample = (g_loss, g_cyc, g_coords, c.targets_c1c2c3(0, n_s, ndigits=-1), c.fetch_span_losses(0, n_s))
 
     for c in ctxs:
         c.close()
@@ -1078,11 +1107,12 @@ def main():
             "comm": type(comm).__name__,
             "rank_devices": rank_devices,
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64",  # loss, gradient, parameters, steps: every counted flop; see config.metric_dtype
             "data": "synthetic" if not os.environ.get("SLAM_BENCH_TEST_STUB") else "STUB: test hook, no GPU work was done, numbers are meaningless",
             "config": {
                 "workload": m["desc"],
                 "basis": m["gname"],
+                "metric_dtype": "f32 (inverse-Hessian preconditioner of the quasi-Newton iteration only; not in the flop count)",
                 "targets_per_step_per_gpu": m["n_per_step"],
                 "restarts": m["restarts"],
                 "span_max": 3,

@@ -38,8 +38,12 @@ extern "C" {
 #define SLAM_ERR_NOMEM (-4)
 #define SLAM_ERR_STATE (-5)       /* call order: targets / basis not set */
 
-#define SLAM_MAX_SPAN_EVAL 5     /* reference default maximum_span_guess, src/slam/basis.py:59 */
-#define SLAM_MAX_SPAN_MINIMIZE 5 /* spans the quasi-Newton kernel is instantiated for (1..3 are the tuned ones) */
+#define SLAM_MAX_SPAN_QUAD 5      /* spans of the register-resident kernels (a quad of lanes per item; 1..3 are the tuned ones);
+                                    the reference's default maximum_span_guess, src/slam/basis.py:59 */
+#define SLAM_MAX_SPAN_EVAL 16     /* spans of slam_eval_*: beyond SLAM_MAX_SPAN_QUAD one wavefront per item (csrc/slam_long.hpp) */
+#define SLAM_MAX_SPAN_MINIMIZE 16 /* spans of slam_minimize_stage / slam_decompose*: beyond SLAM_MAX_SPAN_QUAD a wavefront per item
+                                    with a limited-memory quasi-Newton state (the templates MixedOrderBasisCircuitTemplate builds from
+                                    weak gates, src/slam/basis.py:213-359) */
 #define SLAM_MAX_GATES 256
 #define SLAM_MAX_MAXITER 4000    /* per-restart iteration cap accepted by the kernels (reference: 2500) */
 
@@ -471,11 +475,14 @@ int slam_allreduce_min(slam_comm* comm, double threshold, int64_t* n_below, doub
 /* Library version string. */
 const char* slam_version(void);
 
-/* Binary interface revision: bumped whenever an exported function changes its signature or a structure its layout (round 4: 4 --
- * slam_allreduce_min took its fifth argument, merged_capacity, in round 3 without a new symbol; a caller built against an older
- * header must check this before calling).  The Python binding refuses a library whose revision differs from the one it was
- * written for. */
-#define SLAM_ABI_VERSION 5
+/* Binary interface revision: bumped whenever an exported function changes its signature or a structure its layout.  History:
+ *   4  slam_allreduce_min took its fifth argument, merged_capacity (round 3, without a new symbol: a caller built against an older
+ *      header must check the revision before calling);
+ *   5  round 4: slam_decompose_multi, slam_predict_spans, 32-byte item records;
+ *   6  round 5: SLAM_MAX_SPAN_EVAL / SLAM_MAX_SPAN_MINIMIZE 5 -> 16 -- the per-span arrays of slam_stats and the rows of
+ *      slam_fetch_span_losses grow with them --, SLAM_FLAG_NO_EXTERIOR, kernel_ms_span[0].
+ * The Python binding refuses a library whose revision differs from the one it was written for. */
+#define SLAM_ABI_VERSION 6
 int slam_abi_version(void);
 
 #ifdef __cplusplus

@@ -16,9 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLAM_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslamhip.so")
 
-ABI_VERSION = 5  # include/slam_hip.h: SLAM_ABI_VERSION
-MAX_SPAN_EVAL = 5
-MAX_SPAN_MINIMIZE = 5
+ABI_VERSION = 6  # include/slam_hip.h: SLAM_ABI_VERSION
+MAX_SPAN_QUAD = 5  # SLAM_MAX_SPAN_QUAD: the register-resident kernels (and per-iteration traces)
+MAX_SPAN_EVAL = 16
+MAX_SPAN_MINIMIZE = 16
 
 ST_CONVERGED, ST_MAXITER, ST_LINESEARCH, ST_NONFINITE, ST_STALLED, ST_PREEMPTED = range(6)
 FLAG_EARLY_EXIT = 1

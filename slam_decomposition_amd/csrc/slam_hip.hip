@@ -5,6 +5,7 @@
 #include "slam_sampler.hpp"
 #include "slam_weyl.hpp"
 #include "slam_v2.hpp"
+#include "slam_long.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -131,6 +132,8 @@ struct slam_ctx {
     slam_stats stats{};
     bool max_lds_set[SLAM_MAX_SPAN_EVAL + 1][kGateClasses][3] = {};  // [.][.][0] eval kernel, [1] optimizer kernel, [2] its multi-queue form
     int64_t resident_waves_mq[SLAM_MAX_SPAN_EVAL + 1][kGateClasses] = {};
+    int64_t resident_waves_long = 0;  // wavefront-per-item kernels (slam_long.hpp): resident wavefronts; 0 = not asked yet
+    bool long_eval_ready = false;
     int64_t resident_waves_wl[kGateClasses] = {};  // span_wave_kernel<GC>: resident wavefronts (0 = not asked yet)
     // speculative spans (span_spec_kernel): staging rows, two side streams, fork / join events
     DevBuf spec_loss, spec_x, spec_ev;
@@ -383,6 +386,74 @@ int launch_minimize(slam_ctx* c, const StageLaunch& sl) {
     return SLAM_OK;
 }
 
+// templates of SLAM_MAX_SPAN_QUAD + 1 .. SLAM_MAX_SPAN_MINIMIZE gates: one wavefront per item (slam_long.hpp)
+int launch_minimize_long(slam_ctx* c, const StageLaunch& sl, int k) {
+    if (c->resident_waves_long == 0) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&minimize_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLongLdsBytes));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&minimize_long_kernel), kWave, kLongLdsBytes));
+        c->resident_waves_long = (int64_t)(per_cu < 1 ? 1 : per_cu) * c->compute_units;
+    }
+    const slam_opt_params* prm = sl.prm;
+    LongArgs a{};
+    a.targets = sl.d_stage_targets;
+    a.orig = sl.d_active;
+    a.first_target = sl.first_target;
+    a.x0 = sl.d_x0;
+    a.ctl = sl.ctl;
+    a.restarts = prm->restarts;
+    a.maxiter = prm->maxiter;
+    a.gtol = prm->gtol;
+    a.stop_loss = prm->stop_loss;
+    a.gtol_far = prm->gtol_far;
+    a.far_loss = prm->far_loss;
+    a.exit_loss = sl.exit_loss;
+    a.seed = prm->seed;
+    a.target_base = prm->target_base;
+    a.flags = prm->flags & (SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED);
+    if (prm->flags & SLAM_FLAG_NO_EXTERIOR) a.flags |= kFlagNoExterior;
+    a.cost_kind = c->cost_kind;
+    a.solved = c->solved.as<int32_t>();
+    a.item_rec = c->item_rec.as<ItemRec>();
+    a.item_x = c->item_x.as<double>();
+    a.k = k;
+    if (c->trace_cap > 0) return fail(SLAM_ERR_UNSUPPORTED, "per-iteration traces are recorded for spans 1..%d (got %d)", SLAM_MAX_SPAN_QUAD, k);
+    { int rc = stage_gates(c, k, sl.gate_seq, &a.gates); if (rc) return rc; }
+    int64_t blocks = sl.n_items_max;  // one item per wavefront at a time
+    if (blocks > c->resident_waves_long) blocks = c->resident_waves_long;
+    if (blocks < 1) blocks = 1;
+    HIP_TRY(hipEventRecord(c->ev_a[k], c->stream));
+    hipLaunchKernelGGL(minimize_long_kernel, dim3((unsigned)blocks), dim3(kWave), kLongLdsBytes, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_b[k], c->stream));
+    return SLAM_OK;
+}
+
+int launch_eval_long(slam_ctx* c, int k, const int32_t* gate_seq, const double* d_x, const int32_t* d_tof, int64_t M, double* d_loss, double* d_grad,
+                     double* d_unitary) {
+    if (!c->long_eval_ready) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&eval_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLongLdsBytes));
+        c->long_eval_ready = true;
+    }
+    LongEvalArgs a{};
+    a.targets = c->targets.as<double>();
+    a.x = d_x;
+    a.target_of = d_tof;
+    a.n_items = M;
+    a.loss = d_loss;
+    a.grad = d_grad;
+    a.unitary = d_unitary;
+    a.cost_kind = c->cost_kind;
+    a.k = k;
+    { int rc = stage_gates(c, k, gate_seq, &a.gates); if (rc) return rc; }
+    int64_t blocks = M;
+    const int64_t cap = (int64_t)8 * c->compute_units;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(eval_long_kernel, dim3((unsigned)blocks), dim3(kWave), kLongLdsBytes, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
 int check_gate_seq(slam_ctx* c, int k, const int32_t* gate_seq) {
     if (!gate_seq) return fail(SLAM_ERR_INVALID, "gate_seq is NULL");
     for (int j = 0; j < k; ++j)
@@ -505,7 +576,10 @@ int enqueue_stage(slam_ctx* c, int k, const int32_t* gate_seq, const int32_t* d_
         SLAM_MIN_CASE(3)
         SLAM_MIN_CASE(4)
         SLAM_MIN_CASE(5)
-        default: return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
+        default:
+            if (k < 1 || k > SLAM_MAX_SPAN_MINIMIZE) return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
+            rc = launch_minimize_long(c, sl, k);  // SLAM_MAX_SPAN_QUAD < k: one wavefront per item
+            break;
     }
     if (rc != SLAM_OK) return rc;
 
@@ -1465,6 +1539,7 @@ static int eval_body(slam_ctx* ctx, int k, const int32_t* gate_seq, const double
         SLAM_EVAL_CASE(3)
         SLAM_EVAL_CASE(4)
         default:
+            if (k > SLAM_MAX_SPAN_QUAD) { rc = launch_eval_long(ctx, k, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit); break; }
             if (gc == GC_CX) rc = launch_eval<5, GC_CX>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
             else if (gc == GC_XRI1) rc = launch_eval<5, GC_XRI1>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
             else if (gc == GC_XRI) rc = launch_eval<5, GC_XRI>(ctx, gate_seq, d_x, d_tof, M, d_loss, d_grad, d_unit);
@@ -1695,6 +1770,7 @@ int slam_predict_spans(slam_ctx* ctx, int64_t first, int64_t count, int k_max, c
     if (count == 0) return SLAM_OK;
     if (!spans_out) return fail(SLAM_ERR_INVALID, "spans_out is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
+    static_assert(sizeof(SpanRegions{}.bounds) / sizeof(SpanRegions{}.bounds[0]) == SLAM_MAX_SPAN_EVAL, "SpanRegions::bounds holds SLAM_MAX_SPAN_EVAL prefixes");
     SpanRegions r{};
     r.k_max = k_max;
     r.tol = tol;
@@ -1765,7 +1841,7 @@ int slam_minimize_stage_trace(slam_ctx* ctx, int k, const int32_t* gate_seq, con
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     if (!params) return fail(SLAM_ERR_INVALID, "params is NULL");
     if (trace_cap <= 0 || !trace_loss || !trace_x) return fail(SLAM_ERR_INVALID, "trace buffers and trace_cap > 0 are required");
-    if (k < 1 || k > SLAM_MAX_SPAN_MINIMIZE) return fail(SLAM_ERR_UNSUPPORTED, "minimize supports spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
+    if (k < 1 || k > SLAM_MAX_SPAN_QUAD) return fail(SLAM_ERR_UNSUPPORTED, "per-iteration traces are recorded for spans 1..%d (got %d)", SLAM_MAX_SPAN_QUAD, k);
     if (!active) n_active = ctx->n_targets;
     if (n_active <= 0 || params->restarts <= 0) return fail(SLAM_ERR_INVALID, "nothing to trace");
     const int n = 6 * (k + 1);

@@ -784,7 +784,7 @@ struct WaveLoopArgs {
     double* spec_x;                     // [3 * count][nmax]
     unsigned long long* spec_ev;        // [3 * count][3]: evaluations (all, accepted, pre-empted) of the stage
 };
-constexpr int kSpanLossStride = 5;  // = SLAM_MAX_SPAN_EVAL
+constexpr int kSpanLossStride = 16;  // = SLAM_MAX_SPAN_EVAL
 constexpr int kWlLdsDoubles = 40;  // winner row (<= 36 parameters) + the flag word
 
 template <int K, int GC, int KL = 3, bool SPEC = false>

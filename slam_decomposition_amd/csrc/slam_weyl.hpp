@@ -175,7 +175,7 @@ struct SpanRegions {
     int32_t k_max;                 // 1 .. SLAM_MAX_SPAN_EVAL
     double tol;                    // widens (> 0) the regions, alcove units (= units of pi)
     double point[4];               // k = 1: the alcove point of the first gate
-    double bounds[5][kSpanPatterns];  // k = 2 .. : bounds[k - 1][p] <= sum_p(gamma)  (-inf: no constraint)
+    double bounds[16][kSpanPatterns];  // [SLAM_MAX_SPAN_EVAL]; k = 2 .. : bounds[k - 1][p] <= sum_p(gamma)  (-inf: no constraint)
 };
 
 // alcove point (decreasing, sum 0, a_1 - a_4 <= 1) of i^{2 shift} CAN(c1, c2, c3): coverage._alcove_columns

@@ -27,7 +27,7 @@ import numpy as np
 from . import _ffi, runtime
 from .basis import CircuitTemplate
 from .basisv2 import CircuitTemplateV2
-from .basis_abc import DataDictEntry, RowBlocks, TargetDataList, VariationalTemplate
+from .basis_abc import DataDictEntry, LazyList, RowBlocks, TargetDataList, VariationalTemplate
 from .cost_function import BasicCost, SquareCost, UnitaryCostFunction
 from .sampler import SampleFunction
 
@@ -66,9 +66,9 @@ class TemplateOptimizer:
         self.objective = objective
         self.preseeding = self.basis.preseeded
         self.use_callback = use_callback
-        self.training_loss = []  # per target: final loss (optimizer.py:307-309)
+        self.training_loss = LazyList()  # per target: final loss (optimizer.py:307-309); a list whose big stretches stay arrays
         self.coordinate_list = []
-        self.best_cycle_list = []
+        self.best_cycle_list = LazyList()
         self.override_fail = override_fail
         self.override_method = override_method
         self.success_threshold = SUCCESS_THRESHOLD if success_threshold is None else success_threshold
@@ -176,16 +176,22 @@ class TemplateOptimizer:
             return False
         if count * int(self.training_restarts) <= self.OVERLAP_AUTO_ITEMS or len(ks) < 2 or ks[0] != 1 or ks[-1] > 3:
             return False
-        try:
-            coords = getattr(self.basis, "_gate_coords_all", None)
-            if coords is None:
-                from .weyl import c1c2c3
+        # the share is a property of the basis and of the targets' distribution: measured on the first big batch a basis sees and kept
+        # with the basis (a heuristic for speed only -- results are bit-equal either way)
+        cache = self.basis.__dict__.setdefault("_top_span_share", {})
+        share = cache.get(ks[-1])
+        if share is None:
+            try:
+                coords = getattr(self.basis, "_gate_coords_all", None)
+                if coords is None:
+                    from .weyl import c1c2c3
 
-                coords = self.basis._gate_coords_all = [c1c2c3(m) for m in self.basis.gate_matrices]
-            spans = ctx.predict_spans([coords[i] for i in self.basis.gate_sequence(ks[-1])], ks[-1], 0, count)
-        except (NotImplementedError, ValueError):
-            return False
-        return float(np.mean(spans >= ks[-1])) >= self.OVERLAP_MIN_TOP_SHARE
+                    coords = self.basis._gate_coords_all = [c1c2c3(m) for m in self.basis.gate_matrices]
+                spans = ctx.predict_spans([coords[i] for i in self.basis.gate_sequence(ks[-1])], ks[-1], 0, count)
+            except (NotImplementedError, ValueError):
+                return False
+            share = cache[ks[-1]] = float(np.mean(spans >= ks[-1]))
+        return share >= self.OVERLAP_MIN_TOP_SHARE
 
     def _run_batch(self, targets: np.ndarray, spanning_range: Sequence[int]):
         """``_run`` (optimizer.py:188-313) for all targets at once.  Returns
@@ -288,11 +294,38 @@ class TemplateOptimizer:
     WINDOW_TARGETS = 65536
     windows_in_flight = 5
 
+    window_stagger = False
+
+    def _window_plan(self, n: int):
+        """[(first, count)] of the windows of an n-target sampler: WINDOW_TARGETS each (the last one ragged).  ``window_stagger``: the
+        first windows_in_flight - 1 windows are 1/f, 2/f, ... of a window, so that the calls in flight reach their stage boundaries at
+        different times from the start (a finite job has no time to drift apart by itself)."""
+        W = int(self.WINDOW_TARGETS)
+        f = int(self.windows_in_flight)
+        sizes = []
+        left = n
+        if self.window_stagger and f > 1 and n > W:
+            for i in range(1, f):
+                c = min(left, max(1, (W * i) // f))
+                if c <= 0:
+                    break
+                sizes.append(c)
+                left -= c
+        while left > 0:
+            c = min(W, left)
+            sizes.append(c)
+            left -= c
+        plan, first = [], 0
+        for c in sizes:
+            plan.append((first, c))
+            first += c
+        return plan
+
     def _run_batch_windows(self, n, targets, ks, gate_seqs, prm):
         import threading
 
-        W = int(self.WINDOW_TARGETS)
-        n_win = (n + W - 1) // W
+        plan = self._window_plan(n)
+        n_win = len(plan)
         n_thr = min(int(self.windows_in_flight), n_win)
         device = self.devices[0]
         flags = (prm.flags & ~_ffi.FLAG_OVERLAP) | _ffi.FLAG_NO_OVERLAP  # several calls in flight fill the chip by themselves
@@ -313,8 +346,7 @@ class TemplateOptimizer:
                         next_win[0] += 1
                     if w >= n_win or errors:
                         return
-                    first = w * W
-                    count = min(W, n - first)
+                    first, count = plan[w]
                     if self._device_sampler is not None:
                         self._device_sampler.fill(ctx, first, count)
                     else:
@@ -653,7 +685,7 @@ class TemplateOptimizer:
         for k in all_ks:
             if k <= 0:
                 raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
-            k_lim = _ffi.V2_MAX_SPAN if self._v2 else _ffi.MAX_SPAN_MINIMIZE
+            k_lim = _ffi.V2_MAX_SPAN if self._v2 else _ffi.MAX_SPAN_QUAD  # per-iteration traces: the register-resident kernels only
             if k > k_lim:
                 raise NotImplementedError(f"template spans up to {k_lim} are implemented on the HIP path (got {k})")
             act = np.array([t for t in range(n) if k in spans_per_target[t] and not (best[t] is not None and best[t] < self.success_threshold)],
@@ -902,8 +934,8 @@ class TemplateOptimizer:
             ok = best_loss <= self.success_threshold
             fail = (not self.override_fail) and (not bool(ok.all()))
             stop = int(np.argmin(ok)) + 1 if fail else n
-            self.training_loss.extend(best_loss[:stop].tolist())  # optimizer.py:307-309 (no callback)
-            self.best_cycle_list.extend(best_cycles[:stop].tolist())
+            self.training_loss.extend_array(best_loss[:stop])  # optimizer.py:307-309 (no callback): elements materialise on access
+            self.best_cycle_list.extend_array(best_cycles[:stop])
             if fail:
                 raise ValueError(_FAIL_MSG)
             # list of DataDictEntry (optimizer.py:113), entries built when they are looked at

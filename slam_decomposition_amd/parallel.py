@@ -38,6 +38,35 @@ def shard_range(n_targets: int, rank: int, world: int) -> Tuple[int, int]:
     return first, count
 
 
+def step_groups(step_ids, group: int):
+    """Consecutive steps handed to the library as one call: ``step_ids`` cut into runs of ``group``."""
+    step_ids = list(step_ids)
+    group = max(1, int(group))
+    return [step_ids[i : i + group] for i in range(0, len(step_ids), group)]
+
+
+def merge_slices(step_ids, first_step: int, n_per_step: int, rank: int, world: int, n_streams: int, group: int = 1):
+    """Where each step's resident best-loss window goes in the JOB's merged vector (the one ``ncclAllReduce(min)`` runs over).
+
+    A rank's timed region is ``step_ids`` (consecutive step numbers starting at ``first_step``), ``n_per_step`` targets each; the
+    job vector is rank-major: rank r owns ``[r n_loc, (r + 1) n_loc)`` with ``n_loc = len(step_ids) n_per_step``, and inside it the
+    steps in order.  Steps are dealt to ``n_streams`` contexts in groups of ``group`` (group g goes to stream g mod n_streams, the
+    order bench.py's workers use); step s sits at targets ``[s n_per_step, (s + 1) n_per_step)`` of its context's resident array.
+    Yields ``(stream, local_first, count, global_first)`` -- the arguments of ``slam_comm_merge_add``.  The slices of all ranks
+    tile ``[0, world n_loc)`` exactly once (tests/test_host_logic.py)."""
+    step_ids = list(step_ids)
+    if not (0 <= rank < world) or n_streams < 1 or n_per_step < 1:
+        raise ValueError("bad rank / world / streams / step size")
+    if step_ids != list(range(first_step, first_step + len(step_ids))):
+        raise ValueError("the timed region must be consecutive steps starting at first_step")
+    n_loc = len(step_ids) * n_per_step
+    groups = step_groups(step_ids, group)
+    for w in range(n_streams):
+        for g in groups[w::n_streams]:
+            for s in g:
+                yield w, s * n_per_step, n_per_step, rank * n_loc + (s - first_step) * n_per_step
+
+
 class LocalComm:
     """world_size = 1: reductions are the identity."""
 

@@ -47,6 +47,11 @@ class StubContext:
         self._st["kernel_launches"] += 3
         return loss, np.zeros((count, 24)), cyc
 
+    def best_loss_window(self, first, count):
+        """What the resident best-loss array holds for targets [first, first + count) after their step ran."""
+        idx = self._seed0 + first + np.arange(count)
+        return np.where(idx % 7 == 0, 1e-3, 1e-12 * (1 + idx % 5)).astype(np.float64)
+
     def synchronize(self):
         pass
 
@@ -54,8 +59,42 @@ class StubContext:
         pass
 
 
+class StubRaw:
+    """Stand-in for ``_ffi.Comm``'s device-to-device merge (slam_comm_merge_begin / _add / slam_allreduce_min) on top of a host
+    communicator: the same calls with the same slice arguments, the vector kept on the host."""
+
+    def __init__(self, comm):
+        self.comm = comm
+        self.buf = None
+        self.calls = 0
+
+    def merge_begin(self, n_global):
+        self.buf = np.full(int(n_global), np.inf)
+
+    def merge_add(self, ctx, first_local, count, first_global):
+        assert np.all(np.isinf(self.buf[first_global : first_global + count])), "two windows on the same slice of the job vector"
+        self.buf[first_global : first_global + count] = ctx.best_loss_window(first_local, count)
+        self.calls += 1
+
+    def allreduce_min_merged(self, threshold, want_merged=False):
+        self.comm.allreduce_min(self.buf)
+        assert not np.any(np.isinf(self.buf)), "a slice of the job vector was contributed by no rank"
+        return int((self.buf < threshold).sum()), (self.buf if want_merged else None)
+
+
 def install():
-    from slam_decomposition_amd import _ffi
+    import os
+
+    from slam_decomposition_amd import _ffi, parallel
 
     _ffi.Context = StubContext
     _ffi.device_count = lambda: 1
+    if os.environ.get("SLAM_BENCH_STUB_RAW"):
+        # rehearse bench.py's `resident_merge` branch (the one an RCCL run takes) over the file communicator
+        init = parallel.FileComm.__init__
+
+        def init_with_raw(self, *a, **kw):
+            init(self, *a, **kw)
+            self.raw = StubRaw(self)
+
+        parallel.FileComm.__init__ = init_with_raw

@@ -41,7 +41,10 @@ def test_version_and_struct_layout():
     assert _ffi.OptParams.gtol_far.offset == 40
     p = _ffi.OptParams(restarts=7, seed=2**63 + 5)
     assert p.restarts == 7 and p.seed == 2**63 + 5 and p.gtol_far == 1e-5 and p.far_loss == 1e-6
-    assert ctypes.sizeof(_ffi.Stats) == 8 + 8 + 6 * 8 + 6 * 8 + 8 + 6 * 8 + 6 * 8 + 6 * 8 + 6 * 8
+    w = _ffi.MAX_SPAN_EVAL + 1  # per-span arrays: index k = 0 .. SLAM_MAX_SPAN_EVAL (ABI 6: 16)
+    assert _ffi.MAX_SPAN_EVAL == 16 and _ffi.MAX_SPAN_MINIMIZE == 16 and _ffi.MAX_SPAN_QUAD == 5
+    assert ctypes.sizeof(_ffi.Stats) == 8 + 8 + w * 8 + w * 8 + 8 + w * 8 + w * 8 + w * 8 + w * 8
+    assert lib.slam_abi_version() == _ffi.ABI_VERSION == 6
 
 
 def test_no_gpu_fails_loudly():

@@ -75,6 +75,27 @@ def test_eight_ranks_slice_arithmetic_and_rank_diagnostics(scaling):
     assert out["ms_per_step"] * steps >= max(d["own_ms"]) * 0.999  # the line's time is the MAX over ranks, barrier included
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_strong_default_workload_through_the_resident_merge_branch(world):
+    """The driver's N > 1 command on the DEFAULT workload with `--scaling strong` (65 536 x 32 split over the ranks), through the
+    branch an RCCL run takes -- `resident_merge`: parallel.merge_slices feeding merge_add per context window, then ONE min-all-reduce
+    -- rehearsed with stub contexts and a host stand-in for the device-side merge (tests/bench_stub.py:StubRaw, which refuses
+    overlapping slices and holes).  8 ranks: 8192 targets per rank per step, 16 calls in flight."""
+    steps, warmup = 20, 5
+    p = _run(["--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup), "--scaling", "strong", "--repeats", "1"],
+             {"SLAM_BENCH_COMM": "file", "SLAM_BENCH_STUB_RAW": "1"}, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    per_rank = 65536 // world
+    assert out["n_gpus"] == world and out["scaling"] == "strong" and out["config"]["targets_per_step_per_gpu"] == per_rank
+    assert "device to device" in out["config"]["final_collective"]
+    seed0 = 20260000
+    per_rank_solved = [_solved(seed0 + r * (steps + warmup) * per_rank + warmup * per_rank, steps * per_rank) for r in range(world)]
+    assert abs(out["solved_fraction"] - sum(per_rank_solved) / (world * steps * per_rank)) < 1e-12
+    assert out["rank_diag"]["solved"] == per_rank_solved
+    assert out["rank_diag"]["host_threads"] == [out["config"]["batches_in_flight_per_gpu"] + 1] * world
+
+
 def test_launcher_path_with_one_rank_and_plain_path_agree():
     """`SLAM_BENCH_FORCE_LAUNCH=1 bench.py --gpus 1` (launcher, rank process, communicator) and plain `bench.py` report the
     same work; and a rank whose communicator cannot come up ends the job non-zero instead of falling back."""

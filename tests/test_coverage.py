@@ -253,7 +253,7 @@ def test_haar_volumes_of_the_regions_equal_the_volumes_the_reference_recorded():
 
 
 def test_candidate_gate_scores_from_the_coverage_regions():
-    """candidates.py -- the sweep BASELINE configs[4] is shaped like (bare_candidates.py:47-126: every candidate gate gets a Haar score
+    """tools/candidates.py (a dev tool, not in the product package) -- the sweep BASELINE configs[4] is shaped like (bare_candidates.py:47-126: every candidate gate gets a Haar score
     and the sizes at which CNOT and SWAP are reached, from its coverage set).  For the six gates whose volumes the reference recorded
     (extended_results.json): full coverage at the size the reference's table of those gates gives (parallel_drive_volume.py:91-96:
     iSwap 3, sqiSwap 3, CNOT 3, sqCNOT 6, B 2, sqB 4), Haar score = sum_k k (vol_k - vol_{k-1}) of the RECORDED volumes within the
@@ -261,7 +261,11 @@ def test_candidate_gate_scores_from_the_coverage_regions():
     import json
     import os
 
-    from slam_decomposition_amd import candidates as cd
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("slam_tools_candidates", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "candidates.py"))
+    cd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cd)
     from slam_decomposition_amd.gates import ConversionGainGate
 
     ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_haar_volumes.json")))

@@ -63,6 +63,12 @@ def test_first_iterations_follow_cpu_port(hip_ctx, k, gate):
                 assert abs(out["item_loss"][t, r] - f) < (1e-11 if maxiter == 1 else 1e-5)
 
 
+# (target, restart) pairs of 24 whose HIP and SciPy runs end in the same minimum: what was measured on MI355X minus ONE pair (round 5;
+# until round 4 the bar was 75 % = 18 for every case).  Pairs that differ sit in different local minima of a non-zero landscape (k below
+# the span) or took another path to another zero.
+MIN_AGREE = {("cx", 3): 23, ("sqiswap", 3): 23, ("cx", 2): 23, ("b", 2): 23}  # measured: 24 of 24 in all four cases
+
+
 @pytest.mark.parametrize(
     "name,gate,k,expect_success",
     [("cx", CX, 3, True), ("sqiswap", SQ, 3, True), ("cx", CX, 2, False), ("b", o.berkeley_matrix(), 2, True)],
@@ -86,7 +92,8 @@ def test_converged_loss_matches_scipy_bfgs(hip_ctx, name, gate, k, expect_succes
             )
             ref[t, r] = res.fun
     agree = np.abs(out["item_loss"] - ref) < 1e-6
-    assert agree.mean() >= 0.75
+    print(f"AGREE {name} k={k}: {int(agree.sum())} of {agree.size}")
+    assert int(agree.sum()) >= MIN_AGREE[(name, k)], (name, k, int(agree.sum()))
     assert np.all(np.abs(out["best_loss"] - ref.min(axis=1)) < 1e-6)
     # returned best_x really has the returned loss (re-evaluated by the oracle)
     for t in range(N):

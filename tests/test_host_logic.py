@@ -86,7 +86,8 @@ def test_circuit_template_structure():
     assert gl[0] == ("u", 0, (0.0, 1.0, 2.0)) and gl[1] == ("u", 1, (3.0, 4.0, 5.0)) and gl[3] == ("u", 0, (6.0, 7.0, 8.0))
     assert t.target_invariant(o.cx_matrix()) == (0.5, 0.0, 0.0)
     assert t.target_invariant(np.eye(8)) == (-1, -1, -1, -1)
-    for kwargs in (dict(no_exterior_1q=True), dict(n_qubits=3), dict(edge_params=[[(1, 0)]])):
+    assert CircuitTemplate(no_exterior_1q=True).no_exterior_1q is True  # (round 5: implemented, SLAM_FLAG_NO_EXTERIOR)
+    for kwargs in (dict(n_qubits=3), dict(edge_params=[[(1, 0)]])):
         with pytest.raises(NotImplementedError):
             CircuitTemplate(**kwargs)
 
@@ -336,3 +337,62 @@ def test_no_exterior_template_structure_and_row_blocks():
     assert np.array_equal(td[4].Xk, blocks[1][1][1:3]) and td[0].cycles == 1
     td2 = TargetDataList(np.ones(5, int), np.zeros(5), rb, np.array([1, 1, 1, 1, 1]), lambda c: 2)
     assert np.array_equal(td2[3].Xk, blocks[1][0][:2])
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("group,n_streams", [(1, 5), (1, 16), (4, 3), (20, 4), (3, 1)])
+def test_merge_slices_tile_the_job_vector(world, group, n_streams):
+    """The slice arithmetic of the N > 1 bench's device-to-device merge (parallel.merge_slices, what feeds slam_comm_merge_add):
+    for 1 / 2 / 4 / 8 ranks, grouped and ungrouped steps, the slices of all ranks cover the job vector exactly once, every step's
+    window comes from the context that ran it and from where that step sits in the context's resident array, and rank r's block
+    is [r n_loc, (r + 1) n_loc) with its steps in order."""
+    from slam_decomposition_amd.parallel import merge_slices, step_groups
+
+    n_per_step, warmup, steps = 8192, 5, 20
+    step_ids = list(range(warmup, warmup + steps))
+    n_loc = steps * n_per_step
+    cover = np.zeros(world * n_loc, dtype=np.int32)
+    for rank in range(world):
+        seen = []
+        groups = step_groups(step_ids, group)
+        owner = {s: gi % n_streams for gi, g in enumerate(groups) for s in g}
+        for w, lf, cnt, gf in merge_slices(step_ids, warmup, n_per_step, rank, world, n_streams, group):
+            assert cnt == n_per_step and lf % n_per_step == 0
+            s = lf // n_per_step
+            assert owner[s] == w
+            assert gf == rank * n_loc + (s - warmup) * n_per_step
+            cover[gf : gf + cnt] += 1
+            seen.append(s)
+        assert sorted(seen) == step_ids
+    assert np.all(cover == 1)
+    with pytest.raises(ValueError):
+        list(merge_slices([5, 7], 5, 16, 0, 1, 1))
+    with pytest.raises(ValueError):
+        list(merge_slices(step_ids, warmup, n_per_step, world, world, 1))
+
+
+def test_lazy_list_behaves_like_the_reference_lists():
+    """``training_loss`` / ``best_cycle_list`` (optimizer.py:38-40,307-311) as LazyList: list behaviour with array chunks inside."""
+    from slam_decomposition_amd.basis_abc import LazyList
+
+    l = LazyList()
+    assert len(l) == 0 and list(l) == [] and l == []
+    l.insert(0, 1.5)
+    l.extend_array(np.array([2.0, 3.0]))
+    l.append(4.0)
+    l.extend([5.0])
+    l.extend_array(np.array([7, 8], dtype=np.int32))
+    l.append([-1, 2, 0.5])  # use_callback appends lists (optimizer.py:238,291)
+    assert len(l) == 8 and l[1] == 2.0 and type(l[1]) is float and type(l[6]) is int and l[-1] == [-1, 2, 0.5]
+    assert l[1:4] == [2.0, 3.0, 4.0] and l == [1.5, 2.0, 3.0, 4.0, 5.0, 7, 8, [-1, 2, 0.5]] and l != [1.5]
+    assert l + [1] == list(l) + [1] and [0] + l == [0] + list(l)
+    del l[-1]
+    l[0] = 9.0
+    assert list(l) == [9.0, 2.0, 3.0, 4.0, 5.0, 7, 8]
+    with pytest.raises(IndexError):
+        l[7]
+    m = LazyList()
+    m.extend_array(np.arange(5.0))
+    m.extend_array(np.arange(5.0, 8.0))
+    assert np.array_equal(np.asarray(m), np.arange(8.0)) and m == LazyList(list(np.arange(8.0))) and m.tolist() == list(range(8))
+    assert sum(1 for _ in m) == 8 and all(type(v) is float for v in m)

@@ -1,4 +1,6 @@
-"""Scoring candidate basis gates by what their circuits can reach -- the sweep BASELINE configs[4] is shaped like.
+"""Dev tool (CPU; NOT part of the product package -- SURVEY.md section 2 rows 10 / 13 are out of scope; kept as a consumer of
+``coverage.py`` that checks it against the reference's recorded Haar volumes): scoring candidate basis gates by what their circuits can
+reach -- the sweep BASELINE configs[4] is shaped like.
 
 The reference builds a grid of ``ConversionGainGate`` candidates (``build_gates``, src/slam/utils/gates/bare_candidates.py:47-69) and gives
 every one three scores from its monodromy coverage set (``collect_data``, bare_candidates.py:75-126): the Haar expectation of the number
@@ -21,9 +23,13 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import coverage
-from .gates import ConversionGainGate, gate_matrix
-from .weyl import c1c2c3
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slam_decomposition_amd import coverage  # noqa: E402
+from slam_decomposition_amd.gates import ConversionGainGate, gate_matrix  # noqa: E402
+from slam_decomposition_amd.weyl import c1c2c3  # noqa: E402
 
 CNOT_COORDS = (0.5, 0.0, 0.0)
 SWAP_COORDS = (0.5, 0.5, 0.5)
