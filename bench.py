@@ -702,22 +702,11 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
                 seq_coords = [host_c1c2c3(g)] * 3
             else:
                 seq_coords = [host_c1c2c3(table[i]) for i in gate_seqs[2]]
-            lb = c.predict_spans(seq_coords, 3, first, n_per_step, tol=5e-4)
-            ran = False
-            for k in np.unique(lb):
-                k = int(k)
-                if k < 1 or k > 3:
-                    continue  # local targets need no gate; targets beyond the whole template's reach are not optimised
-                c.decompose_list(first + np.nonzero(lb == k)[0], k, 3, gate_seqs[k - 1 :], prm, threshold, k_layout=3)
-                ran = True
-            if ran:
-                best_loss, best_x, best_cycles = c.fetch_results_range(3, first, n_per_step)
-            else:  # a gate too weak for any target of the batch: nothing to optimise
-                best_loss, best_cycles = np.full(n_per_step, np.inf), np.full(n_per_step, -1, dtype=np.int32)
-            best_loss[lb < 1] = 0.0
-            best_cycles[lb < 1] = 0
-            best_loss[lb > 3] = np.inf  # not optimised in this step (their resident slots may hold an earlier step's result)
-            best_cycles[lb > 3] = -1
+            # round 5: lookup, per-size lists and the span loop in ONE chain of kernels (slam_decompose_predicted, carry: a target that
+            # misses the threshold at its size goes on to the next) -- round 4 built the lists on the host, one call per size.
+            # Local targets come back as (0, 0), targets beyond the whole template's reach as (+inf, -1).
+            c.decompose_predicted(seq_coords, 3, gate_seqs, prm, threshold, first, n_per_step, carry=True, tol=5e-4)
+            best_loss, best_x, best_cycles = c.fetch_results_range(3, first, n_per_step)
             return best_loss, best_cycles
         if sweep:
             c.set_gates(np.stack([sweep_gate(basis_of(s))]))

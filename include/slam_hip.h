@@ -303,6 +303,22 @@ int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t co
                              double* best_loss, double* best_x, int32_t* best_cycles);
 
 /*
+ * CircuitTemplate(use_polytopes=True) for the resident targets [first, first + count) in ONE chain of kernels (round 5): the template
+ * size every target needs is looked up on the device (the half-spaces of slam_predict_spans: `point`, `bounds[k_max][14]`, `tol`), the
+ * targets are sorted into per-size lists there, and one span loop runs in which the targets of size k join at stage k -- what
+ * get_spanning_range + _run do per target in the reference (src/slam/basis.py:95-100 -> utils/polytopes/polytope_wrap.py:39-94,
+ * src/slam/optimizer.py:233-303), without the host's per-size index lists and one slam_decompose_list call per size.
+ *   carry = 0  exact regions: a target runs at its own size only (the reference's range(k, k + 1));
+ *   carry = 1  a target that misses success_threshold at its size goes on to the next one (lower bounds, widened regions).
+ * gate_seqs: the sequences of spans 1 .. k_max, concatenated.  Results stay resident (rows 6 (k_max + 1) wide: fetch with
+ * slam_fetch_results_range(ctx, k_max, ...)); a local target (size 0) gets (loss 0, cycles 0), a target out of the template's reach
+ * (+inf, -1); their numbers come back in n_local / n_unreachable (either may be NULL).
+ */
+int slam_decompose_predicted(slam_ctx* ctx, int64_t first, int64_t count, int k_max, const double* point, const double* bounds, double tol,
+                             int carry, const int32_t* gate_seqs, const slam_opt_params* params, double success_threshold,
+                             int64_t* n_local, int64_t* n_unreachable);
+
+/*
  * Running best loss of resident targets [first, first + count) after every span the span loop ran for them:
  * out[t][k - 1] = best loss after span k, NaN where the target did not run span k (solved earlier, or k outside the
  * call's range) -- the value of the reference's "Cycle (k =...), Best Loss=..." log line (src/slam/optimizer.py:297).

@@ -59,6 +59,7 @@ EXPORTED_SYMBOLS = (
     "slam_fetch_results",
     "slam_decompose_range",
     "slam_decompose_list",
+    "slam_decompose_predicted",
     "slam_decompose_multi",
     "slam_decompose_range_fetch",
     "slam_fetch_results_range",
@@ -190,6 +191,7 @@ def load_library() -> C.CDLL:
     if hasattr(lib, "slam_decompose_range_fetch"):  # (absent from older A/B builds selected with SLAM_HIP_LIB)
         lib.slam_decompose_range_fetch.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P, P]
     lib.slam_decompose_list.argtypes = [P, P, C.c_int64, C.c_int, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
+    lib.slam_decompose_predicted.argtypes = [P, C.c_int64, C.c_int64, C.c_int, P, P, C.c_double, C.c_int, P, C.POINTER(OptParams), C.c_double, P, P]
     if hasattr(lib, "slam_decompose_multi"):
         lib.slam_decompose_multi.argtypes = [C.POINTER(P), C.c_int32, C.c_int64, C.c_int64, C.c_int, C.c_int, P, C.POINTER(OptParams), C.c_double]
     lib.slam_fetch_results_range.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, P, P]
@@ -491,6 +493,27 @@ class Context:
         flat = self._flat_gate_seqs(gate_seqs, k_min, k_max)
         _check(self._lib.slam_decompose_list(self._h, _ptr(idx), idx.shape[0], k_min, k_max, int(k_layout), _ptr(flat),
                                               C.byref(params), float(success_threshold)))
+
+    def decompose_predicted(self, gate_coords_seq, k_max: int, gate_seqs, params: OptParams, success_threshold: float, first: int = 0,
+                            count: Optional[int] = None, carry: bool = False, tol: float = 2e-8):
+        """``use_polytopes`` mode for the resident targets [first, first + count) in one chain of kernels (slam_decompose_predicted): the
+        coverage lookup of ``predict_spans``, per-size target lists and the span loop, all on the device.  ``gate_seqs``: the sequences
+        of spans 1..k_max.  Results stay resident (``fetch_results_range(k_max, ...)``).  Returns (n_local, n_unreachable)."""
+        from . import coverage
+
+        g = np.asarray(gate_coords_seq, dtype=np.float64).reshape(-1, 3)
+        if not 1 <= k_max <= min(len(g), MAX_SPAN_MINIMIZE):
+            raise ValueError(f"k_max must be 1..{min(len(g), MAX_SPAN_MINIMIZE)}")
+        count = self.n_targets - first if count is None else count
+        point = np.ascontiguousarray(coverage.alcove_coordinates(g[:1])[0])
+        bounds = np.full((k_max, len(coverage._PATTERNS)), -np.inf)
+        for k in range(2, k_max + 1):
+            bounds[k - 1] = coverage.region(g[:k])
+        flat = self._flat_gate_seqs(gate_seqs, 1, k_max)
+        n_loc, n_unr = C.c_int64(0), C.c_int64(0)
+        _check(self._lib.slam_decompose_predicted(self._h, int(first), int(count), int(k_max), _ptr(point), _ptr(bounds), float(tol), int(bool(carry)),
+                                                  _ptr(flat), C.byref(params), float(success_threshold), C.byref(n_loc), C.byref(n_unr)))
+        return int(n_loc.value), int(n_unr.value)
 
     def fetch_results_range(self, k_max: int, first: int, count: int):
         nmax = 6 * (k_max + 1)

@@ -97,8 +97,6 @@ class CircuitTemplateV2(VariationalTemplate):
             raise NotImplementedError("the HIP template optimizer handles 2-qubit templates only")
         if param_vec_expand is not None:
             raise NotImplementedError("param_vec_expand (time-sliced smush gates, basisv2.py:47-50) is not implemented on the HIP path")
-        if use_polytopes:
-            raise NotImplementedError("CircuitTemplateV2 with use_polytopes needs monodromy (basisv2.py:77-85)")
         for el in edge_params:
             for e in el:
                 if tuple(e) != (0, 1):
@@ -125,7 +123,10 @@ class CircuitTemplateV2(VariationalTemplate):
         self.constraint_func = None
         self.using_bounds = False
         self.using_constraints = False
-        self.spanning_range = range(1, maximum_span_guess + 1)
+        # basisv2.py:66-70: the brute-force range exists only without polytopes.  With them (basisv2.py:77-85 ->
+        # monodromy_range_from_target) the template size comes from the coverage set: here coverage.py's regions of the circuit the
+        # bounds FIX (every gate parameter bounded to a point) -- see get_spanning_range
+        self.spanning_range = None if use_polytopes else range(1, maximum_span_guess + 1)
         self.maximum_span_guess = maximum_span_guess
         self.coverage = None
         super().__init__(preseed=preseed, use_polytopes=use_polytopes)
@@ -150,7 +151,56 @@ class CircuitTemplateV2(VariationalTemplate):
         return [i % len(self.base_gates) for i in range(k)]
 
     def get_spanning_range(self, target_u):
-        return self.spanning_range
+        """basisv2.py:77-85.  Without polytopes: the brute-force range.  With them: ``range(k, k + 1)`` for the smallest template that
+        reaches the target (polytope_wrap.py:39-94).  The reference reads that off a precomputed ``coverage`` list the caller has to
+        attach; here the regions come from coverage.py, which describes circuits of FIXED gates -- so every gate parameter must be
+        bounded to a point (``add_bound(name, max=v, min=v)``); a template whose gates are still free has no single monodromy
+        polytope per size and raises."""
+        if not self.use_polytopes:
+            return self.spanning_range
+        from .weyl import c1c2c3
+
+        k = int(self.minimal_spans(np.array([c1c2c3(target_u)]))[0])
+        return range(k, k + 1)
+
+    def fixed_gate_coordinates(self, k_max=None):
+        """Weyl coordinates of the template's gates G_1 .. G_kmax when the bounds fix them (min == max for every gate parameter)."""
+        from .gates import gate_matrix
+        from .weyl import c1c2c3
+
+        k_max = int(self.maximum_span_guess) if k_max is None else int(k_max)
+        qn = self.n_gate_params
+        coords = []
+        for j, gi in enumerate(self.gate_sequence(k_max)):
+            vals = []
+            for m in range(qn):
+                b = self.bounds.get(f"Q{qn * j + m}")
+                if b is None or b[0] is None or b[1] is None or float(b[0]) != float(b[1]):
+                    raise NotImplementedError(
+                        f"CircuitTemplateV2(use_polytopes=True): gate parameter Q{qn * j + m} is free -- the coverage regions (coverage.py) "
+                        "describe circuits of fixed gates; bound every gate parameter to a point (add_bound(name, max=v, min=v)), or attach "
+                        "nothing and run without polytopes")
+                vals.append(float(b[0]))
+            coords.append(c1c2c3(gate_matrix(self.base_gates[gi](*vals))))
+        return coords
+
+    def minimal_spans(self, target_coords) -> np.ndarray:
+        """Template size per target from the exact coverage regions of the fixed-gate circuit; raises like the reference's lookup
+        for a target out of reach (polytope_wrap.py:91-93)."""
+        if not self.use_polytopes:
+            raise ValueError("minimal_spans needs use_polytopes=True")
+        from . import coverage
+
+        kmax = int(self.maximum_span_guess)
+        saved = self.cycles
+        try:
+            self.cycles = kmax  # (add_bound names refer to the longest template)
+            k = coverage.minimal_prefix(np.asarray(target_coords, dtype=np.float64).reshape(-1, 3), self.fixed_gate_coordinates(kmax), kmax)
+        finally:
+            self.cycles = saved
+        if np.any(k > kmax):
+            raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
+        return k
 
     def _n_p(self, k=None) -> int:
         k = self.cycles if k is None else k

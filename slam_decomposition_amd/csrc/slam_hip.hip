@@ -118,6 +118,8 @@ struct slam_ctx {
     int32_t result_nmax = 0;
     int64_t result_filled = 0;  // targets whose resident results have been initialised (+inf / -1) for result_nmax
     DevBuf counters;  // StageCtl[SLAM_MAX_SPAN_EVAL + 2]: one control block per span stage (slam_kernels.hpp)
+    DevBuf bucket_lists, bucket_counts;  // slam_decompose_predicted: per-size target lists [k_max][count], their sizes
+    int32_t* h_bucket_counts = nullptr;  // pinned mirror of bucket_counts
     DevBuf solved;
     DevBuf stage_targets;
     DevBuf span_gates;  // 64 slots x [SLAM_MAX_SPAN_EVAL][32] doubles
@@ -156,7 +158,7 @@ struct slam_ctx {
 
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_rec, &item_x, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &v2_cons_w[0], &v2_cons_w[1], &v2_cons_w[2], &v2_cons_w[3], &v2_cons_w[4], &v2_cons_w[5], &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
+                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &bucket_lists, &bucket_counts, &v2_cons_w[0], &v2_cons_w[1], &v2_cons_w[2], &v2_cons_w[3], &v2_cons_w[4], &v2_cons_w[5], &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -166,6 +168,7 @@ struct slam_ctx {
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_stage) (void)hipHostFree(h_stage);
         if (h_gates) (void)hipHostFree(h_gates);
+        if (h_bucket_counts) (void)hipHostFree(h_bucket_counts);
         if (h_mq_args) (void)hipHostFree(h_mq_args);
         mq_args.release();
         spec_loss.release();
@@ -1698,6 +1701,97 @@ int slam_decompose_list(slam_ctx* ctx, const int32_t* targets, int64_t count, in
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     if (!targets) return fail(SLAM_ERR_INVALID, "targets is NULL");
     return decompose_impl(ctx, 0, count, k_min, k_max, gate_seqs, params, success_threshold, targets, k_layout);
+}
+
+// -----------------------------------------------------------------------------------------------------------------------
+// slam_decompose_predicted: CircuitTemplate(use_polytopes=True) for a window of RESIDENT targets without a host step in between --
+// the coverage lookup (span_predict_kernel), the per-size target lists (span_bucket_kernel) and ONE span loop in which the targets of
+// size k join the loop at stage k.  carry = 0: a target runs at its own size only (exact regions: basis.py:95-100 returns
+// range(k, k + 1)); carry = 1: targets that miss the threshold go on to the next size (regions widened by `tol`, lower bounds).
+// Replaces the host's np.nonzero + one slam_decompose_list per size (round 4).
+// -----------------------------------------------------------------------------------------------------------------------
+int decompose_predicted_body(slam_ctx* c, int64_t first, int64_t count, int k_max, const double* point, const double* bounds, double tol,
+                             int carry, const int32_t* gate_seqs, const slam_opt_params* prm, double success_threshold,
+                             int64_t* n_local, int64_t* n_unreachable) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_targets <= 0) return fail(SLAM_ERR_STATE, "no targets");
+    if (c->n_gates <= 0) return fail(SLAM_ERR_STATE, "no gates");
+    if (first < 0 || count <= 0 || first + count > c->n_targets) return fail(SLAM_ERR_INVALID, "target window outside the resident batch");
+    if (k_max < 1 || k_max > SLAM_MAX_SPAN_MINIMIZE) return fail(SLAM_ERR_INVALID, "k_max must be 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k_max);
+    if (!point || (k_max > 1 && !bounds) || !gate_seqs) return fail(SLAM_ERR_INVALID, "point / bounds / gate_seqs is NULL");
+    int rc = check_params(prm);
+    if (rc) return rc;
+    {
+        const int32_t* gs = gate_seqs;
+        for (int k = 1; k <= k_max; ++k) {
+            rc = check_gate_seq(c, k, gs);
+            if (rc) return rc;
+            gs += k;
+        }
+    }
+    if (c->result_nmax != 0 && c->result_nmax != 6 * (k_max + 1) && !(first == 0 && count == c->n_targets))
+        return fail(SLAM_ERR_STATE, "resident results were produced with a different k_max");
+    rc = ensure_results(c, k_max);
+    if (rc) return rc;
+    const int64_t N = count;
+    HIP_TRY(c->active.reserve(N * sizeof(int32_t)));
+    HIP_TRY(c->active2.reserve(N * sizeof(int32_t)));
+    HIP_TRY(c->bucket_lists.reserve((size_t)k_max * N * sizeof(int32_t)));
+    HIP_TRY(c->bucket_counts.reserve((size_t)(SLAM_MAX_SPAN_EVAL + 2) * sizeof(int32_t)));
+    HIP_TRY(c->ev_weyl.reserve((size_t)N * sizeof(int32_t)));
+    if (!c->h_bucket_counts) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_bucket_counts), (SLAM_MAX_SPAN_EVAL + 2) * sizeof(int32_t), hipHostMallocDefault));
+    rc = reserve_stage_buffers(c, N, k_max, prm);
+    if (rc) return rc;
+    SpanRegions r{};
+    r.k_max = k_max;
+    r.tol = tol;
+    for (int j = 0; j < 4; ++j) r.point[j] = point[j];
+    for (int k = 2; k <= k_max; ++k)
+        for (int p = 0; p < kSpanPatterns; ++p) r.bounds[k - 1][p] = bounds[(size_t)(k - 1) * kSpanPatterns + p];
+    HIP_TRY(hipEventRecord(c->ev_t0, c->stream));
+    const int n_words = (int)(sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2) / 8);
+    hipLaunchKernelGGL(clear_ctl_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream, c->counters.as<StageCtl>(), n_words,
+                       c->bucket_counts.as<int32_t>(), SLAM_MAX_SPAN_EVAL + 2);
+    HIP_TRY(hipGetLastError());
+    int32_t* d_spans = c->ev_weyl.as<int32_t>();
+    hipLaunchKernelGGL(span_predict_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, c->stream, c->targets.as<double>() + first * 32, N, r, d_spans);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(span_bucket_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_spans, first, N, (int32_t)k_max,
+                       c->bucket_lists.as<int32_t>(), c->bucket_counts.as<int32_t>(), c->best_loss.as<double>(), c->best_cycles.as<int32_t>(),
+                       c->span_loss.as<double>());
+    HIP_TRY(hipGetLastError());
+    DevBuf* cur = &c->active;
+    DevBuf* nxt = &c->active2;
+    const int32_t* gs = gate_seqs;
+    for (int k = 1; k <= k_max; ++k) {
+        // stage k's list: what the previous stage carried over (carry) + the targets of size k
+        hipLaunchKernelGGL(stage_append_kernel, dim3(1), dim3(1024), 0, c->stream, c->bucket_lists.as<int32_t>() + (size_t)(k - 1) * N,
+                           c->bucket_counts.as<int32_t>() + (k - 1), stage_ctl(c, k), cur->as<int32_t>());
+        HIP_TRY(hipGetLastError());
+        SpanLoopStep step{success_threshold, false, carry && k < k_max, success_threshold, nxt->as<int32_t>()};
+        rc = enqueue_stage(c, k, gs, cur->as<int32_t>(), N, nullptr, prm, &step);
+        if (rc) return rc;
+        gs += k;
+        DevBuf* t = cur; cur = nxt; nxt = t;
+    }
+    HIP_TRY(hipEventRecord(c->ev_t1, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_ctl, c->counters.p, sizeof(StageCtl) * (SLAM_MAX_SPAN_EVAL + 2), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_bucket_counts, c->bucket_counts.p, (SLAM_MAX_SPAN_EVAL + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_done, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_done));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+    c->stats.total_ms = ms;
+    if (n_local) *n_local = c->h_bucket_counts[k_max];
+    if (n_unreachable) *n_unreachable = c->h_bucket_counts[k_max + 1];
+    return collect_stats(c, 1, k_max, c->h_ctl, prm->restarts);
+}
+
+int slam_decompose_predicted(slam_ctx* ctx, int64_t first, int64_t count, int k_max, const double* point, const double* bounds, double tol,
+                             int carry, const int32_t* gate_seqs, const slam_opt_params* params, double success_threshold,
+                             int64_t* n_local, int64_t* n_unreachable) {
+    if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
+    return drained(ctx, decompose_predicted_body(ctx, first, count, k_max, point, bounds, tol, carry, gate_seqs, params, success_threshold, n_local, n_unreachable));
 }
 
 int slam_fetch_results_range(slam_ctx* ctx, int k_max, int64_t first, int64_t count, double* best_loss,

@@ -1111,6 +1111,53 @@ __global__ void stage_prepare_kernel(const double* targets, const int32_t* activ
 // single-stage calls: the host knows the target count
 __global__ void set_n_active_kernel(StageCtl* ctl, int32_t n) { ctl->n_active = n; }
 
+// ---------------------------------------------------------------------------------
+// slam_decompose_predicted: template sizes from the coverage lookup (span_predict_kernel), per-size target lists built on the device.
+//   counts[k - 1]   targets whose size is k (1 .. k_max);  counts[k_max] local targets (size 0), counts[k_max + 1] out of reach
+//   lists[(k - 1) * n + i]  the i-th target of size k (resident index; order = arrival order of the wavefronts -- a target's result
+//                           does not depend on its place in a list)
+// Also resets the window's results: (+inf, -1) -- (0, 0) for a local target, which needs no gate.
+// ---------------------------------------------------------------------------------
+__global__ void span_bucket_kernel(const int32_t* __restrict__ spans, int64_t first, int64_t n, int32_t k_max, int32_t* __restrict__ lists,
+                                   int32_t* __restrict__ counts, double* best_loss, int32_t* best_cycles, double* span_loss) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = t < n;
+    const int32_t s = in ? spans[t] : -1;
+    if (in) {
+        const int64_t tgt = first + t;
+        best_loss[tgt] = s == 0 ? 0.0 : (double)INFINITY;
+        best_cycles[tgt] = s == 0 ? 0 : -1;
+        for (int j = 0; j < kSpanLossStride; ++j) span_loss[tgt * kSpanLossStride + j] = NAN;
+    }
+    const int32_t slot = !in ? -1 : (s == 0 ? k_max : (s > k_max ? k_max + 1 : s - 1));
+    const unsigned long long lt = (1ull << (threadIdx.x & 63)) - 1ull;
+    for (int32_t b = 0; b <= k_max + 1; ++b) {  // one atomic per wavefront and class
+        const unsigned long long m = __ballot(slot == b);
+        if (m == 0ull) continue;
+        int32_t base = 0;
+        if ((threadIdx.x & 63) == __builtin_ctzll(m)) base = atomicAdd(&counts[b], __popcll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (slot == b && b < k_max) lists[(int64_t)b * n + base + __popcll(m & lt)] = (int32_t)(first + t);
+    }
+}
+
+// the targets of size k join the stage's active list behind the ones carried over from the previous stage (single workgroup: the
+// base offset is read before anybody moves it)
+__global__ void stage_append_kernel(const int32_t* __restrict__ bucket, const int32_t* __restrict__ count, StageCtl* ctl, int32_t* active) {
+    __shared__ int32_t base_s;
+    if (threadIdx.x == 0) base_s = ctl->n_active;
+    __syncthreads();
+    const int32_t base = base_s, n = *count;
+    for (int32_t i = threadIdx.x; i < n; i += blockDim.x) active[base + i] = bucket[i];
+    __syncthreads();
+    if (threadIdx.x == 0) ctl->n_active = base + n;
+}
+__global__ void clear_ctl_kernel(StageCtl* ctl_all, int32_t n_words, int32_t* counts, int32_t n_counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) reinterpret_cast<unsigned long long*>(ctl_all)[i] = 0ull;
+    if (i < n_counts) counts[i] = 0;
+}
+
 // reset the results of targets [first, first + n), (optionally) write their indices as the initial
 // active list, and publish n as the first stage's target count
 // ... and prepare the first stage's inputs (early-exit flags; the window's targets as a dense array when

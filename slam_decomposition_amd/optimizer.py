@@ -292,7 +292,7 @@ class TemplateOptimizer:
     # ordered early exit makes a target's result independent of what runs beside it, so the result equals the single call's bit
     # for bit.  Reference: the sequential loop over the sampler, optimizer.py:180-186.
     WINDOW_TARGETS = 65536
-    windows_in_flight = 5
+    windows_in_flight = 4  # measured on 327 680 targets (tools/r5_api_large_probe.py): 2 / 3 / 4 / 5 in flight 112 / 107 / 81 / 88 ms
 
     window_stagger = False
 
@@ -540,6 +540,28 @@ class TemplateOptimizer:
         self._span_losses = ctx.fetch_span_losses(0, len(targets)) if self._want_span_losses else None
         self._set_stats([ctx.stats()])
         return best_loss, best_x, best_cycles  # (padded rows [n, 6 (k_top + 1)]: cut at 6 (cycles + 1) on access)
+
+    def _run_batch_predicted(self, ctx, n: int):
+        """Polytope mode for targets that were generated on the device (exact coverage regions): lookup, per-size lists and the span
+        loop in one chain of kernels (``slam_decompose_predicted``) -- no index list is built on the host (round 4: ``np.nonzero`` per
+        size + one ``slam_decompose_list`` each).  The reference's failures keep their exceptions: a target no prefix of the template
+        reaches (polytope_wrap.py:91-93), a local target (``build(0)``, basis.py:127-128)."""
+        kmax = int(self.basis.maximum_span_guess)
+        self._device_sampler.fill(ctx)
+        ctx.set_gates(self.basis.gate_matrices)
+        ctx.set_cost(self._cost_kind)
+        ctx.reset_stats()
+        prm = self._opt_params()
+        n_local, n_unreach = ctx.decompose_predicted([self.basis._gate_coords_all[i] for i in self.basis.gate_sequence(kmax)], kmax,
+                                                     [self.basis.gate_sequence(k) for k in range(1, kmax + 1)], prm, self.success_threshold, 0, n)
+        if n_unreach:
+            raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
+        if n_local:
+            raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
+        best_loss, best_x, best_cycles = ctx.fetch_results_range(kmax, 0, n)
+        self._span_losses = None
+        self._set_stats([ctx.stats()])
+        return best_loss, best_x, best_cycles
 
     def _run_batch_v2(self, targets: np.ndarray, spanning_range):
         """``_run`` for a CircuitTemplateV2 (optimizer.py:233-303 with method "L-BFGS-B" when the template has bounds, "BFGS"
@@ -885,24 +907,43 @@ class TemplateOptimizer:
             spanning_range = list(self.basis.get_spanning_range(stacked[0]))
             spans_of = [spanning_range] * n
             best_loss, best_xs, best_cycles = self._run_batch_host_method(stacked, spanning_range)
+        elif self._v2 and not self.use_callback and self.basis.use_polytopes:
+            # basisv2.py:77-85: every target at the size its coverage region assigns; one run per size over that size's targets
+            spans = np.asarray(self.basis.minimal_spans(ctx0.c1c2c3(np.asarray(stacked))), dtype=np.int64)
+            if np.any(spans <= 0):
+                raise ValueError()  # build(n_repetitions <= 0), basisv2.py:221-222
+            spans_of = [[int(k)] for k in spans]
+            best_loss = np.full(n, np.inf)
+            best_xs = [None] * n
+            best_cycles = np.full(n, -1, dtype=np.int32)
+            sl_all = np.full((n, _ffi.MAX_SPAN_EVAL), np.nan)
+            stats = []
+            for k in np.unique(spans):
+                sel = np.nonzero(spans == k)[0]
+                bl, bx, bc = self._run_batch_v2(np.asarray(stacked)[sel], [int(k)])
+                best_loss[sel], best_cycles[sel] = bl, bc
+                for i, x in zip(sel.tolist(), bx):
+                    best_xs[i] = x
+                if self._span_losses is not None:
+                    sl_all[sel] = self._span_losses
+                stats.extend(self.last_stats_per_device)
+            self._span_losses = sl_all
+            self._set_stats(stats)
         elif self._v2 and not self.use_callback:
             spanning_range = list(self.basis.get_spanning_range(stacked[0]))
             spans_of = [spanning_range] * n
             best_loss, best_xs, best_cycles = self._run_batch_v2(stacked, spanning_range)
         elif self.use_callback:
             if self.basis.use_polytopes:
+                if coords_arr is None:
+                    coords_arr = ctx0.c1c2c3(np.asarray(stacked))
                 top = None if getattr(self.basis, "span_rules_exact", True) else int(self.basis.maximum_span_guess)
                 spans_of = [list(range(int(k), (int(k) if top is None else top) + 1)) for k in self.basis.minimal_spans(coords_arr)]
             else:
                 spans_of = [list(self.basis.get_spanning_range(stacked[0]))] * n
             best_loss, best_xs, best_cycles = self._run_batch_callback(stacked, spans_of)
         elif poly_resident:
-            kmax = int(self.basis.maximum_span_guess)
-            self._device_sampler.fill(ctx0)
-            spans = ctx0.predict_spans([self.basis._gate_coords_all[i] for i in self.basis.gate_sequence(kmax)], kmax, 0, n).astype(np.int64)
-            if np.any(spans > kmax):
-                raise ValueError("Monodromy did not find a polytope containing U")  # polytope_wrap.py:91-93
-            best_loss, best_xs, best_cycles = self._run_batch_by_span(stacked, spans)
+            best_loss, best_xs, best_cycles = self._run_batch_predicted(ctx0, n)
         elif getattr(self.basis, "mixed_order", False):
             best_loss, best_xs, best_cycles = self._run_batch_mixed_order(stacked, coords_arr)
             spans_of = [None] * n  # (the log lines come from _entries_tried)

@@ -281,3 +281,111 @@ def test_v2_hip_path_matches_the_finite_difference_reference_path():
     assert np.all(r_loss < level) and np.all(best < level)
     assert np.array_equal(cyc, r_cyc)
     assert np.max(np.abs(best - r_loss)) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# item 6: the polytope mode without a host step
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("carry", [False, True])
+def test_decompose_predicted_equals_the_host_driven_polytope_mode(carry):
+    """slam_decompose_predicted (lookup + per-size lists + one span loop, all on the device) against the round-4 form -- predict_spans,
+    ``np.nonzero`` per size, one slam_decompose_list per size -- on the mixed sequence of BASELINE configs[3] and on a weak
+    conversion-gain gate that leaves targets out of reach: identical losses, cycles and parameters bit for bit (a target's result
+    does not depend on its place in a list), the same local / unreachable counts."""
+    from bench import sweep_gate
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    n, R = 3000, 8
+    for table in (np.stack([G.RiSwapGate(1.0).to_matrix(), G.BerkeleyGate().to_matrix()]), np.stack([sweep_gate(24)])):
+        seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
+        coords = [c1c2c3(table[i]) for i in seqs[2]]
+        prm = _ffi.OptParams(restarts=R, seed=9, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+        tol = 5e-4 if carry else 2e-8
+        with _ffi.Context(0) as a, _ffi.Context(0) as b:
+            for c in (a, b):
+                c.sample_haar(31415, n)
+                c.set_gates(table)
+            # identity-like targets cannot come out of the Haar sampler: a local one is planted through set_targets below
+            lb = a.predict_spans(coords, 3, 0, n, tol=tol)
+            for k in np.unique(lb):
+                if 1 <= k <= 3:
+                    a.decompose_list(np.nonzero(lb == k)[0], int(k), 3 if carry else int(k), seqs[int(k) - 1 : (3 if carry else int(k))], prm, 1e-10, k_layout=3)
+            la, xa, ca = a.fetch_results_range(3, 0, n)
+            n_loc, n_unr = b.decompose_predicted(coords, 3, seqs, prm, 1e-10, 0, n, carry=carry, tol=tol)
+            lb_, xb, cb = b.fetch_results_range(3, 0, n)
+            assert n_loc == int((lb == 0).sum()) and n_unr == int((lb > 3).sum())
+            ran = (lb >= 1) & (lb <= 3)
+            assert np.array_equal(la[ran], lb_[ran]) and np.array_equal(ca[ran], cb[ran])
+            for t in np.nonzero(ran)[0][::37]:
+                w = 6 * (int(ca[t]) + 1)
+                assert np.array_equal(xa[t, :w], xb[t, :w])
+            assert np.all(np.isinf(lb_[lb > 3])) and np.all(cb[lb > 3] == -1)
+            assert b.stats()["items"][1] == int((lb == 1).sum()) * R
+
+
+def test_use_polytopes_on_a_device_sampler_runs_without_a_host_list():
+    """TemplateOptimizer(CircuitTemplate(use_polytopes=True)) on a DeviceHaarBatch goes through slam_decompose_predicted: same
+    target_data as the host-side polytope mode (a plain sampler of the same targets)."""
+    n, R = 2000, 8
+    basis = CircuitTemplate(base_gates=[G.RiSwapGate(0.5)], maximum_span_guess=3, use_polytopes=True)
+    s = DeviceHaarBatch(seed=777, n_samples=n)
+    a = TemplateOptimizer(basis, BasicCost(), training_restarts=R, seed=2, override_fail=True)
+    la, _, da = a.approximate_from_distribution(s)
+    T = DeviceHaarBatch(seed=777, n_samples=n).as_array()
+
+    class L:
+        def __iter__(self):
+            return iter(T)
+
+    b = TemplateOptimizer(basis, BasicCost(), training_restarts=R, seed=2, override_fail=True)
+    lb, _, db = b.approximate_from_distribution(L())
+    assert la == lb
+    for i in range(0, n, 53):
+        assert da[i].cycles == db[i].cycles and np.array_equal(np.asarray(da[i].Xk), np.asarray(db[i].Xk))
+    assert np.mean(np.asarray(la) < 1e-10) > 0.99  # (exact size only, 8 restarts: a few targets next to a region's face miss it)
+
+
+def test_v2_template_with_polytopes_runs_at_the_predicted_size():
+    """CircuitTemplateV2(use_polytopes=True) (basisv2.py:77-85 -> polytope_wrap.py:39-94): with every gate parameter bounded to a
+    point the circuit is one of fixed gates and coverage.py gives its regions -- sqrt(iSWAP) here: every target runs ONLY at the
+    size the rule |z| <= x - y assigns and is solved there; a template whose gates are free raises; so does a target out of reach."""
+    from slam_decomposition_amd.basisv2 import CircuitTemplateV2
+    from slam_decomposition_amd.cost_function import SquareCost
+    from slam_decomposition_amd.gates import RiSwapGate
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    basis = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=3, use_polytopes=True)
+    assert basis.spanning_range is None
+    with pytest.raises(NotImplementedError):
+        basis.get_spanning_range(o.haar_unitary(0))  # alpha free: no single polytope per size
+    basis.build(3)
+    for name in basis.parameter_names():
+        if name.startswith("Q"):
+            basis.add_bound(name, max=0.5, min=0.5)
+    T = [o.haar_unitary(300 + i) for i in range(10)]
+    want = []
+    for t in T:
+        c1, c2, c3 = c1c2c3(t)
+        if c1 > 0.5:
+            c1, c3 = 1 - c1, -c3
+        want.append(2 if abs(c3) <= c1 - c2 + 1e-9 else 3)
+    assert [list(basis.get_spanning_range(t)) for t in T] == [[k] for k in want]
+    optm = TemplateOptimizer(basis, SquareCost(), training_restarts=16, seed=8, override_fail=True)
+
+    class S:
+        def __iter__(self):
+            return iter(T)
+
+    loss, _, data = optm.approximate_from_distribution(S())
+    for t, td in enumerate(data):
+        assert td.cycles == want[t] and td.success_label == 1 and td.loss_result <= 1e-10
+        basis.build(td.cycles)
+        assert abs(o.square_cost(basis.eval(td.Xk), T[t]) - td.loss_result) < 1e-12
+        assert np.allclose(np.asarray(td.Xk)[-td.cycles:], 0.5)
+    assert optm.last_stats["items"][1] == 0  # nobody ran the one-gate template
+    weak = CircuitTemplateV2(base_gates=[RiSwapGate], maximum_span_guess=2, use_polytopes=True)
+    weak.build(2)
+    for name in ("Q0", "Q1"):
+        weak.add_bound(name, max=0.25, min=0.25)
+    with pytest.raises(ValueError, match="Monodromy did not find"):
+        weak.get_spanning_range(G.SwapGate().to_matrix())
