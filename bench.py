@@ -20,16 +20,8 @@ Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
 """
 from __future__ import annotations
 
-import argparse
-import json
 import os
-import subprocess
 import sys
-import tempfile
-import threading
-import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 # one hardware queue per batch in flight (the HIP runtime maps streams onto 4 hardware queues by default;
@@ -38,1151 +30,13 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP64_VALU_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
-SUCCESS_LOSS = 1e-8  # BASELINE.json metric: loss < 1e-8
-TARGET_SEED0 = 20260000
-OPT_SEED = 20261003
-
-
-def f_eval(k: int) -> int:
-    """Algorithmic flops of one fused loss+gradient evaluation: dense accounting."""
-    return 3036 * k + 1247
-
-
-def f_eval_v2(k: int) -> int:
-    """Parametrised-gate templates (CircuitTemplateV2): F_eval(k) plus, per gate, the four raw-angle derivatives
-    Re(u (dG/d angle) h) over the four columns -- 4 angles x 4 columns x (2x2 complex block times a 2-vector: 22 flop, real part
-    of the 2-term complex dot: 8 flop) = 480 flop -- and the gate's two block entries from its trig values (8 flop): 488 k."""
-    return f_eval(k) + 488 * k
-
-
-def f_forward(k: int) -> int:
-    """Forward chain + loss only (what a rejected line-search trial is worth)."""
-    return 1080 * k + 251
-
-
-WORKLOADS = {
-    # name: (gate builder name, targets per step, restarts, description)
-    "cfg2": ("cx", 1024, 16, "BASELINE configs[1]: CNOT basis span<=3, 1024 Haar targets x 16 restarts, fp64"),
-    "cfg3": ("sqiswap", 65536, 32, "BASELINE configs[2]: sqrt(iSWAP) basis span<=3, 65536 Haar targets x 32 restarts, fp64"),
-    "cfg4": ("iswap+b", 32768, 16, "BASELINE configs[3] per-GPU shard: iSWAP + B mixed basis, 32768 Haar targets x 16 restarts"),
-    # one step = one basis gate of this GPU's 16 (of 128) against the 4096 shared targets
-    "cfg5": ("cgsweep", 4096, 16, "BASELINE configs[4] per-GPU shard: 16 of 128 ConversionGain(0,0,gc,gg,1) bases x 4096 shared Haar targets x 16 restarts"),
-}
-SWEEP_BASES_PER_GPU = 16
-SWEEP_CPU_BASIS = 64  # m = 9/32, p = 0: the basis the CPU baseline of cfg5 runs
-
-
-PER_SPAN_WARM_STEPS = 3  # untimed steps before the single-stream per-span pass
-
-
-def _batches_in_flight(items_per_stage: int, span_rules: bool) -> int:
-    """Library calls kept in flight per GPU.  Measured on MI355X (sqrt(iSWAP) x 32 restarts, equal total work, tools/r4_strong_regime.sh;
-    decompositions/s relative to 65 536 targets x 5 in flight): 8192 targets -- the per-GPU batch of `--scaling strong` on 8 GPUs --
-    x 8 / 12 / 16 in flight 0.80 / 0.84 / 0.88, 16 384 x 8 / 12 0.93 / 0.95, 32 768 x 5 / 8 0.96 / 0.98."""
-    if span_rules:
-        return 8
-    if items_per_stage <= (1 << 18):
-        return 16
-    if items_per_stage <= (1 << 19):
-        return 12
-    if items_per_stage <= (1 << 20):
-        return 8
-    return 5
-
-
-def sweep_gate(b: int) -> np.ndarray:
-    """Basis b of the 128-gate parametric-Hamiltonian sweep (SURVEY.md §8(d) cfg 5, shaped like build_gates(),
-    utils/gates/bare_candidates.py:47-69): gc = p m pi, gg = (1 - p) m pi, 16 values of m in (0, 0.5] x 8 of p in [0, 1]."""
-    from slam_decomposition_amd import gates as G
-
-    m = 0.5 * (b // 8 + 1) / 16
-    pfrac = (b % 8) / 7
-    return G.ConversionGainGate(0.0, 0.0, pfrac * m * np.pi, (1 - pfrac) * m * np.pi, 1.0).to_matrix()
-
-
-def gate_table(name: str) -> np.ndarray:
-    from slam_decomposition_amd import gates as G
-
-    if name == "cx":
-        return np.stack([G.CXGate().to_matrix()])
-    if name == "sqiswap":
-        return np.stack([G.RiSwapGate(0.5).to_matrix()])
-    if name == "iswap+b":
-        return np.stack([G.RiSwapGate(1.0).to_matrix(), G.BerkeleyGate().to_matrix()])
-    if name == "cgsweep":
-        return np.stack([sweep_gate(0)])
-    raise ValueError(name)
-
-
-def make_targets(n: int, seed0: int) -> np.ndarray:
-    """T_i = unitary_group.rvs(4, default_rng(seed0 + i))."""
-    from slam_decomposition_amd.sampler import random_unitary
-
-    return np.stack([random_unitary(4, seed=seed0 + i) for i in range(n)])
-
-
-# ------------------------------------------------------------------------------------------------
-# CPU baseline (the oracle; allowed here and only here)
-# ------------------------------------------------------------------------------------------------
-def _cpu_one(args):
-    """One target through the reference path on the CPU oracle (SciPy BFGS, finite differences:
-    src/slam/optimizer.py:270-278), restarts sequential with early break like the reference."""
-    seed0, idx, gname, restarts, seed, host_targets, analytic = args
-    from oracle import slam_oracle as o
-
-    if gname == "cgsweep":
-        gates = [sweep_gate(SWEEP_CPU_BASIS)]  # one representative basis of the sweep (sqrt(iSWAP)-like strength)
-    else:
-        gates = {"cx": [o.cx_matrix()], "sqiswap": [o.riswap_matrix(0.5)], "iswap+b": [o.riswap_matrix(1.0), o.berkeley_matrix()]}[gname]
-    target = o.haar_unitary(seed0 + idx) if host_targets else o.haar_philox_port(seed0, idx)
-    t0 = time.perf_counter()
-    best, xk, k, stats = o.run_reference(
-        target, gates, range(1, 4), restarts, SUCCESS_LOSS, x0_fn=lambda kk, r: o.x0_philox(seed, idx, r, kk),
-        analytic_jac=analytic,
-    )
-    dt = time.perf_counter() - t0
-    # (outside the clock) Weyl coordinates of the circuit the reference path found: compared with the GPU's for the same target
-    coords = o.c1c2c3_raw(o.template_eval(xk, o.gate_sequence(gates, k)))
-    return best, k, dt, stats["nfev"], [float(c) for c in coords]
-
-
-def usable_cores():
-    """(worker count, cgroup CPU quota or None): affinity mask, limited by cpu.max (cgroup v2) / cpu.cfs_quota_us (v1)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    quota = None
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = float(q) / float(per)
-    except (OSError, ValueError):
-        try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                quota = q / per
-        except (OSError, ValueError):
-            pass
-    if quota is not None:
-        n = max(1, min(n, int(quota + 0.5)))
-    return min(n, 64), quota  # (64: beyond that the sample below would exceed the bench's time budget)
-
-
-def parity_sample_size(n_sample: int) -> int:
-    return n_sample if n_sample > 0 else 12 * usable_cores()[0]
-
-
-def weyl_distance(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """Max-norm distance of Weyl coordinates (units of pi), modulo the identification (c1, c2, 0) ~ (1 - c1, c2, 0) on the c3 = 0 face."""
-    d = np.abs(a - b).max(axis=-1)
-    am = a.copy()
-    am[..., 0] = 1.0 - am[..., 0]
-    am[..., 2] = -am[..., 2]
-    return np.minimum(d, np.abs(am - b).max(axis=-1))
-
-
-def parity_sample(res, gpu, gpu_threshold=1e-10):
-    """north_star: "match the reference path's converged loss and recovered Weyl coordinates to 1e-6 on identical Haar targets".
-    `res` = the CPU baseline's per-target results (SciPy BFGS + finite differences on the oracle: the reference's path,
-    optimizer.py:270-278), `gpu` = (best_loss, best_cycles, found coordinates, target coordinates, running best loss per span) of the
-    HIP path for the SAME target indices and Philox start points.  A target counts as solved below SUCCESS_LOSS on either side.
-
-    Four separate verdicts (one `pass` over a widened bound said less than it seemed to):
-      * cycles        equal template sizes.  The reference path stops a span loop at the METRIC's level (loss < 1e-8), the HIP path at the
-                      reference's own SUCCESS_THRESHOLD (1e-10): a target whose HIP loss after span k lies in [1e-10, 1e-8) is solved
-                      at k by the metric's criterion on both sides, and the HIP path goes on to k + 1 -- such targets (identified by the
-                      HIP path's own span losses, not by a constant allowance) count as equal at the metric's level;
-      * loss_1e6      |loss difference| <= 1e-6 on targets solved by both;
-      * gpu_vs_target_1e6   Weyl coordinates of the HIP path's circuits within 1e-6 of the TARGET's;
-      * path_vs_path  HIP circuits against the reference path's circuits: within 1e-6 + 4 sqrt(reference loss) -- the reference path's
-                      own circuits sit ~ sqrt(loss) ~ 3e-5 off the target at its finite-difference floor, so 1e-6 path against path is
-                      not attainable by ANY implementation; the bound used is stated, not 1e-6."""
-    g_loss, g_cyc, g_coords, t_coords = gpu[:4]
-    g_span = gpu[4] if len(gpu) > 4 else None
-    n = min(len(res), len(g_loss))
-    c_loss = np.array([r[0] for r in res[:n]])
-    c_cyc = np.array([r[1] for r in res[:n]])
-    c_coords = np.array([r[4] for r in res[:n]])
-    c_ok, g_ok = c_loss < SUCCESS_LOSS, g_loss[:n] < SUCCESS_LOSS
-    both = c_ok & g_ok
-    neither = ~c_ok & ~g_ok  # out of the template's reach for both (basis sweep): different local minima are not a mismatch
-    strict = both & (c_cyc == g_cyc[:n])
-    # solved at the reference's size by the metric's criterion, continued only because of the stricter internal threshold
-    in_gap = np.zeros(n, dtype=bool)
-    if g_span is not None:
-        for t in np.nonzero(both & (g_cyc[:n] == c_cyc + 1))[0]:
-            v = g_span[t, int(c_cyc[t]) - 1]
-            in_gap[t] = bool(gpu_threshold <= v < SUCCESS_LOSS)
-    cycles_equal = int(strict.sum() + neither.sum())
-    cycles_metric = int((strict | in_gap).sum() + neither.sum())
-    dl = float(np.abs(c_loss - g_loss[:n])[both].max()) if both.any() else 0.0
-    d_gt = weyl_distance(g_coords[:n][both], t_coords[:n][both]) if both.any() else np.zeros(0)
-    d_ct = weyl_distance(c_coords[both], t_coords[:n][both]) if both.any() else np.zeros(0)
-    d_gc = weyl_distance(c_coords[both], g_coords[:n][both]) if both.any() else np.zeros(0)
-    pvp_bound = 1e-6 + 4.0 * np.sqrt(c_loss[both])
-    v_cycles = cycles_metric == n
-    v_loss = dl <= 1e-6
-    v_target = bool(np.all(d_gt <= 1e-6))
-    v_pvp = bool(np.all(d_gc <= pvp_bound))
-    mx = lambda v: float(v.max()) if len(v) else 0.0
-    return {"n": n, "cycles_equal": cycles_equal, "cycles_equal_at_metric_level": cycles_metric, "in_threshold_gap": int(in_gap.sum()),
-            "solved_cpu": int(c_ok.sum()), "solved_gpu": int(g_ok.sum()), "both_unsolved": int(neither.sum()),
-            "max_abs_loss_diff": dl, "max_coord_diff_gpu_vs_target": mx(d_gt), "max_coord_diff_cpu_vs_target": mx(d_ct),
-            "max_coord_diff_gpu_vs_cpu": mx(d_gc),
-            "cycles": bool(v_cycles), "loss_1e6": bool(v_loss), "gpu_vs_target_1e6": v_target,
-            "path_vs_path": {"pass": v_pvp, "bound": "1e-6 + 4 sqrt(reference-path loss)", "max_bound": mx(pvp_bound)},
-            "pass": bool(v_cycles and v_loss and v_target and v_pvp),
-            "what": "reference path (SciPy BFGS, finite differences, sequential restarts on the NumPy oracle) vs the HIP path on the same target "
-                    "indices and the same Philox start points; coordinates = c1c2c3 of the found circuits, units of pi.  `pass` = cycles (equal "
-                    "template sizes; a target the HIP path solved at the reference's size with a loss in [1e-10, 1e-8) and then continued counts "
-                    "as equal at the metric's level) and loss_1e6 and gpu_vs_target_1e6 and path_vs_path (whose bound is NOT 1e-6: see it)"}
-
-
-def cpu_baseline(gname: str, restarts: int, seed0: int, seed: int, n_sample: int, host_targets: bool, gpu_sample=None):
-    import multiprocessing as mp
-
-    # every core the box GIVES this process: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box of
-    # the pool shows 256 CPUs and grants 16: 256 workers on that share ran 17x slower per core than 16) -- `value` is a
-    # whole-share number, `host_cpu_count` / `cpu_quota` say what the share is
-    cores, quota = usable_cores()
-    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(var, "1")  # one target per worker process: no BLAS thread pools on top
-    n_sample = parity_sample_size(n_sample)  # every core busy for a dozen targets: ~15-25 s of wall time for the two passes
-    with mp.get_context("spawn").Pool(cores) as pool:
-        pool.map(abs, range(cores))  # workers up (interpreter + NumPy/SciPy import) before the clock starts
-        t0 = time.perf_counter()
-        res = pool.map(_cpu_one, [(seed0, i, gname, restarts, seed, host_targets, False) for i in range(n_sample)], chunksize=1)
-        wall = time.perf_counter() - t0
-        # second, stronger CPU line (SURVEY.md §8(d)): the same loop with the oracle's analytic gradient
-        t1 = time.perf_counter()
-        res_j = pool.map(_cpu_one, [(seed0, i, gname, restarts, seed, host_targets, True) for i in range(n_sample)], chunksize=1)
-        wall_j = time.perf_counter() - t1
-    ok = sum(1 for r in res if r[0] < SUCCESS_LOSS)
-    cpu_s = sum(r[2] for r in res)
-    ok_j = sum(1 for r in res_j if r[0] < SUCCESS_LOSS)
-    cpu_sj = sum(r[2] for r in res_j)
-    parity = parity_sample(res, gpu_sample) if gpu_sample is not None else None
-    return parity, {
-        "value": ok / wall,
-        "unit": "decompositions/s",
-        "cores": cores,
-        "host_cpu_count": os.cpu_count(),
-        "cpu_quota": quota,
-        "kind": "port",
-        "sample": f"{n_sample} targets of the same workload{' (sweep basis %d only)' % SWEEP_CPU_BASIS if gname == 'cgsweep' else ''} "
-        f"(SciPy BFGS + finite differences on the NumPy oracle, "
-        f"sequential restarts with early break, one target per task over {cores} processes), {cpu_s:.1f} core-seconds, {wall:.1f} s wall",
-        "per_core": ok / cpu_s if cpu_s > 0 else None,
-        "analytic_jac": {"value": ok_j / wall_j, "per_core": ok_j / cpu_sj if cpu_sj > 0 else None,
-                         "note": "same sample and loop, SciPy BFGS with the oracle's analytic gradient"},
-    }
-
-
-def traffic_per_launch(workload: str):
-    """HBM bytes per optimizer-kernel launch (mean over the three spans) from the committed PMC passes
-    (profiles/r2_traffic.json, else r1d_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section);
-    None for workloads that were not profiled."""
-    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1d_traffic.json"):
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload]
-            return sum(t.values()) / len(t)
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
-
-
-def pmc_figures(workload: str):
-    """VALU-busy and achieved HBM GB/s of the optimizer launches, per span, from the committed rocprofv3 --pmc passes
-    (profiles/r3_pmc.json, else r2_pmc.json; tools/profile_r3.sh writes them).  Counters cannot be collected inside an
-    unprofiled run: these are the figures of the committed profile of the same command, named in `source`."""
-    for name in ("r4_pmc.json", "r3_pmc.json", "r2_pmc.json"):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            per = d[workload]
-            return {"source": f"profiles/{name}", "valu_busy": {k: v["valu_busy"] for k, v in per.items()},
-                    "hbm_gbps": {k: v["hbm_gbps"] for k, v in per.items()}}
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
-
-
-def gather_strings(comm, rank: int, world: int, text: str, width: int = 64):
-    """Every rank's short string on every rank, through the communicator's sum-all-reduce (bytes as doubles)."""
-    buf = np.zeros(world * width)
-    raw = text.encode()[:width]
-    buf[rank * width : rank * width + len(raw)] = list(raw)
-    comm.allreduce_sum(buf)
-    return [bytes(int(v) for v in buf[r * width : (r + 1) * width] if v > 0).decode(errors="replace") for r in range(world)]
-
-
-# ------------------------------------------------------------------------------------------------
-# launcher: `python bench.py --gpus N` without torchrun
-# ------------------------------------------------------------------------------------------------
-def launch_ranks(n: int) -> int:
-    """Start the N ranks as fresh processes (nothing in this process has touched the GPU: no exec-after-HIP-init,
-    no fork of an initialised runtime) and return the worst exit code.  Rank 0 prints the JSON line."""
-    with tempfile.TemporaryDirectory(prefix="slam_bench_") as tmp:
-        procs = []
-        for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SLAM_COMM_FILE=os.path.join(tmp, "rccl.id"),
-                       SLAM_COMM_DIR=os.path.join(tmp, "filecomm"), SLAM_BENCH_RANK_PROCESS="1")
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-        rc = 0
-        try:
-            live = list(procs)
-            while live:
-                for p in list(live):
-                    code = p.poll()
-                    if code is not None:
-                        live.remove(p)
-                        rc = rc or code
-                if rc:
-                    break  # a rank that died leaves the others waiting in a collective: do not wait for them
-                time.sleep(0.05)
-        finally:
-            for p in procs:  # end what is still running, by pid
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-        return rc
-
-
-class _StdoutToStderr:
-    """RCCL prints its version banner on the C-level stdout when a communicator is created; rank 0's stdout must carry
-    the JSON line only, so fd 1 points at stderr while the communicator comes up."""
-
-    def __enter__(self):
-        sys.stdout.flush()
-        self._saved = os.dup(1)
-        os.dup2(2, 1)
-
-    def __exit__(self, *exc):
-        sys.stdout.flush()
-        os.dup2(self._saved, 1)
-        os.close(self._saved)
-
-
-def make_comm(rank: int, world: int, local_rank: int):
-    from slam_decomposition_amd import parallel
-
-    if world == 1 and not os.environ.get("SLAM_BENCH_RANK_PROCESS"):
-        return parallel.LocalComm()
-    if os.environ.get("SLAM_BENCH_COMM", "rccl") == "file":
-        # rehearsal of the N > 1 path on a one-GPU box (RCCL refuses several ranks on one device)
-        return parallel.FileComm(rank, world, os.environ.get("SLAM_COMM_DIR") or parallel.rendezvous_path() + ".d")
-    from slam_decomposition_amd import _ffi
-
-    # No fallback: a rank whose RCCL communicator does not come up ends the job with a non-zero exit code (the launcher
-    # then stops the other ranks).  A per-rank fallback would leave the healthy ranks blocked in ncclCommInitRank, and a
-    # job-wide one would print a scaling number whose collective went through the file system.
-    try:
-        with _StdoutToStderr():
-            comm = parallel.RcclComm(local_rank % max(1, _ffi.device_count()), rank, world, parallel.rendezvous_path())
-            comm.barrier()  # first collective (lazy channel set-up and its messages) before anything is timed or printed
-    except Exception as exc:
-        print(f"[bench rank {rank}] RCCL communicator failed: {exc}  (SLAM_BENCH_COMM=file rehearses the N > 1 path without RCCL)",
-              file=sys.stderr, flush=True)
-        raise SystemExit(3)
-    if (comm.rccl_rank, comm.rccl_world) != (rank, world):
-        print(f"[bench rank {rank}] RCCL reports rank {comm.rccl_rank} of {comm.rccl_world}, the launcher said {rank} of {world}", file=sys.stderr, flush=True)
-        raise SystemExit(3)
-    return comm
-
-
-def run_v2(rank: int, local_rank: int, steps: int = 512, warmup: int = 32, n_targets: int = 4096, restarts: int = 16, n_streams: int = 8, group: int = 32,
-           base_gate=None, gate_desc: str = "RiSwapGate"):
-    """secondary.v2: CircuitTemplateV2(base_gates=[RiSwapGate]) -- every gate instance with its own free alpha -- SquareCost,
-    spans 1..3, `n_targets` Haar targets x `restarts` restarts per step.  The span loop is the one TemplateOptimizer runs for a
-    V2 template (optimizer.py:_run_batch_v2 -> slam_v2_decompose_range): enqueued on the device as one chain of kernels per
-    step.  Like the configs[1]-sized steps of the fixed-gate path, `group` consecutive steps (windows of one resident array) go
-    to the library as ONE call -- one device-side work queue per span over all their items -- on `n_streams` host threads /
-    contexts / streams (measured, MI355X: one step per call 2.5e6 decompositions/s / 0.19 of peak, 8 per call 6.4e6 / 0.31; round 4,
-    tools/r4_v2_sweep.sh: 64 steps at 8 per call x 4 in flight 6.2e6 / 0.31, 128 steps at 16 x 4 7.6e6 / 0.36, 8 x 8
-    6.8e6 / 0.33, 32 x 2 7.3e6 / 0.34, 256 steps at 32 x 4 7.7e6 / 0.345; tools/r4_v2_sweep2.sh: 512 steps at 16 x 8 8.1e6 / 0.37, at 32 x 8
-    8.3e6 / 0.37 (the default now: a 0.25 s region with eight calls per stream instead of two))."""
-    from slam_decomposition_amd import _ffi
-    from slam_decomposition_amd.basisv2 import CircuitTemplateV2
-    from slam_decomposition_amd.gates import RiSwapGate
-
-    basis = CircuitTemplateV2(base_gates=[RiSwapGate if base_gate is None else base_gate], maximum_span_guess=3)
-    total = steps + warmup
-    group = max(1, min(group, steps))
-    n_streams = max(1, min(n_streams, (steps + group - 1) // group))
-    ctxs = [_ffi.Context(local_rank % max(1, _ffi.device_count())) for _ in range(n_streams)]
-    for c in ctxs:
-        c.sample_haar(TARGET_SEED0 + 7_000_000 + rank * total * n_targets, total * n_targets)
-        c.v2_set_gates(basis._gate_maps)
-        c.set_cost(_ffi.COST_SQUARE)
-    prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
-    threshold = 1e-10
-    layouts = {}
-    for k in (1, 2, 3):
-        basis.build(k)
-        layouts[k] = basis.device_layout(k)
-
-    def one_call(s0: int, n_steps: int, ctx):
-        # the whole span loop on the device (slam_v2_decompose_range): optimizer kernel + epilogue per template size, no host
-        # round trip in between; (best_loss, best_x, best_cycles) of the steps' targets come back at the end
-        best, _, cyc = ctx.v2_decompose_range(s0 * n_targets, n_steps * n_targets, 1, 3, [[0] * k for k in (1, 2, 3)],
-                                              [layouts[k][2:6] for k in (1, 2, 3)], prm, threshold)
-        return best, cyc
-
-    def run(step_ids):
-        res = {}
-        groups = [step_ids[i : i + group] for i in range(0, len(step_ids), group)]
-
-        def worker(w):
-            for g in groups[w::n_streams]:
-                best, cyc = one_call(g[0], len(g), ctxs[w])
-                for i, s in enumerate(g):
-                    res[s] = (best[i * n_targets : (i + 1) * n_targets], cyc[i * n_targets : (i + 1) * n_targets])
-
-        threads = [threading.Thread(target=worker, args=(w,)) for w in range(n_streams)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        return res
-
-    # set-up, not a step: every context runs one call of the timed size (its work buffers are sized by the item count)
-    prime = [threading.Thread(target=one_call, args=(0, min(group, total), c)) for c in ctxs]
-    for t in prime:
-        t.start()
-    for t in prime:
-        t.join()
-    if warmup:
-        # the warm-up steps are repeated until the device has been busy for 0.2 s: after a second of host-side set-up the chip
-        # idles at a low clock, and a timed region of 40 ms that starts there measures the ramp (seen: half the rate)
-        t_w = time.perf_counter()
-        while True:
-            run(list(range(warmup)))
-            if time.perf_counter() - t_w > 0.2:
-                break
-    for c in ctxs:
-        c.synchronize()
-        c.reset_stats()
-    t0 = time.perf_counter()
-    res = run(list(range(warmup, total)))
-    for c in ctxs:
-        c.synchronize()
-    elapsed = time.perf_counter() - t0
-    solved = 0
-    hist = np.zeros(4, dtype=np.int64)
-    for s in range(warmup, total):
-        best, cyc = res[s]
-        solved += int((best < SUCCESS_LOSS).sum())
-        hist += np.bincount(np.clip(cyc, 0, 3), minlength=4)
-    sts = [c.stats() for c in ctxs]
-    for c in ctxs:
-        c.close()
-    ev = {k: sum(x["evals"][k] for x in sts) for k in (1, 2, 3)}
-    kms_span = {k: sum(x["kernel_ms_span"][k] for x in sts) for k in (1, 2, 3)}
-    flops = sum(ev[k] * f_eval_v2(k) for k in (1, 2, 3))
-    return {
-        "workload": f"CircuitTemplateV2(base_gates=[{gate_desc}]) (free gate parameters per gate instance), SquareCost, spans 1..3, {n_targets} Haar targets x {restarts} restarts per step",
-        "value": solved / elapsed, "unit": "decompositions/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
-        "batches_in_flight_per_gpu": n_streams, "steps_per_library_call": group,
-        "solved_fraction": solved / (steps * n_targets), "best_cycles_hist": {str(k): int(hist[k]) for k in range(4)},
-        "roofline_frac": flops / elapsed / 1e12 / PEAK_FP64_VALU_TFLOPS,
-        "kernel_ms_per_step_alone_or_overlapped": {str(k): kms_span[k] / steps for k in (1, 2, 3)},
-        "evals_per_span": {str(k): ev[k] for k in (1, 2, 3)},
-        "flops_per_eval": {str(k): f_eval_v2(k) for k in (1, 2, 3)},
-        "flops_note": "F_eval(k) + 488 k: the fixed-gate count plus the gate-angle derivatives (bench.py:f_eval_v2)",
-        "span_loop": "on the device (slam_v2_decompose_range): one chain of kernels per library call, results fetched at its end",
-    }
-
-
-def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: int = 3, shards: int = 0):
-    """secondary.api: the drop-in method north_star names, end to end --
-    ``TemplateOptimizer(CircuitTemplate([RiSwapGate(1/2)], maximum_span_guess=3), BasicCost(), training_restarts=32)
-    .approximate_from_distribution(DeviceHaarBatch(n_samples=65536))`` (src/slam/optimizer.py:180-186): targets generated on the
-    device, ONE blocking call, results back as the reference's 3-tuple (training_loss, coordinate_list, [DataDictEntry]).  Wall
-    time of the whole Python call, median of `reps` after one untimed call; a fresh sampler seed per call."""
-    from slam_decomposition_amd import _ffi
-    from slam_decomposition_amd.basis import CircuitTemplate
-    from slam_decomposition_amd.cost_function import BasicCost
-    from slam_decomposition_amd.gates import RiSwapGate
-    from slam_decomposition_amd.optimizer import TemplateOptimizer
-    from slam_decomposition_amd.sampler import DeviceHaarBatch
-
-    device = local_rank % max(1, _ffi.device_count())
-    basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3, device=device)
-    times, solved = [], 0
-    for r in range(reps + 1):
-        opt = TemplateOptimizer(basis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True,
-                                **({"devices": [device] * shards} if shards else {}))
-        t0 = time.perf_counter()
-        loss, _, data = opt.approximate_from_distribution(DeviceHaarBatch(seed=TARGET_SEED0 + 9_000_000 + r, n_samples=n_targets, device=device))
-        dt = time.perf_counter() - t0
-        if r:
-            times.append(dt)
-            solved = int((np.asarray(loss) < SUCCESS_LOSS).sum())
-            assert len(data) == n_targets and data[n_targets - 1].cycles in (2, 3)
-    times.sort()
-    med = times[(len(times) - 1) // 2]
-    # the same method on a sampler of FIVE windows (327 680 targets): successive 65 536-target windows on helper contexts, five in
-    # flight (TemplateOptimizer._run_batch_windows) -- the drop-in method at the rate of the bench's own batches in flight
-    big_n = 5 * n_targets
-    btimes, bsolved = [], 0
-    for r in range(reps + 1):
-        bopt = TemplateOptimizer(basis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True)
-        t0 = time.perf_counter()
-        bloss, _, bdata = bopt.approximate_from_distribution(DeviceHaarBatch(seed=TARGET_SEED0 + 9_500_000 + r, n_samples=big_n, device=device))
-        dt = time.perf_counter() - t0
-        if r:
-            btimes.append(dt)
-            bsolved = int((np.asarray(bloss) < SUCCESS_LOSS).sum())
-            assert len(bdata) == big_n and bdata[big_n - 1].cycles in (2, 3)
-    btimes.sort()
-    bmed = btimes[(len(btimes) - 1) // 2]
-    api_large = {"workload": f"TemplateOptimizer.approximate_from_distribution(DeviceHaarBatch(n_samples={big_n})), sqrt(iSWAP) span<=3, {restarts} restarts: "
-                             f"one call, {bopt.windows_in_flight} windows of {bopt.WINDOW_TARGETS} targets in flight",
-                 "value": bsolved / bmed, "unit": "decompositions/s", "wall_ms": 1e3 * bmed, "wall_ms_all": [round(1e3 * t, 3) for t in btimes],
-                 "solved_fraction": bsolved / big_n, "windows": len(bopt.last_stats_per_device)}
-    del bdata, bloss
-    # the reference's atomic call (optimizer.py:65-119): ONE target, the reference's default 5 restarts, spans 1..3 -- latency
-    from slam_decomposition_amd.sampler import random_unitary
-
-    lat = []
-    for i in range(24):
-        one = TemplateOptimizer(basis, BasicCost(), seed=OPT_SEED + i, override_fail=True)
-        U = random_unitary(4, seed=TARGET_SEED0 + i)
-        t0 = time.perf_counter()
-        d = one.approximate_target_U(U)
-        lat.append(time.perf_counter() - t0)
-    lat = sorted(lat[4:])
-    # the same call with use_polytopes=True (basis.py:95-100): every target only at the template size its coverage set assigns -- the
-    # lookup runs on the device too (slam_predict_spans), nothing but the results comes back
-    pbasis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3, use_polytopes=True, device=device)
-    ptimes, psolved = [], 0
-    for r in range(reps + 1):
-        popt = TemplateOptimizer(pbasis, BasicCost(), training_restarts=restarts, seed=OPT_SEED, override_fail=True)
-        t0 = time.perf_counter()
-        ploss, _, pdata = popt.approximate_from_distribution(DeviceHaarBatch(seed=TARGET_SEED0 + 9_000_000 + r, n_samples=n_targets, device=device))
-        dt = time.perf_counter() - t0
-        if r:
-            ptimes.append(dt)
-            psolved = int((np.asarray(ploss) < SUCCESS_LOSS).sum())
-    ptimes.sort()
-    pmed = ptimes[(len(ptimes) - 1) // 2]
-    return {"workload": f"TemplateOptimizer.approximate_from_distribution(DeviceHaarBatch(n_samples={n_targets})), sqrt(iSWAP) span<=3, {restarts} restarts, one blocking call",
-            "value": solved / med, "unit": "decompositions/s", "wall_ms": 1e3 * med, "wall_ms_all": [round(1e3 * t, 3) for t in times],
-            "solved_fraction": solved / n_targets, "kernel_ms": opt.last_stats["kernel_ms"],
-            "approximate_target_U_ms": {"median": round(1e3 * lat[len(lat) // 2], 4), "min": round(1e3 * lat[0], 4), "restarts": 5,
-                                        "what": "one Haar target per call, wall time of the Python call (speculative spans: all three template sizes side by side)",
-                                        "last_loss": float(d.loss_result), "last_cycles": int(d.cycles)},
-            "use_polytopes": {"value": psolved / pmed, "unit": "decompositions/s", "wall_ms": 1e3 * pmed, "solved_fraction": psolved / n_targets,
-                              "what": "the same call with CircuitTemplate(use_polytopes=True): template sizes from the exact coverage sets, looked up on the device"}}, api_large
-
-
-def run_medium_call(local_rank: int, n_targets: int = 4096, restarts: int = 16, reps: int = 9):
-    """secondary.medium_call: ONE call of a medium batch (CNOT, 4096 x 16: beyond the wave kernels, far from filling the chip for long),
-    alone on the device -- the spans of its loop side by side (overlapped spans, the library's own choice at this size) against the
-    span-by-span launches (SLAM_FLAG_STAGED); same results bit for bit (tests/test_gpu_round4.py)."""
-    from slam_decomposition_amd import _ffi
-
-    ctx = _ffi.Context(local_rank % max(1, _ffi.device_count()))
-    ctx.set_gates(gate_table("cx"))
-    ctx.sample_haar(TARGET_SEED0 + 77, n_targets)
-    seqs = [[0], [0, 0], [0, 0, 0]]
-    out = {}
-    for name, extra in (("overlapped_spans", 0), ("span_by_span", _ffi.FLAG_STAGED)):
-        prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED | extra)
-        ts = []
-        for r in range(reps + 2):
-            ctx.reset_stats()
-            t0 = time.perf_counter()
-            loss, _, _ = ctx.decompose_range(0, n_targets, 1, 3, seqs, prm, 1e-10)
-            ts.append(time.perf_counter() - t0)
-        st = ctx.stats()
-        med = sorted(ts[2:])[reps // 2]
-        out[name] = {"wall_ms": round(1e3 * med, 4), "kernel_launches": st["kernel_launches"], "solved_fraction": float((loss < SUCCESS_LOSS).mean()),
-                     "roofline_frac": sum(st["evals"][k] * f_eval(k) for k in (1, 2, 3)) / med / 1e12 / PEAK_FP64_VALU_TFLOPS}
-    ctx.close()
-    return {"workload": f"CNOT span<=3, {n_targets} Haar targets x {restarts} restarts, one blocking call alone on the device", **out}
-
-
-# ------------------------------------------------------------------------------------------------
-def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n_streams_arg, main: bool, group_arg: int = 0):
-    """Run `warmup` untimed + `steps` timed steps of one workload; returns the dict of measurements."""
-    from slam_decomposition_amd import _ffi, parallel
-
-    gname, n_per_step, restarts, desc = WORKLOADS[workload]
-    if main and args.targets:
-        n_per_step = args.targets
-    if main and args.restarts:
-        restarts = args.restarts
-    strong = main and args.scaling == "strong" and world > 1
-    if strong:
-        # strong scaling: the batch of ONE GPU's step is split over the ranks (65 536 x 32 over N for the default workload)
-        if n_per_step % world:
-            raise SystemExit(f"--scaling strong: {n_per_step} targets per step do not divide over {world} ranks")
-        n_per_step //= world
-        desc += f" -- STRONG scaling: one such batch per step split over {world} GPUs ({n_per_step} targets per GPU)"
-    small = n_per_step * restarts <= 65536
-    total_steps = steps + warmup
-    seed0 = TARGET_SEED0 + rank * total_steps * n_per_step  # disjoint targets per rank (weak scaling)
-    # one GPU per rank: LOCAL_RANK; modulo the visible devices, so that a launcher which restricts every rank's
-    # visibility to its own GPU (device 0 everywhere) and the shared-GPU rehearsal (SLAM_BENCH_COMM=file) both work
-    ndev = _ffi.device_count()
-    device = local_rank % max(1, ndev)
-
-    # Small batches are not given a host thread + stream each any more (16 in flight in round 2): `group` consecutive
-    # steps -- windows of the same resident array, same basis and seed -- go to the library as ONE call, i.e. one
-    # device-side work queue per span over all their (target, restart) items, and come back as per-step slices.  With
-    # the ordered early exit every step's results are bit for bit those of its own call (tests/test_gpu_round2.py).
-    group = 1
-    if (small or (main and args.group)) and not (gname == "cgsweep") and not (main and args.span_rules):
-        group = args.group if (main and args.group) else (group_arg or 20)  # measured (320 steps, 4 streams): 10 -> 0.40, 16 -> 0.44, 20 -> 0.445, 32 -> 0.44 of peak
-    group = max(1, min(group, steps))
-    # (the basis sweep cannot group its steps -- every step has its own gate -- so it keeps more of them in flight; measured on
-    # MI355X, 160 steps: 4 in flight 1.42e6 decompositions/s / 0.289 of peak, 8: 1.68e6 / 0.338, 16: 1.82e6 / 0.363)
-    sweep = gname == "cgsweep"
-    # the basis sweep as ONE chain of kernels per 8 bases (round 4, slam_decompose_multi: per span one multi-queue optimizer launch
-    # over the bases' work queues -- a wavefront works on one basis at a time, gates stay scalar operands -- and one bookkeeping
-    # launch), 4 such calls in flight; --no-multi: one call per basis, 16 in flight (round 3).  Measured on MI355X (160 steps,
-    # tools/r4_cfg5b.sh): bases per call x calls in flight 16 x 2 -> 0.325 of peak, 16 x 4 0.324, 8 x 4 0.385, 8 x 6 0.381,
-    # 4 x 8 0.381, 2 x 12 0.375; one call per basis x 16 in flight 0.346.  (A launch over 16 queues runs exactly as fast as one queue
-    # of the same total size -- tools/r4_mq_probe.py --; what separates the rows is how well the calls' stage tails overlap.)
-    mq = sweep and not (main and args.span_rules) and not (main and args.no_multi)
-    if mq:
-        group = min(args.group if (main and args.group) else 8, SWEEP_BASES_PER_GPU, steps)
-    n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else _batches_in_flight(n_per_step * restarts, main and args.span_rules)))
-    n_streams = max(1, min(n_streams, (steps + group - 1) // group))
-    ctxs = [_ffi.Context(device) for _ in range(n_streams * (group if mq else 1))]
-    dev_name, cus, _ = ctxs[0].device_info()
-    table = gate_table(gname)
-    host_targets = main and args.host_targets
-    span_rules_mode = main and args.span_rules
-    stub_mode = bool(os.environ.get("SLAM_BENCH_TEST_STUB"))
-    # every batch resident in HBM before the timed region: Haar targets generated in place by the device
-    # sampler (slam_sample_haar; --host-targets: SciPy's sampler on the host, ~55 us per target, then uploaded)
-    n_resident = n_per_step if sweep else total_steps * n_per_step  # the sweep's targets are shared by all bases
-    targets = make_targets(n_resident, seed0 if not sweep else TARGET_SEED0) if host_targets else None
-    def basis_of(s: int) -> int:
-        # rank r takes column p = r of the (m, p) grid: all 16 strengths m, so every GPU has weak and strong gates
-        return (s % SWEEP_BASES_PER_GPU) * 8 + rank % 8
-
-    ctx_basis = {}
-    for i, c in enumerate(ctxs):
-        # multi-queue sweep: context i of a call's group serves the steps with s mod group == i mod group -- with 16 steps per call
-        # that is ONE basis for the whole run (its gate is set once, here)
-        if mq:
-            ctx_basis[id(c)] = basis_of(i % group)
-        c.set_gates(np.stack([sweep_gate(basis_of(i % group))]) if mq else table)
-        if host_targets:
-            c.set_targets(targets)
-        else:
-            c.sample_haar(seed0 if not sweep else TARGET_SEED0, n_resident)
-    gate_seqs = [[i % len(table) for i in range(k)] for k in (1, 2, 3)]
-    ipq = args.items_per_quad if (main and args.items_per_quad >= 0) else (3 if (small and group == 1 and n_streams > 1) else 0)
-    flags = _ffi.FLAG_EARLY_EXIT | (0 if args.fast_exit else _ffi.FLAG_ORDERED)
-    if n_streams > 1:
-        flags |= _ffi.FLAG_NO_OVERLAP  # several calls in flight fill the chip: no speculative stages beside them
-    prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=flags, items_per_quad=ipq)
-    threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
-
-    if span_rules_mode:
-        from slam_decomposition_amd.weyl import c1c2c3 as host_c1c2c3
-
-    def one_step(s: int, c):
-        if span_rules_mode:
-            # use_polytopes=True (basis.py:95-100): every target starts at the template size its coverage set assigns -- exact for every
-            # gate sequence (coverage.py: the monodromy inequalities; the half-spaces of the three prefixes go to the device, which
-            # evaluates them on the resident targets: slam_predict_spans) -- and runs on from there like the span loop does.
-            # tol: the metric accepts loss < 1e-8, i.e. targets up to ~1e-4 in coordinates outside the exact reachable set
-            first = 0 if sweep else s * n_per_step
-            if sweep:
-                g = sweep_gate(basis_of(s))
-                c.set_gates(np.stack([g]))
-                seq_coords = [host_c1c2c3(g)] * 3
-            else:
-                seq_coords = [host_c1c2c3(table[i]) for i in gate_seqs[2]]
-            # round 5: lookup, per-size lists and the span loop in ONE chain of kernels (slam_decompose_predicted, carry: a target that
-            # misses the threshold at its size goes on to the next) -- round 4 built the lists on the host, one call per size.
-            # Local targets come back as (0, 0), targets beyond the whole template's reach as (+inf, -1).
-            c.decompose_predicted(seq_coords, 3, gate_seqs, prm, threshold, first, n_per_step, carry=True, tol=5e-4)
-            best_loss, best_x, best_cycles = c.fetch_results_range(3, first, n_per_step)
-            return best_loss, best_cycles
-        if sweep:
-            c.set_gates(np.stack([sweep_gate(basis_of(s))]))
-            best_loss, best_x, best_cycles = c.decompose_range(0, n_per_step, 1, 3, gate_seqs, prm, threshold)
-        else:
-            best_loss, best_x, best_cycles = c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm, threshold)
-        return best_loss, best_cycles
-
-    def sync():
-        # barrier + device synchronisation on both sides of the timed region (all streams of this rank drained,
-        # then all ranks arrived, then drained again)
-        for c in ctxs:
-            c.synchronize()
-        comm.barrier()
-        for c in ctxs:
-            c.synchronize()
-
-    resident_merge = world > 1 and hasattr(comm, "raw") and not sweep and not span_rules_mode
-
-    def run_steps(step_ids, results, first_step):
-        # steps are dealt round-robin to n_streams host threads, each with its own context / HIP stream,
-        # so the tail of one batch (a stage lasts as long as its slowest work item) overlaps the next batch
-        groups = parallel.step_groups(step_ids, group)
-
-        def worker(w):
-            for g in groups[w::n_streams]:
-                if mq:
-                    # one library call for up to 16 consecutive steps = 16 different bases (step s -> basis slot s mod 16)
-                    cg = ctxs[w * group : (w + 1) * group]
-                    sub = [cg[s % group] for s in g]
-                    for s, c in zip(g, sub):
-                        if ctx_basis[id(c)] != basis_of(s):  # (fewer than 16 steps per call: the slot changes its basis)
-                            c.set_gates(np.stack([sweep_gate(basis_of(s))]))
-                            ctx_basis[id(c)] = basis_of(s)
-                    _ffi.decompose_multi(sub, 0, n_per_step, 1, 3, gate_seqs, prm, threshold)
-                    for s, c in zip(g, sub):
-                        bl, _, bc = c.fetch_results_range(3, 0, n_per_step)
-                        results[s] = (bl, bc)
-                    continue
-                if len(g) == 1 or g != list(range(g[0], g[0] + len(g))):
-                    for s in g:
-                        results[s] = one_step(s, ctxs[w])
-                    continue
-                # one library call for the whole group of consecutive steps, results handed back per step
-                bl, _, bc = ctxs[w].decompose_range(g[0] * n_per_step, len(g) * n_per_step, 1, 3, gate_seqs, prm, threshold)
-                for i, s in enumerate(g):
-                    results[s] = (bl[i * n_per_step : (i + 1) * n_per_step], bc[i * n_per_step : (i + 1) * n_per_step])
-
-        if n_streams == 1:
-            worker(0)
-        else:
-            threads = [threading.Thread(target=worker, args=(w,)) for w in range(n_streams)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        if world > 1:
-            # the job's one collective: final best-loss all-reduce (min) over RCCL / xGMI.  Every rank
-            # contributes +inf outside its shard and ends with the whole job's per-target losses.
-            n_loc = len(step_ids) * n_per_step
-            if resident_merge:
-                # device to device: each context's resident best_loss windows -> this rank's slice of the job vector
-                comm.raw.merge_begin(world * n_loc)
-                for w, local_first, cnt, global_first in parallel.merge_slices(step_ids, first_step, n_per_step, rank, world, n_streams, group):
-                    comm.raw.merge_add(ctxs[w], local_first, cnt, global_first)
-                t_c = time.perf_counter()
-                results["merged_solved"], _ = comm.raw.allreduce_min_merged(SUCCESS_LOSS)
-                results["collective_ms"] = 1e3 * (time.perf_counter() - t_c)
-            else:
-                merged = np.full(world * n_loc, np.inf)
-                merged[rank * n_loc : (rank + 1) * n_loc] = np.concatenate([results[s][0] for s in step_ids])
-                t_c = time.perf_counter()
-                comm.allreduce_min(merged)
-                results["collective_ms"] = 1e3 * (time.perf_counter() - t_c)
-                results["merged_solved"] = int((merged < SUCCESS_LOSS).sum())
-
-    # set-up, not a step: every context runs one batch once so that its device buffers exist and its
-    # kernels are loaded (with 8 contexts, W < 8 warm-up steps would leave some of them cold)
-    def prime_one(c):
-        if mq:
-            w = ctxs.index(c) // group
-            _ffi.decompose_multi(ctxs[w * group : (w + 1) * group], 0, n_per_step, 1, 3, gate_seqs, prm, threshold)
-        elif group > 1:
-            # the grouped call's work buffers are sized by its item count: allocate them here, not inside the timed region
-            # (W < group warm-up steps would make a smaller call), and bring the device out of its idle clock state
-            c.decompose_range(0, min(group, total_steps) * n_per_step, 1, 3, gate_seqs, prm, threshold)
-        else:
-            one_step(0, c)
-
-    if n_streams > 1 or group > 1:
-        prime = [threading.Thread(target=prime_one, args=(c,)) for c in (ctxs[::group] if mq else ctxs)]
-        for t in prime:
-            t.start()
-        for t in prime:
-            t.join()
-    def sum_stats():
-        sts = [c.stats() for c in ctxs]
-        out = {"kernel_ms": sum(x["kernel_ms"] for x in sts), "kernel_launches": sum(x["kernel_launches"] for x in sts)}
-        for key in ("evals", "items", "evals_accepted", "evals_preempted", "kernel_ms_span", "wave_rounds"):
-            out[key] = [sum(x[key][k] for x in sts) for k in range(6)]
-        return out
-
-    res = {}
-    if warmup:
-        run_steps(list(range(warmup)), res, 0)
-    # The timed region -- exactly `steps` steps between barrier + drained streams on both sides, MAX over ranks -- is
-    # repeated `reps` times on the same resident batches (identical work every time); the line reports the MEDIAN
-    # repetition and the spread, so that box noise shows in a single run of the command.
-    reps = max(1, args.repeats)
-    rep_runs = []
-    for _ in range(reps):
-        sync()
-        for c in ctxs:
-            c.reset_stats()
-        res = {}
-        t0 = time.perf_counter()
-        run_steps(list(range(warmup, total_steps)), res, warmup)
-        res["own_ms"] = 1e3 * (time.perf_counter() - t0)  # this rank's own steps + the collective, before the closing barrier
-        sync()
-        tt = np.array([time.perf_counter() - t0])
-        comm.allreduce_max(tt)  # max over ranks of the time
-        rep_runs.append((float(tt[0]), res, sum_stats()))
-    order = sorted(range(reps), key=lambda i: rep_runs[i][0])
-    elapsed, res, st = rep_runs[order[(reps - 1) // 2]]
-    rep_ms = [1e3 * r[0] / steps for r in rep_runs]
-
-    solved = 0
-    cyc_hist = np.zeros(4, dtype=np.int64)
-    worst = 0.0
-    for s in range(warmup, total_steps):
-        bl, bc = res[s]
-        ok = bl < SUCCESS_LOSS
-        solved += int(ok.sum())
-        worst = max(worst, float(bl.max()))
-        cyc_hist += np.bincount(np.clip(bc, 0, 3), minlength=4)
-    per_basis = None
-    if sweep:
-        # SURVEY.md §8(d) cfg 5 output: per-basis success fraction and mean best_cycles (rank 0's bases)
-        per_basis = {}
-        for s in range(warmup, total_steps):
-            b = basis_of(s)
-            if b in per_basis:
-                continue
-            bl, bc = res[s]
-            ok = bl < SUCCESS_LOSS
-            per_basis[b] = {"solved_fraction": float(ok.mean()), "mean_cycles": float(bc[ok].mean()) if ok.any() else None}
-
-    # solved targets counted on the all-reduced vector (same on every rank)
-    rank_diag = None
-    if world > 1:
-        solved_all = res["merged_solved"]
-        cnt = np.array([float(solved)])
-        comm.allreduce_sum(cnt)
-        assert int(cnt[0]) == solved_all, "merged best-loss vector disagrees with the per-rank counts"
-        # what a first N > 1 run needs to diagnose itself: every rank's own time for the median repetition's timed region
-        # (steps + collective, before the closing barrier), its solved count, the collective's duration, its evaluations
-        cores, quota = usable_cores()
-        flat = np.zeros(world * 6)
-        flat[6 * rank : 6 * rank + 6] = [res["own_ms"], float(solved), res.get("collective_ms", 0.0), float(sum(st["evals"][k] for k in (1, 2, 3))),
-                                         float(threading.active_count()), float(quota if quota is not None else cores)]
-        comm.allreduce_sum(flat)
-        diag = flat.reshape(world, 6)
-        rank_diag = {"own_ms": [round(float(v), 3) for v in diag[:, 0]], "solved": [int(v) for v in diag[:, 1]],
-                     "collective_ms": [round(float(v), 3) for v in diag[:, 2]], "evals": [int(v) for v in diag[:, 3]],
-                     "host_threads": [len(ctxs) // (group if mq else 1) + 1] * world, "live_threads_at_report": [int(v) for v in diag[:, 4]],
-                     "cpu_share": [round(float(v), 2) for v in diag[:, 5]],
-                     "note": "per rank, median repetition: wall time of its own steps + the final collective (before the closing barrier), "
-                             "targets it solved, duration of the collective as it saw it, loss+gradient evaluations; host_threads = worker "
-                             "threads (one per call in flight) + the main one, cpu_share = the cores this rank's cgroup / affinity grants: "
-                             "N ranks x host_threads on one node must fit the node's cores or the calls in flight starve each other"}
-    else:
-        solved_all = solved
-
-    # per-span pass, ONE batch in flight: launches do not overlap, so every frac below is evals x F_eval(k) / the HIP
-    # events around that launch -- the figure `rocprofv3 --kernel-trace --stats` reports for the same launches
-    # (tools/r4_trace_summary.py picks them out of the driver command's trace).  Not part of `value`.
-    # The steps are enqueued BACK TO BACK on one stream (no result fetch in between: the 13 MB copy into pageable memory
-    # leaves the chip idle for ~1 ms, and the launch after an idle gap runs 2-10 % slower while the clock ramps:
-    # profiles/r4_solo_probe.txt), after one untimed step of the same kind.
-    per_span = None
-    if main and rank == 0 and not span_rules_mode and args.per_span_steps > 0:
-        c = ctxs[0]
-
-        def solo_step(s):
-            if sweep:
-                c.set_gates(np.stack([sweep_gate(basis_of(s))]))
-                c.decompose_range(0, n_per_step, 1, 3, gate_seqs, prm, threshold, fetch=False)
-            else:
-                c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm, threshold, fetch=False)
-
-        for s in range(PER_SPAN_WARM_STEPS):  # untimed: the chip's clocks settle under this load (the first launches after an idle
-            solo_step(s % total_steps)        # period run 2-3 % slower: profiles/r4_solo_probe.txt)
-        rows = []
-        for s in range(args.per_span_steps):
-            c.reset_stats()
-            solo_step(s % total_steps)
-            rows.append(c.stats())
-        per_span = {}
-        for k in (1, 2, 3):
-            rk = [r for r in rows if r["items"][k] and r["kernel_ms_span"][k] > 0]
-            if not rk:
-                continue
-            ms = sum(r["kernel_ms_span"][k] for r in rk)
-            ev = sum(r["evals"][k] for r in rk)
-            per_span[str(k)] = {
-                "launches": len(rk),
-                "evals_per_launch": ev / len(rk),
-                "hip_event_ms": ms / len(rk),
-                "hip_event_ms_all": [round(r["kernel_ms_span"][k], 4) for r in rk],
-                "achieved": ev * f_eval(k) / (ms * 1e-3) / 1e12,
-                "frac": ev * f_eval(k) / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                "quad_occupancy": ev / 16 / max(1, sum(r["wave_rounds"][k] for r in rk)),
-            }
-        tot_ms = sum(r["kernel_ms_span"][k] for r in rows for k in (1, 2, 3))
-        tot_fl = sum(r["evals"][k] * f_eval(k) for r in rows for k in (1, 2, 3))
-        per_span["all"] = {"hip_event_ms_per_step": tot_ms / len(rows),
-                           "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if tot_ms > 0 else None,
-                           "warm_steps": PER_SPAN_WARM_STEPS,
-                           "mode": "one batch in flight, steps enqueued back to back on one stream, no result fetch in between"}
-
-    # parity sample: the HIP path's answers for the targets the CPU baseline solves (same indices of the resident array, same
-    # Philox start points); with the ordered early exit a window's results do not depend on what else is in the call
-    gpu_sample = None
-    if main and rank == 0 and world == 1 and not args.no_cpu_baseline and not span_rules_mode and not host_targets and not stub_mode:
-        n_s = min(parity_sample_size(args.cpu_sample), n_per_step)
-        c = ctxs[0]
-        if sweep:
-            c.set_gates(np.stack([sweep_gate(SWEEP_CPU_BASIS)]))
-        g_loss, g_x, g_cyc = c.decompose_range(0, n_s, 1, 3, gate_seqs, prm, threshold)
-        g_coords = np.full((n_s, 3), np.nan)
-        for k in np.unique(g_cyc):
-            k = int(k)
-            if k < 1:
-                continue
-            sel = np.nonzero(g_cyc == k)[0]
-            g_coords[sel] = c.eval_c1c2c3(gate_seqs[k - 1], np.ascontiguousarray(g_x[sel, : 6 * (k + 1)]), ndigits=-1)
-        gpu_sample = (g_loss, g_cyc, g_coords, c.targets_c1c2c3(0, n_s, ndigits=-1), c.fetch_span_losses(0, n_s))
-
-    for c in ctxs:
-        c.close()
-
-    flops = sum(st["evals"][k] * f_eval(k) for k in (1, 2, 3))
-    rejected = [st["evals"][k] - st["evals_accepted"][k] - st["evals_preempted"][k] for k in range(6)]
-    flops_accepted = sum(st["evals_accepted"][k] * f_eval(k) for k in (1, 2, 3))
-    flops_strict = flops_accepted + sum(rejected[k] * f_forward(k) for k in (1, 2, 3))
-    # one batch in flight: launches do not overlap, achieved = flops / sum of HIP-event launch durations.
-    # several batches in flight: launches of different streams share the chip and their event
-    # durations overlap, so the denominator is the wall time of the timed region instead.
-    kernel_s = st["kernel_ms"] * 1e-3 if n_streams == 1 else elapsed
-    achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
-    return {
-        "desc": desc, "gname": gname, "n_per_step": n_per_step, "restarts": restarts, "threshold": threshold, "sweep": sweep,
-        "n_streams": n_streams, "ipq": ipq, "dev_name": dev_name, "cus": cus, "elapsed": elapsed, "solved_all": solved_all,
-        "cyc_hist": cyc_hist, "worst": worst, "per_basis": per_basis, "st": st, "achieved": achieved, "kernel_s": kernel_s,
-        "rejected": rejected, "flops_accepted": flops_accepted, "flops_strict": flops_strict, "per_span": per_span,
-        "resident_merge": resident_merge, "rep_ms": rep_ms, "strong": strong, "group": group, "gpu_sample": gpu_sample,
-        "rank_diag": rank_diag, "mq": mq,
-    }
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 320 for cfg2-sized batches)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 5; 32 for cfg2-sized batches)")
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS),
-                    help="cfg3 = BASELINE configs[2] (default: the largest single-GPU configuration); cfg2 = configs[1]; "
-                         "cfg4 / cfg5 = one GPU's shard of configs[3] / configs[4] (targets / bases sharded over --gpus ranks)")
-    ap.add_argument("--targets", type=int, default=None, help="override targets per step per GPU")
-    ap.add_argument("--restarts", type=int, default=None)
-    ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight per GPU (one host thread + context + HIP stream each); default 16 for cfg2-sized batches, 5 otherwise "
-                         "(measured on cfg3: 3 -> 2.95e6, 4 -> 3.0e6, 5 -> 3.19e6, 6 -> 3.20e6 decompositions/s; batches below 2^20 items per span, "
-                         "e.g. the cfg4 shard: 8 -- round 4, tools/r4_cfg4_sweep.sh: 5 -> 1.03e7, 8 -> 1.16e7; by batch size up to 16: _batches_in_flight)")
-    ap.add_argument("--group", type=int, default=0,
-                    help="small batches: consecutive steps handed to the library as one call = one device-side work queue per span "
-                         "(default 20 for cfg2-sized batches, 1 otherwise)")
-    ap.add_argument("--items-per-quad", type=int, default=int(os.environ.get("SLAM_BENCH_IPQ", "-1")),
-                    help="launch shaping (slam_opt_params.items_per_quad); 0 = library default (one item per quad, lowest "
-                         "latency); default here: 3 for small batches with several in flight (+4.7 %% measured), else 0")
-    ap.add_argument("--host-targets", action="store_true", help="draw the Haar targets with SciPy on the host instead of on the device")
-    ap.add_argument("--span-rules", action="store_true",
-                    help="polytope mode (CircuitTemplate(use_polytopes=True)): each target is optimised only at the template "
-                         "size the analytic span rules assign to it (device c1c2c3 + span_rules.py) instead of spans 1..3")
-    ap.add_argument("--fast-exit", action="store_true",
-                    help="drop SLAM_FLAG_ORDERED: the first restart to FINISH below stop_loss wins (timing-dependent winner) instead of "
-                         "the lowest-index successful restart (the reference's sequential semantics, bitwise reproducible; default)")
-    ap.add_argument("--repeats", type=int, default=3,
-                    help="repetitions of the timed region (each exactly --steps steps between barriers); the line reports the median one and min / max")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): every GPU gets its own full-size batches; strong: one GPU's batch per step is split over the --gpus ranks")
-    ap.add_argument("--no-multi", action="store_true", help="cfg5: one library call per basis, 16 in flight (round 3) instead of slam_decompose_multi")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="targets of the CPU baseline sample (default 4 x host cores)")
-    ap.add_argument("--per-span-steps", type=int, default=5, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 / v2 measurements")
-    ap.add_argument("--v2-only", action="store_true", help="dev: run only the secondary.v2 measurement (CircuitTemplateV2) and print it")
-    ap.add_argument("--api-only", action="store_true", help="dev: run only the secondary.api measurement (TemplateOptimizer.approximate_from_distribution) and print it")
-    args = ap.parse_args()
-
-    stub = os.environ.get("SLAM_BENCH_TEST_STUB")
-    if stub:
-        # TEST HOOK (tests/test_bench_cpu.py): a stand-in for _ffi.Context so that the launcher / rank / communicator /
-        # JSON plumbing of the N > 1 path can be exercised on a box without a GPU.  Its numbers mean nothing; the line
-        # says so in "data".  Never set outside the tests.
-        import importlib.util
-
-        spec = importlib.util.spec_from_file_location("slam_bench_test_stub", stub)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        mod.install()
-
-    if args.v2_only:
-        kw = {k: int(os.environ[e]) for k, e in (("steps", "SLAM_V2_STEPS"), ("group", "SLAM_V2_GROUP"), ("n_streams", "SLAM_V2_STREAMS"), ("n_targets", "SLAM_V2_TARGETS")) if e in os.environ}
-        print(json.dumps(run_v2(0, 0, **kw)), flush=True)  # (dev: SLAM_V2_STEPS / _GROUP / _STREAMS / _TARGETS override the defaults)
-        return
-    if args.api_only:
-        r, big = run_api(0)
-        print(json.dumps({"value": r["value"], "wall_ms_all": r["wall_ms_all"], "kernel_ms": r["kernel_ms"],
-                          "approximate_target_U_ms": r["approximate_target_U_ms"]["median"], "use_polytopes": r["use_polytopes"], "api_large": big}), flush=True)
-        return
-    env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and (args.gpus > 1 or os.environ.get("SLAM_BENCH_FORCE_LAUNCH")):
-        # plain `python bench.py --gpus N`: become the launcher (no GPU call has happened in this process)
-        raise SystemExit(launch_ranks(args.gpus))
-    world = int(env_world or "1")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
-
-    _, n_default, r_default, _ = WORKLOADS[args.workload]
-    small = (args.targets or n_default) * (args.restarts or r_default) <= 65536
-    steps = args.steps if args.steps is not None else (320 if small else 20)
-    warmup = args.warmup if args.warmup is not None else (32 if small else 5)
-
-    comm = make_comm(rank, world, local_rank)
-    m = run_workload(args, args.workload, rank, world, local_rank, comm, steps, warmup, args.streams, main=True)
-    secondary = None
-    if not args.no_secondary and args.workload == "cfg3" and not args.span_rules and not args.targets and not args.restarts:
-        # BASELINE configs[1] (1024 x 16 CNOT, the latency-bound small-batch regime) beside the headline
-        s2 = run_workload(args, "cfg2", rank, world, local_rank, comm, 320, 32, None, main=False)
-        fl2 = sum(s2["st"]["evals"][k] * f_eval(k) for k in (1, 2, 3))
-        secondary = {"cfg2": {
-            "workload": s2["desc"], "value": s2["solved_all"] / s2["elapsed"], "unit": "decompositions/s", "steps": 320, "warmup": 32,
-            "ms_per_step": 1e3 * s2["elapsed"] / 320, "batches_in_flight_per_gpu": s2["n_streams"], "steps_per_library_call": s2["group"],
-            "items_per_quad": s2["ipq"],
-            "solved_fraction": s2["solved_all"] / (world * 320 * s2["n_per_step"]),
-            "roofline_frac": fl2 / s2["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
-        }}
-        # the same batches ONE per library call, one call in flight: the latency of a lone small batch (round 4: the whole span loop of
-        # a target in one wavefront, one launch -- span_wave_kernel)
-        s3 = run_workload(args, "cfg2", rank, world, local_rank, comm, 40, 8, 1, main=False, group_arg=1)
-        fl3 = sum(s3["st"]["evals"][k] * f_eval(k) for k in (1, 2, 3))
-        secondary["cfg2"]["one_batch_per_call"] = {"value": s3["solved_all"] / s3["elapsed"], "ms_per_step": 1e3 * s3["elapsed"] / 40,
-                                                   "roofline_frac": fl3 / s3["elapsed"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                                                   "kernel_launches_per_step": s3["st"]["kernel_launches"] / 40}
-        if rank == 0 and not os.environ.get("SLAM_BENCH_TEST_STUB"):
-            secondary["v2"] = run_v2(rank, local_rank)
-            secondary["api"], secondary["api_large"] = run_api(local_rank)
-            secondary["medium_call"] = run_medium_call(local_rank)
-
-    rank_devices = gather_strings(comm, rank, world, f"{m['dev_name'].strip()} cu={m['cus']} dev={local_rank}")
-    if rank == 0:
-        st = m["st"]
-        n_launch = max(1, st["kernel_launches"])
-        pmc = pmc_figures(args.workload)
-        rep_ms = sorted(m["rep_ms"])
-        out = {
-            "metric": "Haar 2-qubit decompositions/sec (span<=3, loss<1e-8)",
-            "value": m["solved_all"] / m["elapsed"],
-            "unit": "decompositions/s",
-            "n_gpus": world,
-            "steps": steps,
-            "warmup": warmup,
-            "ms_per_step": 1e3 * m["elapsed"] / steps,
-            # the timed region (exactly `steps` steps between barriers) ran `repetitions` times on the same batches;
-            # value / ms_per_step / roofline are the MEDIAN repetition's, min / max show the box noise of this run
-            "repetitions": len(rep_ms),
-            "ms_per_step_min": rep_ms[0],
-            "ms_per_step_max": rep_ms[-1],
-            "ms_per_step_all": m["rep_ms"],
-            "higher_is_better": True,
-            "scaling": "strong" if m["strong"] else "weak",
-            # what RCCL itself reports for the communicator the collective ran on (ncclCommCount); None: no RCCL in this run
-            "rccl_world": getattr(comm, "rccl_world", None),
-            "comm": type(comm).__name__,
-            "rank_devices": rank_devices,
-            "vs_baseline": None,
-            "dtype": "f64",  # loss, gradient, parameters, steps: every counted flop; see config.metric_dtype
-            "data": "synthetic" if not os.environ.get("SLAM_BENCH_TEST_STUB") else "STUB: test hook, no GPU work was done, numbers are meaningless",
-            "config": {
-                "workload": m["desc"],
-                "basis": m["gname"],
-                "metric_dtype": "f32 (inverse-Hessian preconditioner of the quasi-Newton iteration only; not in the flop count)",
-                "targets_per_step_per_gpu": m["n_per_step"],
-                "restarts": m["restarts"],
-                "span_max": 3,
-                "span_selection": ("use_polytopes mode: every target starts at the template size its exact coverage set assigns (coverage.py: "
-                                   "the monodromy inequalities; looked up on the device, slam_predict_spans)") if args.span_rules else "brute force 1..3 (reference default)",
-                "success_threshold": m["threshold"],
-                "restart_early_exit": "first restart to finish below stop_loss wins (timing-dependent)" if args.fast_exit
-                else "ordered: lowest-index successful restart wins (reference semantics, bitwise reproducible)",
-                "parallelism": (f"bases sharded over {world} GPU(s) ({SWEEP_BASES_PER_GPU} each), targets replicated, no data-path collective"
-                                if m["sweep"] else f"targets sharded over {world} GPU(s), one process per GPU, no data-path collective"),
-                "final_collective": (None if world == 1 else
-                                     ("slam_allreduce_min: ncclAllReduce(min) of the resident best-loss windows, device to device (RCCL via C ABI)"
-                                      if m["resident_merge"] else f"min-all-reduce of the best-loss vector ({type(comm).__name__})")),
-                "batches_in_flight_per_gpu": m["n_streams"],
-                "steps_per_library_call": m["group"],
-                **({"library_call": "slam_decompose_multi: one multi-queue optimizer launch per span over the call's bases"} if m["mq"] else {}),
-                "items_per_quad": m["ipq"],
-                "device": m["dev_name"],
-                "compute_units": m["cus"],
-            },
-            "solved_fraction": m["solved_all"] / (world * steps * m["n_per_step"]),
-            "best_cycles_hist_rank0": {str(k): int(m["cyc_hist"][k]) for k in range(4)},
-            "worst_loss_rank0": m["worst"],
-            **({"per_basis_rank0": {str(b): v for b, v in sorted(m["per_basis"].items())}} if m["per_basis"] is not None else {}),
-            "roofline": {
-                "bound": "valu_fp64",
-                "achieved": m["achieved"],
-                "peak": PEAK_FP64_VALU_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": m["achieved"] / PEAK_FP64_VALU_TFLOPS,
-                # the DOMINANT kernel alone on the chip (minimize_kernel<1>: 64 % of the flops): algorithmic flops of a launch / the
-                # HIP events around it, mean over the back-to-back single-stream launches of `per_span` (= rocprofv3's average for
-                # those launches, profiles/r4_trace_summary.json).  `frac` above is the whole job on the wall clock.
-                "frac_kernel": (m["per_span"] or {}).get("1", {}).get("frac"),
-                "kernel_dominant": "minimize_kernel<1, *>",
-                "traffic": traffic_per_launch(args.workload),
-                # north_star's two evidence figures, per span, from the committed PMC passes of this workload
-                "valu_busy": pmc["valu_busy"] if pmc else None,
-                "hbm_gbps": pmc["hbm_gbps"] if pmc else None,
-                "pmc_source": pmc["source"] if pmc else None,
-                "kernel": "minimize_kernel<K> (k=1..3)",
-                "scope": "rank 0's GPU",
-                "time_basis": "hip_events" if m["n_streams"] == 1 else "wall_clock_of_timed_region",
-                "kernel_ms_total": st["kernel_ms"],
-                "kernel_ms_span": {str(k): st["kernel_ms_span"][k] for k in (1, 2, 3)},
-                "kernel_launches": st["kernel_launches"],
-                "avg_launch_ms": st["kernel_ms"] / n_launch,
-                "evals_per_span": {str(k): st["evals"][k] for k in (1, 2, 3)},
-                "evals_accepted": {str(k): st["evals_accepted"][k] for k in (1, 2, 3)},
-                "evals_rejected": {str(k): m["rejected"][k] for k in (1, 2, 3)},
-                "evals_preempted": {str(k): st["evals_preempted"][k] for k in (1, 2, 3)},
-                "items_per_span": {str(k): st["items"][k] for k in (1, 2, 3)},
-                "flops_per_eval": {str(k): f_eval(k) for k in (1, 2, 3)},
-                # the same time, stricter numerators: accepted points only; accepted at F_eval + rejected line-search
-                # trials at the forward-only count (SURVEY.md §8(d)), pre-empted restarts not counted at all
-                "frac_accepted": m["flops_accepted"] / m["kernel_s"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                "frac_accepted_plus_rejected_forward": m["flops_strict"] / m["kernel_s"] / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                "peak_note": "nominal: 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz; a pure v_fma_f64 loop sustains 58.8 TFLOP/s on this "
-                             "chip (it holds ~1.65 GHz under that load: tools/ubench_valu.hip, profiles/r2_ubench_valu.txt)",
-                "numerator_note": "dense flop accounting of SURVEY.md 8(d) for every lock-step evaluation; structured gates (CX = a swap) "
-                                  "count at the dense 4x4 product's cost",
-                **({"per_span": m["per_span"]} if m["per_span"] else {}),
-            },
-        }
-        if secondary:
-            out["secondary"] = secondary
-        if m["rank_diag"]:
-            out["rank_diag"] = m["rank_diag"]
-        parity = None
-        if world == 1 and not args.no_cpu_baseline:
-            parity, out["cpu_baseline"] = cpu_baseline(m["gname"], m["restarts"], TARGET_SEED0, OPT_SEED, args.cpu_sample, args.host_targets,
-                                                       gpu_sample=m["gpu_sample"])
-            if parity is not None:
-                out["parity_sample"] = parity
-        print(json.dumps(out), flush=True)
-        if parity is not None and not parity["pass"]:
-            print(f"[bench] parity sample FAILED: {parity}", file=sys.stderr, flush=True)
-            comm.close()
-            raise SystemExit(4)
-    comm.close()
-
+# the bench lives in benchlib/ (workloads, CPU baseline + parity sample, launcher, secondary probes, timed region + CLI); the names dev tools
+# and tests import from here stay importable
+from benchlib.cpu_baseline import cpu_baseline, parity_sample, parity_sample_size, usable_cores, weyl_distance  # noqa: E402,F401
+from benchlib.run import main, run_workload  # noqa: E402,F401
+from benchlib.secondary import run_api, run_long, run_medium_call, run_v2  # noqa: E402,F401
+from benchlib.workloads import (OPT_SEED, PEAK_FP64_VALU_TFLOPS, SUCCESS_LOSS, TARGET_SEED0, WORKLOADS, f_eval, f_eval_v2, f_forward,  # noqa: E402,F401
+                                gate_table, make_targets, sweep_gate)
 
 if __name__ == "__main__":
     main()

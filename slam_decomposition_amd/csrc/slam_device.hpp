@@ -108,6 +108,18 @@ __host__ __device__ constexpr int lds_work_doubles() {
 // twice per round); an LDS read is requested ahead and counted exactly by lgkmcnt
 constexpr int kColdDoubles = 4;
 constexpr int kSincosLdsDoubles = 2 * kSincosTableDoubles;  // the LDS copy of the sincos table covers the whole circle
+// Span 1, structured gate classes: the START POINTS of the next kSeedRing queue positions of the wavefront's chunk are generated
+// together -- one Philox block per lane, kSeedRing N / 2 = 48 lanes busy -- and parked in the SPARE doubles [70, 82) of the exchange
+// areas of quads 8 .. 15 (XNEED = 69 of XSTRIDE = 84 at span 1; the fp32 overlay of the quasi-Newton algebra ends inside quad 6's area):
+// no LDS is added, a k = 1 wavefront keeps sharing its SIMD's CU with a k = 3 one (4 x (11.5 + 27.7) KB = 157 of 160 KB).  A refill then
+// only copies.  Round 4 ran the blocks at the refill for the quads that took an item -- 12 .. 18 of 64 lanes busy for ~110 vector
+// instructions (20 quarter-rate 32 x 32 -> 64-bit multiplies among them) every four or five rounds.  (A 64-position ring in 6 KB of
+// extra LDS ran the k = 1 launch 3.4 % faster alone -- 8.73 -> 8.43 ms, 885 -> 860 vector instructions per round -- and the driver's
+// command 0.3 % SLOWER: with 17.5 KB per k = 1 wavefront the k = 1 / k = 3 pairing no longer fits four times into a CU.)
+constexpr int kSeedRing = 8;
+constexpr int kSeedRingOff = 70;
+template <int K, int GC>
+__host__ __device__ constexpr bool seed_ring() { return K == 1 && psq_layout<K, GC>(); }
 template <int K, int GC>
 __host__ __device__ constexpr int lds_doubles() { return lds_work_doubles<K, GC>() + kSincosLdsDoubles + kColdDoubles; }
 

@@ -252,6 +252,11 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
     // MQ: the wavefront starts on sub-problem blockIdx.x mod n_sub and moves on to the next one (cyclically) when that one's queue
     // is exhausted AND its own quads have drained -- gates, targets and outputs are wave-uniform, so a wavefront never holds items of
     // two sub-problems at once; it leaves after n_sub exhausted queues in a row
+    constexpr bool kRing = seed_ring<K, GC>();
+    if constexpr (kRing) static_assert(kSeedRingOff + C::N <= C::XSTRIDE && kSeedRingOff >= C::XNEED && (kSeedRingOff & 1) == 0, "the ring slots sit in the spare part of a quad's exchange area");
+    // ring slot r = the spare doubles of quad 8 + r's exchange area: the start point of queue position ring_base + r
+    double* const ring = xchg + 8 * C::XSTRIDE + kSeedRingOff;
+    unsigned ring_base = 0, ring_end = 0;  // wave-uniform: the queue positions the ring holds
     unsigned sub_idx = MQ ? (unsigned)blockIdx.x % (unsigned)n_sub : 0u;
     unsigned long long cur = MQ ? (unsigned long long)(subs + sub_idx) : 0ull;  // wave-uniform
     int sub_tries = 0;
@@ -323,6 +328,8 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
                 exhausted = false;
                 cur_next = 0;
                 cur_end = 0;
+                ring_base = 0;
+                ring_end = 0;  // (another queue: the parked start points are not its positions')
                 if (lane == 0) pre_base = atomicAdd(&cold_args<K, MQ>(cur)->ctl->work_counter, kChunk);
             }
         }
@@ -360,7 +367,32 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
                 // ---- scan up to 64 queue positions at once: lane l looks at position cur_next + l.  Positions whose
                 // target already has a successful restart are dropped here (one flag load for the whole window, their
                 // outputs written by the scanning lanes); the idle quads get the first positions that still need work.
-                const unsigned wlen = (cur_end - cur_next < (unsigned)kWave) ? cur_end - cur_next : (unsigned)kWave;
+                bool use_ring = false;  // wave-uniform
+                if constexpr (kRing) {
+                    use_ring = cold_args<K, MQ>(cur)->x0 == nullptr;
+                    if (use_ring && cur_next >= ring_end) {
+                        // the next kSeedRing positions' start points: lane l runs Philox block l % (N / 2) of position cur_next + l / (N / 2)
+                        constexpr int kPairs = C::N / 2;
+                        ring_base = cur_next;
+                        ring_end = (cur_next + (unsigned)kSeedRing < cur_end) ? cur_next + (unsigned)kSeedRing : cur_end;
+                        const int gr_ = lane / kPairs, gm = lane - gr_ * kPairs;
+                        if ((unsigned)gr_ < ring_end - ring_base) {
+                            const unsigned gp = ring_base + (unsigned)gr_;
+                            const unsigned grs = gp / n_act, gsl = gp - grs * n_act;
+                            int gt_;
+                            if constexpr (WL) gt_ = wl.t;
+                            else gt_ = cold_args<K, MQ>(cur)->orig ? cold_args<K, MQ>(cur)->orig[gsl] : cold_args<K, MQ>(cur)->first_target + (int)gsl;
+                            const uint64_t gseed = cold_args<K, MQ>(cur)->seed;
+                            uint32_t w[4];
+                            philox4x32_10((uint32_t)gm, grs, (uint32_t)(gt_ + (int)cold_args<K, MQ>(cur)->target_base), (uint32_t)K, (uint32_t)gseed,
+                                          (uint32_t)(gseed >> 32), w);
+                            *reinterpret_cast<double2*>(ring + gr_ * C::XSTRIDE + 2 * gm) = make_double2(x0_from_words(w[0], w[1]), x0_from_words(w[2], w[3]));
+                        }
+                        lds_fence();
+                    }
+                }
+                unsigned wlen = (cur_end - cur_next < (unsigned)kWave) ? cur_end - cur_next : (unsigned)kWave;
+                if (kRing && use_ring && ring_end - cur_next < wlen) wlen = ring_end - cur_next;  // hand out only what the ring holds
                 const bool valid = (unsigned)lane < wlen;
                 const unsigned pos = cur_next + (unsigned)lane;   // queue position
                 const unsigned prs = pos / n_act;                 // restart
@@ -400,12 +432,14 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
                 if (handed) {
                     wp[myrank] = (int)psl;
                     wp[16 + myrank] = (int)prs;
+                    if constexpr (kRing) wp[32 + myrank] = (int)(pos - ring_base);  // where this position's start point sits
                 }
                 lds_fence();
                 const int qrank = __popcll(idle & ((1ull << (lane & ~3)) - 1ull));  // rank of this quad among the idle ones
                 const bool get = !live && qrank < n_take;
                 const unsigned sl = get ? (unsigned)wp[qrank] : 0u;
                 const unsigned rs = get ? (unsigned)wp[16 + qrank] : 0u;
+                const int rslot = (kRing && get) ? wp[32 + qrank] : 0;
                 lds_fence();
                 cur_next += consumed;
                 {
@@ -453,7 +487,12 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
                         nev = 0; iters = 0; nback = 0; nstall = 0; status = ST_MAXITER;
                         scaled = false; fresh = true; live = true; taken = true;
                     }
-                    if constexpr (kSharedSeeds) {
+                    if constexpr (kRing) {
+                        if (shared && get) {
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) x[a] = (4 * a + q < C::N) ? ring[rslot * C::XSTRIDE + 4 * a + q] : 0.0;
+                        }
+                    } else if constexpr (kSharedSeeds) {
                         if (shared) {
                             constexpr int kPairs = C::N / 2;
                             static_assert(5 * C::N <= C::XSTRIDE && 4 * C::N * 8 >= 64 * 4, "staging area [4N, 5N) inside the quad's exchange area and clear of wp");

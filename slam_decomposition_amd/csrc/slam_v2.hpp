@@ -70,7 +70,13 @@ struct CfgV2 {
     static constexpr int LDS_BOUNDS = 2 * NA * 4;                // (lo, hi) per parameter, padded to 4 NA
     static constexpr int LDS_CW = NA * 4 + kQuadsPerWave * 8;    // cost constraint (after the trig table): one weight per parameter, then per quad
                                                                  // (mu, loss, c, multiplier updates) at x and (loss, c) at the trial point
-    static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH + LDS_BOUNDS + kSincosLdsDoubles + LDS_CW;
+    // span 1: the raw start values (x0_philox) of kRing consecutive queue positions, generated one position per lane when the
+    // wavefront reaches them -- a refill then copies.  (Until round 5 every taking lane ran its NA Philox blocks at the refill and the
+    // whole wavefront waited: ~460 vector instructions per refill event, one event every two or three rounds of ~1000 at span 1.)
+    static constexpr int kRing = (K == 1) ? 32 : 0;
+    static constexpr int RN = (N + 1) / 2 * 2;  // ring row: N values, padded to a double2 boundary
+    static constexpr int LDS_RING = kRing * RN;
+    static constexpr int LDS_DOUBLES = LDS_XCHG + LDS_FH + LDS_BOUNDS + kSincosLdsDoubles + LDS_CW + LDS_RING;
 };
 
 // ---- conversion-gain gate actions from the (cos, sin) table entries of the four raw angles -------------------------
@@ -680,6 +686,9 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
     // the item's multiplier state lives in LDS (all four lanes of a quad write the same values): the kernels that handle bounds
     // without a constraint keep their register budget
     double* cst = cw + 4 * NA + quad * 8;  // [0] mu [1] loss(x) [2] c(x) [3] updates [4] loss(trial) [5] c(trial)
+    double* const ring = lds + C::LDS_XCHG + C::LDS_FH + C::LDS_BOUNDS + kSincosLdsDoubles + C::LDS_CW;  // [kRing][RN]
+    unsigned ring_base = 0, ring_end = 0;  // wave-uniform: queue positions the ring holds
+    const bool use_ring = C::kRing > 0 && args.x0 == nullptr;  // wave-uniform
     lds_fence();
     const int theta_bits = theta_slot_bits_v2<K, QN>(q);
     // n_active < 0: the stage's target count is produced on the device by the previous stage's compaction (span loop enqueued
@@ -742,7 +751,30 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
                 cur_end = (b + kChunk < n_items) ? b + kChunk : n_items;
                 if (lane == 0) pre_base = atomicAdd(&args.ctl->work_counter, kChunk);
             }
-            const unsigned wlen = (cur_end - cur_next < (unsigned)kWave) ? cur_end - cur_next : (unsigned)kWave;
+            if constexpr (C::kRing > 0) {
+                if (use_ring && cur_next >= ring_end) {
+                    // the next kRing positions' start values: lane l runs the (N + 1) / 2 Philox blocks of position cur_next + l
+                    ring_base = cur_next;
+                    ring_end = (cur_next + (unsigned)C::kRing < cur_end) ? cur_next + (unsigned)C::kRing : cur_end;
+                    if ((unsigned)lane < ring_end - ring_base) {
+                        const unsigned gp = ring_base + (unsigned)lane;
+                        const unsigned gr = gp / n_act, gsl = gp - gr * n_act;
+                        const int gt_ = args.active ? args.active[gsl] : (int)gsl;
+                        const uint32_t tw = (uint32_t)(gt_ + (int)args.target_base);
+#pragma unroll 1
+                        for (int m = 0; m < C::RN / 2; ++m) {
+                            uint32_t w[4];
+                            philox4x32_10((uint32_t)m, gr, tw, (uint32_t)(K | 0x100), (uint32_t)args.seed, (uint32_t)(args.seed >> 32), w);
+                            *reinterpret_cast<double2*>(ring + lane * C::RN + 2 * m) = make_double2(x0_from_words(w[0], w[1]), x0_from_words(w[2], w[3]));
+                        }
+                    }
+                    lds_fence();
+                }
+            }
+            unsigned wlen = (cur_end - cur_next < (unsigned)kWave) ? cur_end - cur_next : (unsigned)kWave;
+            if constexpr (C::kRing > 0) {
+                if (use_ring && ring_end - cur_next < wlen) wlen = ring_end - cur_next;  // hand out only what the ring holds
+            }
             const bool valid = (unsigned)lane < wlen;
             const unsigned pos = cur_next + (unsigned)lane;
             const unsigned prs = pos / n_act, psl = pos - prs * n_act;
@@ -771,12 +803,14 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
             if (handed) {
                 wp[myrank] = (int)psl;
                 wp[16 + myrank] = (int)prs;
+                if constexpr (C::kRing > 0) wp[32 + myrank] = (int)(pos - ring_base);
             }
             lds_fence();
             const int qrank = __popcll(idle & ((1ull << (lane & ~3)) - 1ull));  // rank of this quad among the idle ones
             const bool get = !live && qrank < n_take;
             const unsigned sl = get ? (unsigned)wp[qrank] : 0u;
             const unsigned rs = get ? (unsigned)wp[16 + qrank] : 0u;
+            const int rslot = (C::kRing > 0 && get) ? wp[32 + qrank] : 0;
             lds_fence();
             cur_next += consumed;
             if (get) {
@@ -796,8 +830,9 @@ __global__ void __launch_bounds__(kWave, SLAM_V2_WAVES(K, QN, GQ, FREE)) minimiz
                         } else {
                             // same Philox stream layout as the fixed-gate path, span tagged with 0x100 (V2), mapped onto the
                             // parameter's start range
-                            const double u = x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), (uint32_t)rs, (uint32_t)(K | 0x100), (uint32_t)i) *
-                                             (1.0 / 6.283185307179586476925286766559);
+                            const double raw = (C::kRing > 0) ? ring[rslot * C::RN + i]
+                                                              : x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), (uint32_t)rs, (uint32_t)(K | 0x100), (uint32_t)i);
+                            const double u = raw * (1.0 / 6.283185307179586476925286766559);
                             xv = fma(u, args.init_hi[i] - args.init_lo[i], args.init_lo[i]);
                         }
                         const double2 b = bnd[i];

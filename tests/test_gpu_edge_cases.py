@@ -76,7 +76,7 @@ def test_error_codes(hip_ctx):
         hip_ctx.minimize_stage([0], _prm(restarts=0))
     assert e.value.code == -1
     with pytest.raises(_ffi.SlamHipError) as e:
-        hip_ctx.minimize_stage([0] * 6, _prm())  # span 6: unsupported
+        hip_ctx.minimize_stage([0] * 17, _prm())  # span 17: unsupported (round 5: 6..16 run, one wavefront per item)
     assert e.value.code == -3
     with pytest.raises(_ffi.SlamHipError) as e:
         hip_ctx.minimize_stage([0], _prm(restarts=1), active=np.array([5], np.int32))
