@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 SRC   := slam_decomposition_amd/csrc/slam_hip.hip slam_decomposition_amd/csrc/slam_comm.hip
-HDRS  := slam_decomposition_amd/csrc/slam_device.hpp slam_decomposition_amd/csrc/slam_kernels.hpp slam_decomposition_amd/csrc/slam_sampler.hpp slam_decomposition_amd/csrc/slam_weyl.hpp slam_decomposition_amd/csrc/slam_sincos.hpp slam_decomposition_amd/csrc/slam_v2.hpp include/slam_hip.h
+HDRS  := slam_decomposition_amd/csrc/slam_device.hpp slam_decomposition_amd/csrc/slam_kernels.hpp slam_decomposition_amd/csrc/slam_sampler.hpp slam_decomposition_amd/csrc/slam_weyl.hpp slam_decomposition_amd/csrc/slam_sincos.hpp slam_decomposition_amd/csrc/slam_v2.hpp slam_decomposition_amd/csrc/slam_long.hpp include/slam_hip.h
 OUT   := slam_decomposition_amd/lib/libslamhip.so
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -ldl
 

@@ -39,7 +39,9 @@ constexpr int kLongOffTrig = kLongOffG + kLongNP;               // (cos, sin) of
 constexpr int kLongOffPre = kLongOffTrig + 12 * kLongMaxLayers; // Pre_j, column-major 4x4 complex: [L][16] double2
 constexpr int kLongOffQ = kLongOffPre + 32 * kLongMaxLayers;    // Q_j
 constexpr int kLongOffHist = kLongOffQ + 32 * kLongMaxLayers;   // S[8][NP], Y[8][NP] as float
-constexpr int kLongLdsDoubles = kLongOffHist + (2 * kLongHist * kLongNP + 1) / 2;
+constexpr int kLongOffRho = kLongOffHist + (2 * kLongHist * kLongNP + 1) / 2;  // 1 / (s.y) of the stored pairs
+constexpr int kLongLdsDoubles = kLongOffRho + kLongHist;
+static_assert(8 * (size_t)kLongLdsDoubles * sizeof(double) <= 160 * 1024, "two wavefronts per SIMD need eight wavefronts' LDS per CU");
 constexpr size_t kLongLdsBytes = (size_t)kLongLdsDoubles * sizeof(double);
 
 struct LongArgs {
@@ -143,7 +145,30 @@ __device__ __forceinline__ void row_mat(const double (&ar)[4], const double (&ai
 // (tcol = T[0][c]), the gate table.  Out: the loss (wave-uniform), the gradient in lds[kLongOffG ..], W = Pre_{L-1} in LDS.
 // `pin_exterior`: layers 0 and k contribute no gradient (SLAM_FLAG_NO_EXTERIOR).
 // ---------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double eval_long(double* lds, const double* tcol, const double* gates, int k, int cost_kind, bool pin_exterior) {
+// The item's target column and the lane's gate columns (column c of G_j for the layers j = quad, quad + 16 this lane's quad owns: constant
+// for the whole launch) are loaded by the caller ONCE -- per evaluation they were two rounds of global loads with two wavefronts per SIMD
+// to hide them.
+struct LongGateCols {
+    double r[2][4], i[2][4];
+};
+__device__ __forceinline__ LongGateCols load_gate_cols(const double* gates, int k) {
+    LongGateCols g;
+    const int c = threadIdx.x & 3, quad = threadIdx.x >> 2;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int j = quad + 16 * ps;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double2 e = make_double2(r == c ? 1.0 : 0.0, 0.0);  // G_0 = 1
+            if (j >= 1 && j <= k) e = *reinterpret_cast<const double2*>(gates + 32 * (j - 1) + (r * 4 + c) * 2);
+            g.r[ps][r] = e.x;
+            g.i[ps][r] = e.y;
+        }
+    }
+    return g;
+}
+template <bool HUGE_ARGS>
+__device__ __forceinline__ double eval_long(double* lds, const double (&tre)[4], const double (&tim)[4], const LongGateCols& gcol, int k, int cost_kind, bool pin_exterior) {
     const int lane = threadIdx.x;
     const int c = lane & 3;
     const int quad = lane >> 2;
@@ -156,13 +181,6 @@ __device__ __forceinline__ double eval_long(double* lds, const double* tcol, con
     double2* Q = reinterpret_cast<double2*>(lds + kLongOffQ);
     const int npass = L > 16 ? 2 : 1;
 
-    double tre[4], tim[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double2 t = *reinterpret_cast<const double2*>(tcol + 8 * r);
-        tre[r] = t.x;
-        tim[r] = t.y;
-    }
     // ---- 1. trig entries: lane c of quad j handles parameters c and c + 4 of layer j
     for (int ps = 0; ps < npass; ++ps) {
         const int j = quad + 16 * ps;
@@ -174,7 +192,8 @@ __device__ __forceinline__ double eval_long(double* lds, const double* tcol, con
                     const double xv = xs[6 * j + m];
                     const double arg = (m == 0 || m == 3) ? 0.5 * xv : xv;
                     double s, co;
-                    sincos_any(arg, tbl, s, co);
+                    if constexpr (HUGE_ARGS) sincos_any(arg, tbl, s, co);
+                    else sincos_tbl(arg, tbl, s, co);  // (the optimizer's angles stay far below the table path's limit)
                     trig[6 * j + m] = make_double2(co, s);
                 }
             }
@@ -187,16 +206,10 @@ __device__ __forceinline__ double eval_long(double* lds, const double* tcol, con
         if (j < L) {
             const U3t B = load_u3(reinterpret_cast<const double*>(trig), 6 * j), A = load_u3(reinterpret_cast<const double*>(trig), 6 * j + 3);
             double Fr[4], Fi[4];
-            if (j == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { Fr[r] = (r == c) ? 1.0 : 0.0; Fi[r] = 0.0; }
-            } else {
-                const double* G = gates + 32 * (j - 1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double2 e = *reinterpret_cast<const double2*>(G + (r * 4 + c) * 2);
-                    Fr[r] = e.x; Fi[r] = e.y;
-                }
+            for (int r = 0; r < 4; ++r) {
+                Fr[r] = ps == 0 ? gcol.r[0][r] : gcol.r[1][r];
+                Fi[r] = ps == 0 ? gcol.i[0][r] : gcol.i[1][r];
             }
             u3_col(B, Fr[0], Fi[0], Fr[1], Fi[1]);
             u3_col(B, Fr[2], Fi[2], Fr[3], Fi[3]);
@@ -375,6 +388,7 @@ __global__ void __launch_bounds__(kWave, 2) eval_long_kernel(LongEvalArgs a) {
     const int lane = threadIdx.x;
     const int n = 6 * (a.k + 1);
     long_prologue(lds);
+    const LongGateCols gcol = load_gate_cols(a.gates, a.k);
     for (int64_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         const int64_t tgt = a.target_of[item];
 #pragma unroll
@@ -383,7 +397,14 @@ __global__ void __launch_bounds__(kWave, 2) eval_long_kernel(LongEvalArgs a) {
             if (i < kLongNP) lds[kLongOffX + i] = (i < n) ? a.x[item * n + i] : 0.0;
         }
         lds_fence();
-        const double f = eval_long(lds, a.targets + tgt * 32 + (lane & 3) * 2, a.gates, a.k, a.cost_kind, false);
+        double tre[4], tim[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 t = *reinterpret_cast<const double2*>(a.targets + tgt * 32 + (lane & 3) * 2 + 8 * r);
+            tre[r] = t.x;
+            tim[r] = t.y;
+        }
+        const double f = eval_long<true>(lds, tre, tim, gcol, a.k, a.cost_kind, false);
         if (lane == 0) a.loss[item] = f;
         if (a.grad) {
 #pragma unroll
@@ -413,7 +434,9 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
     const int n = 6 * (k + 1);
     float* Sh = reinterpret_cast<float*>(lds + kLongOffHist);
     float* Yh = Sh + kLongHist * kLongNP;
+    double* rho = lds + kLongOffRho;  // (wave-uniform values, in LDS: indexed by the ring position at run time)
     long_prologue(lds);
+    const LongGateCols gcol = load_gate_cols(args.gates, k);
     const unsigned n_act = (unsigned)args.ctl->n_active;
     const unsigned n_items = n_act * (unsigned)args.restarts;
     const bool early = args.flags & 1u, ordered = args.flags & 2u, pin = args.flags & kFlagNoExterior;
@@ -442,7 +465,13 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
             }
         }
         const int tgt = args.orig ? args.orig[sl] : args.first_target + (int)sl;
-        const double* tcol = args.targets + (int64_t)sl * 32 + (lane & 3) * 2;
+        double tre[4], tim[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 t = *reinterpret_cast<const double2*>(args.targets + (int64_t)sl * 32 + (lane & 3) * 2 + 8 * r);
+            tre[r] = t.x;
+            tim[r] = t.y;
+        }
         double x[kLongSlots], g[kLongSlots], p[kLongSlots];
 #pragma unroll
         for (int s = 0; s < kLongSlots; ++s) {
@@ -453,11 +482,10 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
             if (i < kLongNP) lds[kLongOffX + i] = xv;
         }
         lds_fence();
-        double f = eval_long(lds, tcol, args.gates, k, args.cost_kind, pin);
+        double f = eval_long<false>(lds, tre, tim, gcol, k, args.cost_kind, pin);
         ++rounds;
         int nev = 1, nacc = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
         int cnt = 0, head = 0;  // history: cnt pairs, the newest at (head - 1) mod kLongHist
-        double rho[kLongHist];
         double gamma = 1.0, grow = 1.0;
         double gnorm = 0.0, gp = 0.0, pp = 0.0, alpha = 0.0;
         bool done = false;
@@ -493,7 +521,7 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
                 if (i < kLongNP) lds[kLongOffX + i] = xt[s];
             }
             lds_fence();
-            const double ft = eval_long(lds, tcol, args.gates, k, args.cost_kind, pin);
+            const double ft = eval_long<false>(lds, tre, tim, gcol, k, args.cost_kind, pin);
             ++rounds;
             ++nev;
             const bool finite = isfinite(ft);
@@ -527,9 +555,7 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
                             Yh[head * kLongNP + i] = (float)(gt[s] - g[s]);
                         }
                     }
-                    const double r = fast_rcp(sy);
-#pragma unroll
-                    for (int h = 0; h < kLongHist; ++h) rho[h] = (h == head) ? r : rho[h];
+                    if (lane == 0) rho[head] = fast_rcp(sy);
                     head = (head + 1 == kLongHist) ? 0 : head + 1;
                     cnt = cnt < kLongHist ? cnt + 1 : kLongHist;
                     gamma = sy * fast_rcp(yy);
@@ -558,9 +584,8 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
                         if (t < cnt) {
                             int h = head - 1 - t;
                             h = h < 0 ? h + kLongHist : h;
-                            double d = 0.0, rh = 0.0;
-#pragma unroll
-                            for (int hh = 0; hh < kLongHist; ++hh) rh = (hh == h) ? rho[hh] : rh;
+                            double d = 0.0;
+                            const double rh = rho[h];
                             double sv[kLongSlots], yv[kLongSlots];
 #pragma unroll
                             for (int s = 0; s < kLongSlots; ++s) {
@@ -582,9 +607,8 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
                         if (t < cnt) {
                             int h = head - 1 - t;
                             h = h < 0 ? h + kLongHist : h;
-                            double d = 0.0, rh = 0.0;
-#pragma unroll
-                            for (int hh = 0; hh < kLongHist; ++hh) rh = (hh == h) ? rho[hh] : rh;
+                            double d = 0.0;
+                            const double rh = rho[h];
                             double sv[kLongSlots];
 #pragma unroll
                             for (int s = 0; s < kLongSlots; ++s) {

@@ -1,9 +1,10 @@
 #!/bin/bash
-# GPU box: the start-point rings (in-tree build: k = 1 fixed-gate kernels, span-1 V2 kernels) against the previous build (lib/ab/base.so):
-# bit-equality / parity tests, kbench A/B, VALU per round, the driver command A/B, secondary.v2 A/B.
+# GPU box: the in-tree build against a previous one (tools/ab_build.sh base <rev> -> lib/ab/base.so), everything a kernel change has to
+# show in one call: bit-equality / parity tests, the 65 536 x 32 kernels alone (kbench), dynamic instructions per round (PMC), the driver's
+# command, secondary.v2.  (Round 5: the start-point rings -- profiles/r5_ring_ab.txt.)
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r5_ring; mkdir -p $OUT
+OUT=gpurun_out/ab_full; mkdir -p $OUT
 timeout -k 10 1000 python3 -m pytest tests/test_gpu_minimize_parity.py tests/test_gpu_round2.py tests/test_gpu_round4.py tests/test_gpu_edge_cases.py tests/test_gpu_api.py tests/test_gpu_v2.py -x -q > $OUT/pytest.txt 2>&1; rc=$?
 tail -4 $OUT/pytest.txt
 [ $rc -ne 0 ] && { grep -n "Error\|assert\|FAILED" $OUT/pytest.txt | tail -20; exit 1; }
