@@ -49,6 +49,11 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     group = 1
     if (small or (main and args.group)) and not (gname == "cgsweep") and not (main and args.span_rules):
         group = args.group if (main and args.group) else (group_arg or 20)  # measured (320 steps, 4 streams): 10 -> 0.40, 16 -> 0.44, 20 -> 0.445, 32 -> 0.44 of peak
+    # the configs[3] shard (32 768 x 16): two steps per call, eight calls in flight -- measured on 80 steps (gpurun_out/r5_cfg4_sweep2.txt): one
+    # step per call x 12 in flight 1.24e7 decompositions/s / 0.410 of peak, 2 x 8 1.36e7 / 0.429, 5 x 4 1.33e7 / 0.404, 4 x 6 1.20e7, 8 x 3 1.09e7
+    cfg4_shape = main and workload == "cfg4" and not args.group and not n_streams_arg and not args.span_rules and not args.targets and not strong
+    if cfg4_shape:
+        group = 2
     group = max(1, min(group, steps))
     # (the basis sweep cannot group its steps -- every step has its own gate -- so it keeps more of them in flight; measured on
     # MI355X, 160 steps: 4 in flight 1.42e6 decompositions/s / 0.289 of peak, 8: 1.68e6 / 0.338, 16: 1.82e6 / 0.363)
@@ -63,6 +68,8 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     if mq:
         group = min(args.group if (main and args.group) else 8, SWEEP_BASES_PER_GPU, steps)
     n_streams = n_streams_arg if n_streams_arg else ((4 if mq else 16) if sweep else (4 if small else _batches_in_flight(n_per_step * restarts, main and args.span_rules)))
+    if cfg4_shape:
+        n_streams = 8
     n_streams = max(1, min(n_streams, (steps + group - 1) // group))
     ctxs = [_ffi.Context(device) for _ in range(n_streams * (group if mq else 1))]
     dev_name, cus, _ = ctxs[0].device_info()
@@ -456,8 +463,14 @@ def main():
 
     _, n_default, r_default, _ = WORKLOADS[args.workload]
     small = (args.targets or n_default) * (args.restarts or r_default) <= 65536
-    steps = args.steps if args.steps is not None else (320 if small else 20)
-    warmup = args.warmup if args.warmup is not None else (32 if small else 5)
+    # default length of the timed region by workload: at least a quarter of a second of device time (the cfg4 shard's 20 steps were a 58 ms
+    # region with calls of 35 ms latency in flight: a fifth of it was the pipeline filling and draining -- 1.13e7 against 1.24e7 on 80 steps)
+    by_workload = {"cfg4": (80, 8), "cfg5": (160, 16)}
+    d_steps, d_warm = by_workload.get(args.workload, (320, 32) if small else (20, 5))
+    if small:
+        d_steps, d_warm = 320, 32
+    steps = args.steps if args.steps is not None else d_steps
+    warmup = args.warmup if args.warmup is not None else d_warm
 
     comm = make_comm(rank, world, local_rank)
     m = run_workload(args, args.workload, rank, world, local_rank, comm, steps, warmup, args.streams, main=True)

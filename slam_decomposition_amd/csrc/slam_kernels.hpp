@@ -350,7 +350,13 @@ __device__ __forceinline__ void minimize_body(const MinimizeArgs<K>& args, const
             // the refill code is wave-wide (everyone waits while it runs), so at short spans -- where
             // items last only ~40 rounds -- it pays to let kRefillBatch quads go idle before running it
             // (3 / 2 / 1 before the seeds were shared out over the wave; measured again since: k = 1 10.96 -> 10.72 ms, k = 2 7.95 -> 7.87)
-            constexpr int kRefillBatch = (K == 1) ? 2 : 1;
+#ifndef SLAM_REFILL_BATCH_K1
+#define SLAM_REFILL_BATCH_K1 2
+#endif
+#ifndef SLAM_REFILL_BATCH_K2
+#define SLAM_REFILL_BATCH_K2 1
+#endif
+            constexpr int kRefillBatch = (K == 1) ? SLAM_REFILL_BATCH_K1 : (K == 2 ? SLAM_REFILL_BATCH_K2 : 1);
             const int n_idle = __popcll(__ballot(!live && q == 0));
             const bool go = n_idle >= kRefillBatch || n_idle == __popcll(__ballot(q == 0));
             while (go && !exhausted && __any(!live)) {
