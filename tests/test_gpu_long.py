@@ -155,3 +155,73 @@ def test_mixed_order_template_of_twelve_weak_gates_through_the_api():
             sel = np.nonzero(want == k)[0].astype(np.int32)
             out = ctx.minimize_stage([0] * (int(k) - 1), prm, active=sel, want_items=False)
             assert np.all(out["best_loss"] > 1e-8), (k, out["best_loss"])
+
+
+def test_sixteen_gates_optimizer_and_pinned_exterior(hip_ctx):
+    """The two-pass case (17 layers: quad 0 owns layers 0 and 16) through the optimizer, and SLAM_FLAG_NO_EXTERIOR on the long kernels:
+    a 16-gate template of the weak gate reaches targets built from it (SciPy BFGS on the oracle reaches the same loss from the same
+    start); with the exterior layers pinned the result keeps them at exactly zero and equals SciPy on the reduced function."""
+    k = 16
+    rng = np.random.default_rng(2016)
+    T = np.stack([o.template_eval(rng.uniform(0, 2 * np.pi, 6 * (k + 1)), [WEAK] * k) for _ in range(2)])
+    hip_ctx.set_targets(T)
+    hip_ctx.set_gates(WEAK[None])
+    R = 3
+    x0 = rng.uniform(0, 2 * np.pi, (2, R, 6 * (k + 1)))
+    out = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=1), x0=x0)
+    assert np.all(out["best_loss"] < 1e-10)
+    for t in range(2):
+        assert abs(o.loss(out["best_x"][t], [WEAK] * k, T[t]) - out["best_loss"][t]) < 1e-12
+        ref = opt.minimize(lambda xx: o.loss_and_grad(xx, [WEAK] * k, T[t]), x0[t, 0], jac=True, method="BFGS", options={"maxiter": 2500, "gtol": 1e-9}).fun
+        assert ref < 1e-10
+    # pinned exterior layers at k = 6: targets inside the reduced template's reach
+    k = 6
+
+    def pad(xr):
+        x = np.zeros(6 * (k + 1))
+        x[6 : 6 * k] = xr
+        return x
+
+    T = np.stack([o.template_eval(pad(rng.uniform(0, 2 * np.pi, 6 * (k - 1))), [SQ] * k) for _ in range(3)])
+    hip_ctx.set_targets(T)
+    hip_ctx.set_gates(SQ[None])
+    x0 = rng.uniform(0, 2 * np.pi, (3, 4, 6 * (k + 1)))
+    out = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=4, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=1, flags=_ffi.FLAG_NO_EXTERIOR), x0=x0)
+    assert np.all(out["best_x"][:, :6] == 0.0) and np.all(out["best_x"][:, 6 * k :] == 0.0)
+    assert np.all(out["best_loss"] < 1e-10)
+    for t in range(3):
+        assert abs(o.loss(out["best_x"][t], [SQ] * k, T[t]) - out["best_loss"][t]) < 1e-12
+
+
+def test_predicted_span_loop_crossing_into_the_long_kernels():
+    """slam_decompose_predicted with k_max = 7 on the pi/16 gain gate: the targets of sizes 4 .. 7 join the loop at their stage -- quad
+    kernels up to five gates, wavefront-per-item kernels beyond -- and everything the host-side lookup assigns a size <= 7 is solved
+    at that size (exact regions, carry = 0); bigger targets come back as out of reach."""
+    from slam_decomposition_amd import coverage
+    from slam_decomposition_amd.weyl import c1c2c3
+
+    n, R, kmax = 400, 12, 7
+    coords = [c1c2c3(WEAK)] * kmax
+    with _ffi.Context(0) as ctx:
+        ctx.sample_haar(8080, n)
+        ctx.set_gates(WEAK[None])
+        tc = ctx.targets_c1c2c3(0, n)
+        want = coverage.minimal_prefix(tc, coords, kmax)
+        prm = _ffi.OptParams(restarts=R, seed=4, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+        n_loc, n_unr = ctx.decompose_predicted(coords, kmax, [[0] * k for k in range(1, kmax + 1)], prm, 1e-10, 0, n)
+        loss, x, cyc = ctx.fetch_results_range(kmax, 0, n)
+    assert n_loc == 0 and n_unr == int((want > kmax).sum()) and 0 < n_unr < n
+    ran = want <= kmax
+    assert np.array_equal(cyc[ran], want[ran]) and np.all(cyc[~ran] == -1)
+    assert np.mean(loss[ran] < 1e-10) > 0.97  # (a few targets next to a region's face miss it with 12 restarts)
+    for t in np.nonzero(ran & (loss < 1e-10))[0][::9]:
+        kk = int(cyc[t])
+        assert abs(o.loss(x[t, : 6 * (kk + 1)], [WEAK] * kk, DeviceTargets.get(8080, t)) - loss[t]) < 1e-12
+
+
+class DeviceTargets:
+    """The device sampler's targets on the host (oracle port of slam_sample_haar)."""
+
+    @staticmethod
+    def get(seed, i):
+        return o.haar_philox_port(seed, i)

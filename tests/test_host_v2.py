@@ -68,9 +68,21 @@ def test_bounds_follow_the_reference_semantics():
     b.set_constraint(1.0)  # (the HIP path runs cost constraints since round 3: test_constraint_layout_... below)
     assert b.using_constraints
     b.remove_constraint()
-    for kw in (dict(param_vec_expand=[1, 2]), dict(use_polytopes=True), dict(n_qubits=3)):
+    for kw in (dict(param_vec_expand=[1, 2]), dict(n_qubits=3)):
         with pytest.raises(NotImplementedError):
             CircuitTemplateV2(**kw)
+    # use_polytopes (round 5): the coverage regions describe circuits of FIXED gates -- free gate parameters raise at the lookup,
+    # parameters bounded to a point give range(k, k + 1) (basisv2.py:77-85; GPU side: tests/test_gpu_round5.py)
+    pv = CircuitTemplateV2(use_polytopes=True, maximum_span_guess=3)
+    assert pv.spanning_range is None
+    with pytest.raises(NotImplementedError):
+        pv.get_spanning_range(np.eye(4)[[0, 2, 1, 3]])
+    pv.build(3)
+    for name in ("Q0", "Q1", "Q2"):
+        pv.add_bound(name, max=1.0, min=1.0)  # three iSWAPs
+    from oracle import slam_oracle as oo
+    assert list(pv.get_spanning_range(oo.riswap_matrix(1.0))) == [1] and list(pv.get_spanning_range(oo.cx_matrix())) == [2]
+    assert list(pv.get_spanning_range(np.eye(4)[[0, 2, 1, 3]])) == [3]  # SWAP needs three iSWAPs
     with pytest.raises(NotImplementedError):
         b.build(6)  # spans above SLAM_V2_MAX_SPAN = 5
     with pytest.raises(ValueError):
