@@ -118,6 +118,7 @@ struct slam_ctx {
     int32_t result_nmax = 0;
     int64_t result_filled = 0;  // targets whose resident results have been initialised (+inf / -1) for result_nmax
     DevBuf counters;  // StageCtl[SLAM_MAX_SPAN_EVAL + 2]: one control block per span stage (slam_kernels.hpp)
+    DevBuf long_hmem;  // inverse Hessian approximations of the wavefront-per-item kernels: [resident wavefronts][n][128] floats
     DevBuf bucket_lists, bucket_counts;  // slam_decompose_predicted: per-size target lists [k_max][count], their sizes
     int32_t* h_bucket_counts = nullptr;  // pinned mirror of bucket_counts
     DevBuf solved;
@@ -158,7 +159,7 @@ struct slam_ctx {
 
     ~slam_ctx() {
         DevBuf* all[] = {&targets, &gates, &active, &active2, &x0, &item_rec, &item_x, &stage_loss, &stage_x, &stage_restart, &best_loss,
-                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &bucket_lists, &bucket_counts, &v2_cons_w[0], &v2_cons_w[1], &v2_cons_w[2], &v2_cons_w[3], &v2_cons_w[4], &v2_cons_w[5], &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
+                         &best_x, &best_cycles, &span_loss, &trace_loss, &trace_x, &v2_maps, &v2_bounds, &v2_hmem, &long_hmem, &bucket_lists, &bucket_counts, &v2_cons_w[0], &v2_cons_w[1], &v2_cons_w[2], &v2_cons_w[3], &v2_cons_w[4], &v2_cons_w[5], &counters, &solved, &stage_targets, &span_gates, &ev_x, &ev_tof, &ev_loss, &ev_grad, &ev_unitary, &ev_weyl};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ev_a) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_b) if (e) (void)hipEventDestroy(e);
@@ -425,6 +426,9 @@ int launch_minimize_long(slam_ctx* c, const StageLaunch& sl, int k) {
     int64_t blocks = sl.n_items_max;  // one item per wavefront at a time
     if (blocks > c->resident_waves_long) blocks = c->resident_waves_long;
     if (blocks < 1) blocks = 1;
+    // (sized for the whole grid and the longest template once: growing it between two stages of a chain would free it under the stage in flight)
+    HIP_TRY(c->long_hmem.reserve((size_t)c->resident_waves_long * (size_t)(6 * (SLAM_MAX_SPAN_MINIMIZE + 1)) * kLongHStride * sizeof(float)));
+    a.hmem = c->long_hmem.as<float>();
     HIP_TRY(hipEventRecord(c->ev_a[k], c->stream));
     hipLaunchKernelGGL(minimize_long_kernel, dim3((unsigned)blocks), dim3(kWave), kLongLdsBytes, c->stream, a);
     HIP_TRY(hipGetLastError());

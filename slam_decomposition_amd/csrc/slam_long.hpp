@@ -11,10 +11,14 @@
 //     exchanged through the wave's LDS) instead of a chain of 16 dependent layers;
 //   * the loss needs Tr(T^+ Pre_L-1); the six derivatives of layer j need row c of Suf_j = z T^+ Q_j+1 and column c of Pre_j -- the
 //     quad computes them with the same U3 derivative formulas as eval_quad (slam_device.hpp) and the gradient goes back through LDS;
-//   * the optimizer is L-BFGS (8 pairs, kept in LDS as fp32 -- a preconditioner, like the quad kernels' fp32 metric) with the SAME
-//     line search and acceptance rules as minimize_body: Armijo backtracking from a first step capped at 2 rad, cautious update
-//     (pairs violating the weak-Wolfe curvature condition are not stored, the next first step grows), periodic restart, the same
-//     stopping tests.  Control flow is wave-uniform: one item per wavefront, no lock-step state machine.
+//   * the optimizer is the SAME quasi-Newton iteration as minimize_body (oracle/bfgs_port.py is its NumPy form): BFGS with the inverse
+//     Hessian approximation in fp32 -- here an n x n matrix per wavefront in DEVICE MEMORY (at most 102 x 128 floats = 52 KB per
+//     wavefront; the slices of the resident wavefronts sit in L2 / Infinity Cache), lane l owning columns 2l and 2l + 1 --, one
+//     matrix-vector product and one rank-2 update per accepted step, Armijo backtracking from a first step capped at 2 rad, cautious
+//     update (steps violating the weak-Wolfe curvature condition do not touch the metric, the next first step grows), periodic restart,
+//     the same stopping tests.  (A first version kept 8 L-BFGS pairs in LDS: on an 8-gate template of a weak gate SciPy's L-BFGS-B with
+//     8 pairs needs 3.4 x the evaluations of its BFGS -- mean 621 against 183, maximum 1788 against 396 --, and one item per wavefront
+//     turns every straggler into stage time.)  Control flow is wave-uniform: one item per wavefront, no lock-step state machine.
 // Loss, gradient, parameters, steps: fp64.
 //
 // Reference behaviour: CircuitTemplate.eval src/slam/basis.py:102-104,124-169; BasicCost src/slam/cost_function.py:140-145; the
@@ -27,9 +31,10 @@ namespace slamdev {
 constexpr int kLongMaxSpan = 16;
 constexpr int kLongMaxLayers = kLongMaxSpan + 1;  // 17: quads 0..15 in pass 0, quad 0 again in pass 1
 constexpr int kLongN = 6 * kLongMaxLayers;        // 102 parameters at most
-constexpr int kLongNP = 104;                      // padded vector length in LDS
-constexpr int kLongSlots = 2;                     // parameter slots per lane: component i = lane + 64 a
-constexpr int kLongHist = 8;                      // L-BFGS pairs
+constexpr int kLongNP = 128;                      // vector length in LDS: component i = 2 lane + a, a = 0, 1
+constexpr int kLongSlots = 2;                     // parameter slots per lane (an adjacent pair: one Philox block, one float2 of a metric row)
+constexpr int kLongHStride = kLongNP;             // floats per row of the inverse Hessian in device memory
+constexpr int kLongRowBatch = 12;                 // rows of it requested together (mat-vec / update passes)
 
 // LDS of one wavefront, in doubles
 constexpr int kLongOffTbl = 0;                                  // sincos table (64 double2)
@@ -38,11 +43,10 @@ constexpr int kLongOffG = kLongOffX + kLongNP;                  // gradient g[NP
 constexpr int kLongOffTrig = kLongOffG + kLongNP;               // (cos, sin) of the 6 angles of every layer: [L][6] double2
 constexpr int kLongOffPre = kLongOffTrig + 12 * kLongMaxLayers; // Pre_j, column-major 4x4 complex: [L][16] double2
 constexpr int kLongOffQ = kLongOffPre + 32 * kLongMaxLayers;    // Q_j
-constexpr int kLongOffHist = kLongOffQ + 32 * kLongMaxLayers;   // S[8][NP], Y[8][NP] as float
-constexpr int kLongOffRho = kLongOffHist + (2 * kLongHist * kLongNP + 1) / 2;  // 1 / (s.y) of the stored pairs
-constexpr int kLongLdsDoubles = kLongOffRho + kLongHist;
-static_assert(8 * (size_t)kLongLdsDoubles * sizeof(double) <= 160 * 1024, "two wavefronts per SIMD need eight wavefronts' LDS per CU");
+constexpr int kLongOffF32 = kLongOffQ + 32 * kLongMaxLayers;    // three fp32 vectors [NP]: broadcast operands of the metric's mat-vec / update
+constexpr int kLongLdsDoubles = kLongOffF32 + 3 * kLongNP / 2;
 constexpr size_t kLongLdsBytes = (size_t)kLongLdsDoubles * sizeof(double);
+static_assert(8 * kLongLdsBytes <= 160 * 1024, "two wavefronts per SIMD need eight wavefronts' LDS per CU");
 
 struct LongArgs {
     const double* targets;    // [n_active][32]: target of stage slot s
@@ -62,6 +66,7 @@ struct LongArgs {
     double* item_x;           // [M][n]
     const double* gates;      // [k][32]
     int32_t k;
+    float* hmem;              // [gridDim.x][n][kLongHStride]: the wavefronts' inverse Hessian approximations
 };
 
 struct LongEvalArgs {
@@ -393,8 +398,8 @@ __global__ void __launch_bounds__(kWave, 2) eval_long_kernel(LongEvalArgs a) {
         const int64_t tgt = a.target_of[item];
 #pragma unroll
         for (int s = 0; s < kLongSlots; ++s) {
-            const int i = lane + 64 * s;
-            if (i < kLongNP) lds[kLongOffX + i] = (i < n) ? a.x[item * n + i] : 0.0;
+            const int i = 2 * lane + s;
+            lds[kLongOffX + i] = (i < n) ? a.x[item * n + i] : 0.0;
         }
         lds_fence();
         double tre[4], tim[4];
@@ -409,7 +414,7 @@ __global__ void __launch_bounds__(kWave, 2) eval_long_kernel(LongEvalArgs a) {
         if (a.grad) {
 #pragma unroll
             for (int s = 0; s < kLongSlots; ++s) {
-                const int i = lane + 64 * s;
+                const int i = 2 * lane + s;
                 if (i < n) a.grad[item * n + i] = lds[kLongOffG + i];
             }
         }
@@ -425,16 +430,20 @@ __global__ void __launch_bounds__(kWave, 2) eval_long_kernel(LongEvalArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// L-BFGS minimisation, one item per wavefront, persistent wavefronts pulling (restart-major) queue positions
+// Quasi-Newton minimisation (the iteration of minimize_body / oracle/bfgs_port.py), one item per wavefront, persistent wavefronts
+// pulling (restart-major) queue positions.  Lane l holds components 2l and 2l + 1 of x, g, p; the fp32 inverse Hessian approximation
+// H (n rows of kLongHStride floats in device memory, this wavefront's slice) is read row by row as float2 per lane: since H is
+// symmetric, lane l's two COLUMNS give its two components of H v, and a row is one coalesced 8 n-byte access of the wavefront.
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int k = args.k;
     const int n = 6 * (k + 1);
-    float* Sh = reinterpret_cast<float*>(lds + kLongOffHist);
-    float* Yh = Sh + kLongHist * kLongNP;
-    double* rho = lds + kLongOffRho;  // (wave-uniform values, in LDS: indexed by the ring position at run time)
+    float* f32a = reinterpret_cast<float*>(lds + kLongOffF32);  // [NP] broadcast vector of the mat-vec: g'
+    float* f32b = f32a + kLongNP;                               // [NP] pending update: s
+    float* f32c = f32b + kLongNP;                               // [NP] pending update: v
+    float2* const Hm = reinterpret_cast<float2*>(args.hmem + (size_t)blockIdx.x * (size_t)n * kLongHStride) + lane;  // + j * 64: row j
     long_prologue(lds);
     const LongGateCols gcol = load_gate_cols(args.gates, k);
     const unsigned n_act = (unsigned)args.ctl->n_active;
@@ -444,9 +453,10 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
     bool valid[kLongSlots];
 #pragma unroll
     for (int s = 0; s < kLongSlots; ++s) {
-        const int i = lane + 64 * s;
+        const int i = 2 * lane + s;
         valid[s] = i < n && !(pin && (i < 6 || i >= 6 * k));
     }
+    const bool lane_in = 2 * lane < n;  // this lane holds components of the problem (n is even)
 
     while (true) {
         unsigned pos = 0;
@@ -473,20 +483,37 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
             tim[r] = t.y;
         }
         double x[kLongSlots], g[kLongSlots], p[kLongSlots];
+        {
+            // start point: explicit, or Philox block `lane` = the parameter pair (2 lane, 2 lane + 1) -- the numbers of oracle.x0_philox
+            double x0v[2] = {0.0, 0.0};
+            if (lane_in) {
+                if (args.x0) {
+                    x0v[0] = args.x0[(int64_t)item * n + 2 * lane];
+                    x0v[1] = args.x0[(int64_t)item * n + 2 * lane + 1];
+                } else {
+                    uint32_t w[4];
+                    philox4x32_10((uint32_t)lane, rs, (uint32_t)(tgt + (int)args.target_base), (uint32_t)k, (uint32_t)args.seed, (uint32_t)(args.seed >> 32), w);
+                    x0v[0] = x0_from_words(w[0], w[1]);
+                    x0v[1] = x0_from_words(w[2], w[3]);
+                }
+            }
 #pragma unroll
-        for (int s = 0; s < kLongSlots; ++s) {
-            const int i = lane + 64 * s;
-            double xv = 0.0;
-            if (valid[s]) xv = args.x0 ? args.x0[(int64_t)item * n + i] : x0_philox(args.seed, (uint32_t)(tgt + (int)args.target_base), rs, (uint32_t)k, (uint32_t)i);
-            x[s] = xv;
-            if (i < kLongNP) lds[kLongOffX + i] = xv;
+            for (int s = 0; s < kLongSlots; ++s) {
+                x[s] = valid[s] ? x0v[s] : 0.0;
+                lds[kLongOffX + 2 * lane + s] = x[s];
+            }
         }
         lds_fence();
         double f = eval_long<false>(lds, tre, tim, gcol, k, args.cost_kind, pin);
         ++rounds;
         int nev = 1, nacc = 0, iters = 0, nback = 0, nstall = 0, status = ST_MAXITER;
-        int cnt = 0, head = 0;  // history: cnt pairs, the newest at (head - 1) mod kLongHist
-        double gamma = 1.0, grow = 1.0;
+        bool ident = true, scaled = false;  // ident: H is the identity (nothing of it is in memory yet)
+        // The rank-2 update of an accepted step is applied by the NEXT step's mat-vec pass (one read + one write of the matrix per
+        // accepted step instead of two reads + one write: at 16 gates the passes are bound by the memory system): pend = an update is
+        // waiting; its s and v in LDS (f32b, f32c), this lane's components of w and s in registers
+        bool pend = false;
+        float pw0 = 0.0f, pw1 = 0.0f, ps0 = 0.0f, ps1 = 0.0f;
+        double hs1 = 0.0, grow = 1.0;       // the effective metric is H + hs1 I (the one-off scaling of the initial metric)
         double gnorm = 0.0, gp = 0.0, pp = 0.0, alpha = 0.0;
         bool done = false;
         if (!isfinite(f)) {
@@ -497,16 +524,19 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
             double gg = 0.0, gm = 0.0;
 #pragma unroll
             for (int s = 0; s < kLongSlots; ++s) {
-                const int i = lane + 64 * s;
-                g[s] = valid[s] ? lds[kLongOffG + i] : 0.0;
-                p[s] = -g[s];
-                gg = fma(g[s], g[s], gg);
+                g[s] = valid[s] ? lds[kLongOffG + 2 * lane + s] : 0.0;
+                // (the first direction is -H g with H = 1 in fp32, as in the quad kernels and the NumPy port)
+                p[s] = -(double)(float)g[s];
                 gm = max_abs(gm, g[s]);
             }
-            gg = wave_sum(gg);
+#pragma unroll
+            for (int s = 0; s < kLongSlots; ++s) gg = fma(g[s], p[s], gg);
+            gp = wave_sum(gg);
+            double d2 = 0.0;
+#pragma unroll
+            for (int s = 0; s < kLongSlots; ++s) d2 = fma(p[s], p[s], d2);
+            pp = wave_sum(d2);
             gnorm = wave_max_abs(gm);
-            gp = -gg;
-            pp = gg;
             alpha = (pp > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(pp)) : grow;
             if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) { status = ST_CONVERGED; done = true; }
             else if (args.maxiter <= 0) { status = ST_MAXITER; done = true; }
@@ -516,9 +546,8 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
             double xt[kLongSlots];
 #pragma unroll
             for (int s = 0; s < kLongSlots; ++s) {
-                const int i = lane + 64 * s;
                 xt[s] = fma(alpha, p[s], x[s]);
-                if (i < kLongNP) lds[kLongOffX + i] = xt[s];
+                lds[kLongOffX + 2 * lane + s] = xt[s];
             }
             lds_fence();
             const double ft = eval_long<false>(lds, tre, tim, gcol, k, args.cost_kind, pin);
@@ -528,12 +557,11 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
             const bool armijo = finite && (ft <= f + kArmijoC1 * alpha * gp);
             if (armijo) {
                 ++nacc;
-                double gt[kLongSlots];
+                double gt[kLongSlots], qv[kLongSlots];
                 double pgt = 0.0, yy = 0.0, gm = 0.0;
 #pragma unroll
                 for (int s = 0; s < kLongSlots; ++s) {
-                    const int i = lane + 64 * s;
-                    gt[s] = valid[s] ? lds[kLongOffG + i] : 0.0;
+                    gt[s] = valid[s] ? lds[kLongOffG + 2 * lane + s] : 0.0;
                     const double ya = gt[s] - g[s];
                     pgt = fma(p[s], gt[s], pgt);
                     yy = fma(ya, ya, yy);
@@ -541,24 +569,92 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
                 }
                 pgt = wave_sum(pgt);
                 yy = wave_sum(yy);
+                // ---- q = H g' (fp32), H = the matrix in memory (or the identity) + the pending update: one pass over the rows -- row j is
+                // read (float2 per lane: this lane's two columns), updated with s_j w + v_j s, written back, and multiplied by g'_j
+                if (ident && !pend) {
+#pragma unroll
+                    for (int s = 0; s < kLongSlots; ++s) qv[s] = (double)(float)gt[s];
+                } else {
+                    f32a[2 * lane] = (float)gt[0];
+                    f32a[2 * lane + 1] = (float)gt[1];
+                    lds_fence();
+                    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;  // two accumulator pairs: even / odd rows
+                    if (lane_in) {
+                        // kLongRowBatch rows requested before the first one is used: a row is one 8 n-byte access of the wavefront, and with
+                        // one or two in flight the pass ran at the memory's latency (45 us per iteration at 12 gates)
+                        for (int j0 = 0; j0 < n; j0 += kLongRowBatch) {
+                            float2 h[kLongRowBatch];
+#pragma unroll
+                            for (int u = 0; u < kLongRowBatch; ++u) {
+                                const int j = j0 + u;
+                                if (ident) h[u] = make_float2(j == 2 * lane ? 1.0f : 0.0f, j == 2 * lane + 1 ? 1.0f : 0.0f);
+                                else if (j < n) h[u] = Hm[(size_t)j * 64];
+                                else h[u] = make_float2(0.0f, 0.0f);
+                            }
+                            if (pend) {
+#pragma unroll
+                                for (int u = 0; u < kLongRowBatch; ++u) {
+                                    const int j = j0 + u;
+                                    const float sj = f32b[j], vj = f32c[j];
+                                    h[u].x = fmaf(vj, ps0, h[u].x); h[u].y = fmaf(vj, ps1, h[u].y);
+                                    h[u].x = fmaf(sj, pw0, h[u].x); h[u].y = fmaf(sj, pw1, h[u].y);
+                                    if (j < n) Hm[(size_t)j * 64] = h[u];
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < kLongRowBatch; u += 2) {
+                                const float g0 = f32a[j0 + u], g1 = f32a[j0 + u + 1];  // (rows beyond n: g' = 0 there; the vectors have kLongNP entries)
+                                a0 = fmaf(h[u].x, g0, a0); a1 = fmaf(h[u].y, g0, a1);
+                                b0 = fmaf(h[u + 1].x, g1, b0); b1 = fmaf(h[u + 1].y, g1, b1);
+                            }
+                        }
+                    }
+                    if (pend) ident = false;  // the matrix is in memory now
+                    pend = false;
+                    qv[0] = (double)(a0 + b0);
+                    qv[1] = (double)(a1 + b1);
+                    lds_fence();
+                }
+                const double sg = alpha * pgt;
                 const double sy = alpha * (pgt - gp);
                 const double ss = (alpha * alpha) * pp;
                 const bool too_short = sy < (1.0 - kWolfeC2) * alpha * (-gp);  // weak-Wolfe curvature condition violated
                 const bool curv = !too_short && sy > 0.0 && (sy * sy > (kCurvEps * kCurvEps) * (ss * yy));
-                if (curv) {
-                    // store the pair (s, y) = (alpha p, g' - g) as fp32 at the ring's head
+                const bool first = curv && !scaled;
+                scaled = scaled || curv;
+                // first update of an item: scale the initial metric (the identity) by s.y / y.y -- as the scalar hs1
+                const double fac = first ? (sy * fast_rcp(yy)) : 1.0;
+                hs1 = first ? fac - 1.0 : hs1;
+                double yu = 0.0;
 #pragma unroll
-                    for (int s = 0; s < kLongSlots; ++s) {
-                        const int i = lane + 64 * s;
-                        if (i < kLongNP) {
-                            Sh[head * kLongNP + i] = (float)(alpha * p[s]);
-                            Yh[head * kLongNP + i] = (float)(gt[s] - g[s]);
-                        }
-                    }
-                    if (lane == 0) rho[head] = fast_rcp(sy);
-                    head = (head + 1 == kLongHist) ? 0 : head + 1;
-                    cnt = cnt < kLongHist ? cnt + 1 : kLongHist;
-                    gamma = sy * fast_rcp(yy);
+                for (int s = 0; s < kLongSlots; ++s) {
+                    qv[s] = fma(hs1, gt[s], qv[s]);  // q = H_eff g'
+                    const double ua = fma(fac, p[s], qv[s]);  // u = H_eff y = q + fac p   (p = -H_eff g before this round's scaling)
+                    yu = fma(gt[s] - g[s], ua, yu);
+                }
+                yu = wave_sum(yu);
+                const double rho = curv ? fast_rcp(sy) : 0.0;
+                const double cf = rho * (1.0 + rho * yu);
+                double wg = 0.0;
+                double sa[kLongSlots], wa[kLongSlots], va[kLongSlots];
+#pragma unroll
+                for (int s = 0; s < kLongSlots; ++s) {
+                    sa[s] = alpha * p[s];
+                    const double ua = fma(fac, p[s], qv[s]);
+                    wa[s] = cf * sa[s] - rho * ua;
+                    va[s] = -rho * ua;
+                    wg = fma(wa[s], gt[s], wg);
+                }
+                wg = wave_sum(wg);
+                // ---- H += s w^T + v s^T (fp32; row j gets s_j w + v_j s): left pending for the next accepted step's pass
+                if (curv) {
+                    f32b[2 * lane] = (float)sa[0];
+                    f32b[2 * lane + 1] = (float)sa[1];
+                    f32c[2 * lane] = (float)va[0];
+                    f32c[2 * lane + 1] = (float)va[1];
+                    pw0 = (float)wa[0]; pw1 = (float)wa[1];
+                    ps0 = (float)sa[0]; ps1 = (float)sa[1];
+                    pend = true;
                     lds_fence();
                 }
                 nstall = (f - ft <= kStallDf) ? nstall + 1 : 0;
@@ -566,85 +662,39 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
                 ++iters;
                 nback = 0;
                 grow = too_short ? fmin(grow * kGrowFactor, kGrowMax) : 1.0;
+                double d1 = 0.0, d2 = 0.0;
 #pragma unroll
-                for (int s = 0; s < kLongSlots; ++s) { x[s] = xt[s]; g[s] = gt[s]; }
+                for (int s = 0; s < kLongSlots; ++s) {
+                    x[s] = xt[s];
+                    g[s] = gt[s];
+                    p[s] = -(qv[s] + sa[s] * wg + va[s] * sg);
+                    d1 = fma(g[s], p[s], d1);
+                    d2 = fma(p[s], p[s], d2);
+                }
                 gnorm = wave_max_abs(gm);
+                gp = wave_sum(d1);
+                pp = wave_sum(d2);
+                alpha = (pp > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(pp)) : grow;
                 if (f < args.stop_loss || gnorm < args.gtol || (gnorm < args.gtol_far && f > args.far_loss)) { status = ST_CONVERGED; done = true; }
                 else if (nstall >= 2) { status = ST_STALLED; done = true; }
                 else if (iters >= args.maxiter) { status = ST_MAXITER; done = true; }
-                if (!done) {
-                    if ((iters & (kRestartPeriod - 1)) == 0) cnt = 0;  // periodic restart of the metric
-                    // ---- two-loop recursion: r = H g
-                    double q[kLongSlots], al[kLongHist];
-#pragma unroll
-                    for (int s = 0; s < kLongSlots; ++s) q[s] = g[s];
-#pragma unroll
-                    for (int t = 0; t < kLongHist; ++t) {
-                        al[t] = 0.0;
-                        if (t < cnt) {
-                            int h = head - 1 - t;
-                            h = h < 0 ? h + kLongHist : h;
-                            double d = 0.0;
-                            const double rh = rho[h];
-                            double sv[kLongSlots], yv[kLongSlots];
-#pragma unroll
-                            for (int s = 0; s < kLongSlots; ++s) {
-                                const int i = lane + 64 * s;
-                                sv[s] = (i < kLongNP) ? (double)Sh[h * kLongNP + i] : 0.0;
-                                yv[s] = (i < kLongNP) ? (double)Yh[h * kLongNP + i] : 0.0;
-                                d = fma(sv[s], q[s], d);
-                            }
-                            d = wave_sum(d);
-                            al[t] = rh * d;
-#pragma unroll
-                            for (int s = 0; s < kLongSlots; ++s) q[s] = fma(-al[t], yv[s], q[s]);
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < kLongSlots; ++s) q[s] *= (cnt > 0 ? gamma : 1.0);
-#pragma unroll
-                    for (int t = kLongHist - 1; t >= 0; --t) {
-                        if (t < cnt) {
-                            int h = head - 1 - t;
-                            h = h < 0 ? h + kLongHist : h;
-                            double d = 0.0;
-                            const double rh = rho[h];
-                            double sv[kLongSlots];
-#pragma unroll
-                            for (int s = 0; s < kLongSlots; ++s) {
-                                const int i = lane + 64 * s;
-                                sv[s] = (i < kLongNP) ? (double)Sh[h * kLongNP + i] : 0.0;
-                                const double yv = (i < kLongNP) ? (double)Yh[h * kLongNP + i] : 0.0;
-                                d = fma(yv, q[s], d);
-                            }
-                            d = wave_sum(d);
-                            const double be = rh * d;
-#pragma unroll
-                            for (int s = 0; s < kLongSlots; ++s) q[s] = fma(al[t] - be, sv[s], q[s]);
-                        }
-                    }
-                    double d1 = 0.0, d2 = 0.0;
+                // not a descent direction (H lost positive definiteness numerically), or the periodic restart: steepest descent again
+                const bool periodic = !done && ((iters & (kRestartPeriod - 1)) == 0);
+                if (!done && (!(gp < 0.0) || periodic)) {
+                    ident = true;
+                    pend = false;
+                    hs1 = 0.0;
+                    scaled = periodic ? false : scaled;
+                    double gg = 0.0;
 #pragma unroll
                     for (int s = 0; s < kLongSlots; ++s) {
-                        p[s] = -q[s];
-                        d1 = fma(g[s], p[s], d1);
-                        d2 = fma(p[s], p[s], d2);
+                        p[s] = -g[s];
+                        gg = fma(g[s], g[s], gg);
                     }
-                    gp = wave_sum(d1);
-                    pp = wave_sum(d2);
-                    if (!(gp < 0.0)) {  // not a descent direction: steepest descent, the history starts over
-                        cnt = 0;
-                        double gg = 0.0;
-#pragma unroll
-                        for (int s = 0; s < kLongSlots; ++s) {
-                            p[s] = -g[s];
-                            gg = fma(g[s], g[s], gg);
-                        }
-                        gg = wave_sum(gg);
-                        gp = -gg;
-                        pp = gg;
-                    }
-                    alpha = (pp > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(pp)) : grow;
+                    gg = wave_sum(gg);
+                    gp = -gg;
+                    pp = gg;
+                    alpha = periodic ? ((gg > 1e-300) ? fmin(grow, kStepMax * fast_rsqrt(gg)) : grow) : alpha;
                 }
             } else {
                 // safeguarded quadratic interpolation backtrack
@@ -666,7 +716,7 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
         if (lane == 0) item_rec_store(args.item_rec + item, f, iters, status, nev, nacc);
 #pragma unroll
         for (int s = 0; s < kLongSlots; ++s) {
-            const int i = lane + 64 * s;
+            const int i = 2 * lane + s;
             if (i < n) args.item_x[(int64_t)item * n + i] = x[s];
         }
     }

@@ -225,3 +225,26 @@ class DeviceTargets:
     @staticmethod
     def get(seed, i):
         return o.haar_philox_port(seed, i)
+
+
+@pytest.mark.parametrize("k,gate", [(6, SQ), (7, WEAK)])
+def test_long_template_runs_follow_the_cpu_port(hip_ctx, k, gate):
+    """The wavefront-per-item kernels run the SAME quasi-Newton iteration as the quad kernels (fp32 metric, Armijo backtracking, cautious
+    update, scaling of the first metric, periodic restart): against oracle/bfgs_port.py item by item -- same converged loss, and, rounding
+    of the float32 metric aside, the same number of evaluations."""
+    from oracle.bfgs_port import minimize_port
+
+    n_t, R = 4, 3
+    T = o.haar_batch(n_t, seed0=1300 + k)
+    hip_ctx.set_targets(T)
+    hip_ctx.set_gates(gate[None])
+    out = hip_ctx.minimize_stage([0] * k, _ffi.OptParams(restarts=R, seed=21))
+    same = 0
+    for t in range(n_t):
+        for r in range(R):
+            f, x, it, st, nev = minimize_port(o.x0_philox(21, t, r, k), [gate] * k, T[t])
+            assert out["item_status"][t, r] in (0, 4) and st in (0, 4)
+            assert abs(out["item_loss"][t, r] - f) < 1e-6, (k, t, r, out["item_loss"][t, r], f)
+            same += int(out["item_evals"][t, r] == nev)
+            assert abs(int(out["item_evals"][t, r]) - nev) <= max(10, nev // 3), (k, t, r, out["item_evals"][t, r], nev)
+    assert same >= (n_t * R) // 3, same
