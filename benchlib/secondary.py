@@ -141,8 +141,8 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
             assert len(data) == n_targets and data[n_targets - 1].cycles in (2, 3)
     times.sort()
     med = times[(len(times) - 1) // 2]
-    # the same method on a sampler of FIVE windows (327 680 targets): successive 65 536-target windows on helper contexts, five in
-    # flight (TemplateOptimizer._run_batch_windows) -- the drop-in method at the rate of the bench's own batches in flight
+    # the same method on a sampler of 327 680 targets: contiguous shares on helper contexts, each run as successive windows of at most
+    # 65 536 targets (TemplateOptimizer._run_batch_windows) -- the drop-in method on the bench's own scheme of batches in flight
     big_n = 5 * n_targets
     btimes, bsolved = [], 0
     for r in range(reps + 1):
@@ -157,7 +157,7 @@ def run_api(local_rank: int, n_targets: int = 65536, restarts: int = 32, reps: i
     btimes.sort()
     bmed = btimes[(len(btimes) - 1) // 2]
     api_large = {"workload": f"TemplateOptimizer.approximate_from_distribution(DeviceHaarBatch(n_samples={big_n})), sqrt(iSWAP) span<=3, {restarts} restarts: "
-                             f"one call, {bopt.windows_in_flight} windows of {bopt.WINDOW_TARGETS} targets in flight",
+                             f"one call, {bopt.windows_in_flight} helper contexts in flight, windows of at most {bopt.WINDOW_TARGETS} targets",
                  "value": bsolved / bmed, "unit": "decompositions/s", "wall_ms": 1e3 * bmed, "wall_ms_all": [round(1e3 * t, 3) for t in btimes],
                  "solved_fraction": bsolved / big_n, "windows": len(bopt.last_stats_per_device)}
     del bdata, bloss

@@ -28,7 +28,7 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint64_t idx, 
     n1 = r * s;
 }
 
-__global__ void haar_targets_kernel(double* targets, int64_t first_index, int64_t n, uint64_t seed) {
+__global__ void __launch_bounds__(128) haar_targets_kernel(double* targets, int64_t first_index, int64_t n, uint64_t seed) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint64_t idx = (uint64_t)(first_index + t);

@@ -285,80 +285,81 @@ class TemplateOptimizer:
         return best_loss, best_x, best_cycles
 
     # ------------------------------------------------------------------------------------------
-    # A sampler larger than one window: SUCCESSIVE windows of WINDOW_TARGETS targets in flight on the one GPU, each on its own
-    # cached context (stream + stage buffers + host thread), as bench.py runs its batches.  What several calls in flight buy is
-    # the overlap of one window's stage tails, its k = 3 stage and its launch gaps with the next window's work (DESIGN.md 5.1);
-    # target shards of the SAME window do not get it (round 4, negative).  Seeds are keyed on the global target index and the
-    # ordered early exit makes a target's result independent of what runs beside it, so the result equals the single call's bit
-    # for bit.  Reference: the sequential loop over the sampler, optimizer.py:180-186.
+    # A sampler larger than one window: the targets are dealt in contiguous shares to windows_in_flight helpers -- cached contexts of
+    # the one GPU, each with its own stream, stage buffers and host thread -- and every helper runs its share as SUCCESSIVE windows of
+    # at most WINDOW_TARGETS targets, as bench.py runs its batches.  What several calls in flight buy is the overlap of one window's
+    # stage tails, its k = 3 stage and its launch gaps with the other helpers' work; target shards of ONE window do
+    # not get it (round 4, negative).  A helper's whole share is made resident before the first window starts: a generator launch
+    # behind running optimizer kernels waits for a free wave slot, i.e. for the end of a stage (measured: 20-27 ms, profiles/
+    # r5_api_timeline.txt), and a helper that starts late leaves a window to run alone at the end.  Seeds are keyed on the global
+    # target index and the ordered early exit makes a target's result independent of what runs beside it, so the result equals the
+    # single call's bit for bit.  Reference: the sequential loop over the sampler, optimizer.py:180-186.
     WINDOW_TARGETS = 65536
-    windows_in_flight = 4  # measured on 327 680 targets (tools/r5_api_large_probe.py): 2 / 3 / 4 / 5 in flight 112 / 107 / 81 / 88 ms
-
-    window_stagger = False
+    windows_in_flight = 4  # measured (tools/r5_api_large_probe.py): 327 680 targets 4 / 5 / 6 helpers 82.1 / 81.8 / 81.2 ms, 655 360: 156 / 167 / 160
+    window_stagger = False  # (measured: no gain, 81-83 ms either way; starting the helpers 2-9 ms apart: none either)
 
     def _window_plan(self, n: int):
-        """[(first, count)] of the windows of an n-target sampler: WINDOW_TARGETS each (the last one ragged).  ``window_stagger``: the
-        first windows_in_flight - 1 windows are 1/f, 2/f, ... of a window, so that the calls in flight reach their stage boundaries at
-        different times from the start (a finite job has no time to drift apart by itself)."""
-        W = int(self.WINDOW_TARGETS)
-        f = int(self.windows_in_flight)
-        sizes = []
-        left = n
-        if self.window_stagger and f > 1 and n > W:
-            for i in range(1, f):
-                c = min(left, max(1, (W * i) // f))
-                if c <= 0:
-                    break
-                sizes.append(c)
-                left -= c
-        while left > 0:
-            c = min(W, left)
-            sizes.append(c)
-            left -= c
-        plan, first = [], 0
-        for c in sizes:
-            plan.append((first, c))
-            first += c
+        """Per helper the list [(first, count)] of its windows: helper j owns the contiguous share j of the n targets (shares differ by
+        at most one target), cut into equal windows of at most WINDOW_TARGETS.  ``window_stagger``: a helper's first window is
+        (j + 1) / f of a window and its last one the rest, so that the helpers reach their stage boundaries at different times."""
+        W = max(1, int(self.WINDOW_TARGETS))
+        f = max(1, min(int(self.windows_in_flight), -(-n // W)))
+        plan, base = [], 0
+        for j in range(f):
+            T = n // f + (1 if j < n % f else 0)
+            units = max(1, -(-T // W))
+            sizes = [T // units + (1 if u < T % units else 0) for u in range(units)]
+            if self.window_stagger and f > 1 and T >= 2 * f:
+                a = max(1, (sizes[0] * (j + 1)) // f)
+                if a < sizes[0]:
+                    sizes = [a] + sizes[1:] + [sizes[0] - a]
+            wins, first = [], base
+            for c in sizes:
+                if c > 0:
+                    wins.append((first, c))
+                    first += c
+            plan.append(wins)
+            base += T
         return plan
 
     def _run_batch_windows(self, n, targets, ks, gate_seqs, prm):
         import threading
 
         plan = self._window_plan(n)
-        n_win = len(plan)
-        n_thr = min(int(self.windows_in_flight), n_win)
+        n_thr = len(plan)
         device = self.devices[0]
         flags = (prm.flags & ~_ffi.FLAG_OVERLAP) | _ffi.FLAG_NO_OVERLAP  # several calls in flight fill the chip by themselves
-        parts = [None] * n_win
-        stats = [None] * n_win
+        parts = [[None] * len(w) for w in plan]
+        stats = [[None] * len(w) for w in plan]
         errors = []
-        next_win = [0]
-        lock = threading.Lock()
+        resident = threading.Barrier(n_thr)
 
         def work(slot):
             try:
                 ctx = runtime.get_context(device, slot)
-                ctx.set_gates(self.basis.gate_matrices)
-                ctx.set_cost(self._cost_kind)
-                while True:
-                    with lock:
-                        w = next_win[0]
-                        next_win[0] += 1
-                    if w >= n_win or errors:
-                        return
-                    first, count = plan[w]
+                wins = plan[slot]
+                base = wins[0][0]
+                share = wins[-1][0] + wins[-1][1] - base
+                try:
+                    ctx.set_gates(self.basis.gate_matrices)
+                    ctx.set_cost(self._cost_kind)
                     if self._device_sampler is not None:
-                        self._device_sampler.fill(ctx, first, count)
+                        self._device_sampler.fill(ctx, base, share)
                     else:
-                        ctx.set_targets(targets[first : first + count])
+                        ctx.set_targets(targets[base : base + share])
+                finally:
+                    resident.wait()
+                sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
+                                    flags=flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
+                                    target_base=base)
+                for i, (first, count) in enumerate(wins):
+                    if errors:
+                        return
                     ctx.reset_stats()
-                    sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
-                                        flags=flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
-                                        target_base=first)
-                    out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
-                    sl = ctx.fetch_span_losses(0, count) if self._want_span_losses else None
-                    parts[w] = out + (sl,)
-                    stats[w] = ctx.stats()
+                    out = ctx.decompose_range(first - base, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
+                    sl = ctx.fetch_span_losses(first - base, count) if self._want_span_losses else None
+                    parts[slot][i] = out + (sl,)
+                    stats[slot][i] = ctx.stats()
             except Exception as exc:  # surfaced below
                 errors.append(exc)
 
@@ -369,10 +370,11 @@ class TemplateOptimizer:
             t.join()
         if errors:
             raise errors[0]
+        parts = [p for per in parts for p in per]  # in target order: shares are contiguous, windows ascending
         best_loss = np.concatenate([p[0] for p in parts])
         best_cycles = np.concatenate([p[2] for p in parts])
         self._span_losses = np.concatenate([p[3] for p in parts]) if self._want_span_losses else None
-        self._set_stats(stats)
+        self._set_stats([s for per in stats for s in per])
         # the parameter blocks stay per window (63 MB for 327 680 x 24 parameters would be copied once more): rows are looked up
         # through RowBlocks when an entry of target_data is built
         return best_loss, RowBlocks([p[1] for p in parts]), best_cycles

@@ -36,8 +36,8 @@ def _fold(c):
 # item 2: windows in flight
 # ------------------------------------------------------------------------------------------------------------------
 def test_windows_in_flight_equal_the_single_call():
-    """A sampler of several windows through ``approximate_from_distribution``: windows of WINDOW_TARGETS targets on helper contexts,
-    several in flight; ``target_data`` (lazy, per-window blocks) equals the single call's entry by entry, bit for bit -- seeds are
+    """A sampler of several windows through ``approximate_from_distribution``: contiguous shares on helper contexts, each run as
+    windows of at most WINDOW_TARGETS targets, several in flight; ``target_data`` (lazy, per-window blocks) equals the single call's entry by entry, bit for bit -- seeds are
     keyed on the global target index and the ordered early exit makes a target's result independent of its neighbours."""
     n, R = 5000, 8
     basis = CircuitTemplate(base_gates=[G.RiSwapGate(0.5)], maximum_span_guess=3)
@@ -49,17 +49,17 @@ def test_windows_in_flight_equal_the_single_call():
         return np.asarray(loss), data, optm
 
     l1, d1, o1 = run(1 << 30, 1)          # one call
-    l2, d2, o2 = run(1024, 4)             # five windows (the last one ragged), four in flight
-    l3, d3, o3 = run(1999, 2)             # three windows, ragged
+    l2, d2, o2 = run(1024, 4)             # four helpers, two windows of 625 each
+    l3, d3, o3 = run(1999, 3)             # three helpers with shares 1667 / 1667 / 1666, one window each
     assert np.array_equal(l1, l2) and np.array_equal(l1, l3)
     assert len(d2) == n and len(d3) == n
-    for i in list(range(0, n, 97)) + [1023, 1024, 1998, 1999, n - 1]:
+    for i in list(range(0, n, 97)) + [624, 625, 1249, 1250, 1666, 1667, 3333, 3334, n - 1]:
         for d in (d2, d3):
             assert d[i].cycles == d1[i].cycles and d[i].loss_result == d1[i].loss_result and d[i].success_label == d1[i].success_label
             assert np.array_equal(np.asarray(d[i].Xk), np.asarray(d1[i].Xk))
     assert o2.best_cycle_list == o1.best_cycle_list
     # stats are summed over the windows
-    assert o2.last_stats["evals"][1] == o1.last_stats["evals"][1] and len(o2.last_stats_per_device) == 5
+    assert o2.last_stats["evals"][1] == o1.last_stats["evals"][1] and len(o2.last_stats_per_device) == 8 and len(o3.last_stats_per_device) == 3
     assert np.all(l1 < 1e-10)
 
 

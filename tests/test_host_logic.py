@@ -396,3 +396,25 @@ def test_lazy_list_behaves_like_the_reference_lists():
     m.extend_array(np.arange(5.0, 8.0))
     assert np.array_equal(np.asarray(m), np.arange(8.0)) and m == LazyList(list(np.arange(8.0))) and m.tolist() == list(range(8))
     assert sum(1 for _ in m) == 8 and all(type(v) is float for v in m)
+
+
+@pytest.mark.parametrize("n,window,helpers,stagger", [(327680, 65536, 4, False), (327680, 65536, 5, False), (5000, 1024, 4, False), (5000, 1999, 3, False),
+                                                       (131073, 65536, 5, True), (65537, 65536, 4, True), (70000, 65536, 4, False), (7, 2, 4, True)])
+def test_window_plan_tiles_the_sampler_in_contiguous_helper_shares(n, window, helpers, stagger):
+    """``TemplateOptimizer._window_plan``: every helper owns ONE contiguous share (it is made resident before the first window starts), the
+    shares differ by at most one target, windows are at most WINDOW_TARGETS, and together they tile [0, n) in order."""
+    from slam_decomposition_amd.optimizer import TemplateOptimizer
+
+    class Knobs:
+        WINDOW_TARGETS, windows_in_flight, window_stagger = window, helpers, stagger
+
+    plan = TemplateOptimizer._window_plan(Knobs(), n)
+    assert 1 <= len(plan) <= helpers and len(plan) <= -(-n // window)
+    flat = [w for wins in plan for w in wins]
+    assert flat[0][0] == 0 and flat[-1][0] + flat[-1][1] == n
+    assert all(a[0] + a[1] == b[0] for a, b in zip(flat, flat[1:]))
+    assert all(0 < c <= window for _, c in flat)
+    shares = [sum(c for _, c in wins) for wins in plan]
+    assert max(shares) - min(shares) <= 1
+    if stagger and len(plan) > 1 and min(shares) >= 2 * len(plan):
+        assert len({wins[0][1] for wins in plan}) > 1  # first windows of different sizes
