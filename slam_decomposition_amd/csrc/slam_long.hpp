@@ -233,7 +233,7 @@ __device__ __forceinline__ double eval_long(double* lds, const double (&tre)[4],
         const int j = quad;
         const int top = L < 16 ? L : 16;  // layers of pass 0
 #pragma unroll 1
-        for (int s = 1; s < 16; s <<= 1) {
+        for (int s = 1; s < top; s <<= 1) {  // (three levels up to 8 layers, four beyond)
             const bool dp = j < top && j >= s;
             const bool dq = j + s < top;
             double pr[4], pi[4], qr[4], qi[4];
