@@ -11,6 +11,7 @@ from slam_decomposition_amd.optimizer import TemplateOptimizer
 from slam_decomposition_amd.sampler import DeviceHaarBatch
 
 N = 327680
+FL = [int(a) for a in sys.argv[1:]] or [4]  # helpers per repetition, cycled
 basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
 log = []
 t0 = [0.0]
@@ -45,12 +46,12 @@ def fill(self, ctx, first, count):
 DeviceHaarBatch.fill = fill
 for fetch in (True,):
     mode["fetch"] = fetch
-    for r in range(6):
+    for r in range(13):
         log.clear(); fills.clear()
-        opt = TemplateOptimizer(basis, BasicCost(), training_restarts=32, seed=20261003, override_fail=True)
+        opt = TemplateOptimizer(basis, BasicCost(), training_restarts=32, seed=20261003, override_fail=True, windows_in_flight=FL[r % len(FL)])
         t0[0] = time.perf_counter()
         loss, _, data = opt.approximate_from_distribution(DeviceHaarBatch(seed=20260000 + 9_500_000 + r, n_samples=N))
         dt = time.perf_counter() - t0[0]
         time.sleep(0.01)
         if r:
-            print(f"fetch {fetch}: total {1e3 * dt:.2f} ms; run_batch_windows {marks}; fills {sorted(fills)}; windows (base, decompose start, end): {sorted(log)}", flush=True)
+            print(f"helpers {FL[r % len(FL)]} fetch {fetch}: total {1e3 * dt:.2f} ms; run_batch_windows {marks}; fills {sorted(fills)}; windows (base, decompose start, end): {sorted(log)}", flush=True)
