@@ -336,19 +336,21 @@ class TemplateOptimizer:
 
         def work(slot):
             try:
-                ctx = runtime.get_context(device, slot)
                 wins = plan[slot]
                 base = wins[0][0]
                 share = wins[-1][0] + wins[-1][1] - base
                 try:
+                    ctx = runtime.get_context(device, slot)
                     ctx.set_gates(self.basis.gate_matrices)
                     ctx.set_cost(self._cost_kind)
                     if self._device_sampler is not None:
                         self._device_sampler.fill(ctx, base, share)
                     else:
                         ctx.set_targets(targets[base : base + share])
-                finally:
-                    resident.wait()
+                except Exception:
+                    resident.abort()  # the other helpers must not wait for this one
+                    raise
+                resident.wait()
                 sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
                                     flags=flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
                                     target_base=base)
@@ -360,6 +362,8 @@ class TemplateOptimizer:
                     sl = ctx.fetch_span_losses(first - base, count) if self._want_span_losses else None
                     parts[slot][i] = out + (sl,)
                     stats[slot][i] = ctx.stats()
+            except threading.BrokenBarrierError:
+                pass  # another helper failed while making its share resident: its exception is the one to surface
             except Exception as exc:  # surfaced below
                 errors.append(exc)
 

@@ -418,3 +418,77 @@ def test_window_plan_tiles_the_sampler_in_contiguous_helper_shares(n, window, he
     assert max(shares) - min(shares) <= 1
     if stagger and len(plan) > 1 and min(shares) >= 2 * len(plan):
         assert len({wins[0][1] for wins in plan}) > 1  # first windows of different sizes
+
+
+class _FakeWindowCtx:
+    """Stands in for a helper context of ``_run_batch_windows``: 'decomposes' a window into its GLOBAL target indices."""
+
+    def __init__(self, slot, fail_slot=None):
+        self.slot, self.fail_slot, self.n = slot, fail_slot, 0
+
+    def set_gates(self, g):
+        if self.slot == self.fail_slot:
+            raise RuntimeError("helper %d cannot come up" % self.slot)
+
+    def set_cost(self, kind):
+        pass
+
+    def set_targets(self, t):
+        self.n = len(t)
+        self.first_value = float(np.real(t[0, 0, 0]))
+
+    def reset_stats(self):
+        pass
+
+    def stats(self):
+        return {"evals": [0, 1, 0, 0], "total_ms": 1.0}
+
+    def decompose_range(self, first, count, k_min, k_max, gate_seqs, params, thr):
+        assert 0 <= first and first + count <= self.n and params.target_base == int(self.first_value)
+        idx = params.target_base + first + np.arange(count)
+        return idx.astype(np.float64), np.repeat(idx[:, None], 6 * (k_max + 1), axis=1).astype(np.float64), np.full(count, k_max, dtype=np.int32)
+
+
+@pytest.mark.parametrize("n,window,helpers", [(1000, 128, 4), (1001, 300, 3), (257, 256, 4)])
+def test_windowed_path_puts_the_windows_back_in_target_order(monkeypatch, n, window, helpers):
+    """``TemplateOptimizer._run_batch_windows`` with stand-in contexts: every helper makes its contiguous share resident, runs its windows
+    with ``target_base`` = the share's first target, and the results come back in target order (losses, cycles, parameter blocks)."""
+    from slam_decomposition_amd import optimizer as O, runtime
+
+    monkeypatch.setattr(runtime, "get_context", lambda device, slot=0: _FakeWindowCtx(slot))
+    opt = O.TemplateOptimizer(CircuitTemplate(base_gates=[CXGate()], maximum_span_guess=3), BasicCost(), training_restarts=4, seed=1, windows_in_flight=helpers)
+    opt.WINDOW_TARGETS = window
+    opt._want_span_losses = False
+    targets = np.zeros((n, 4, 4), dtype=np.complex128)
+    targets[:, 0, 0] = np.arange(n)  # a target "is" its index
+    loss, xs, cycles = opt._run_batch_windows(n, targets, [1, 2, 3], [[0], [0, 0], [0, 0, 0]], opt._opt_params())
+    assert np.array_equal(loss, np.arange(n)) and np.all(cycles == 3)
+    assert all(xs[i][0] == i for i in (0, 1, n // 2, n - 1))
+    assert len(opt.last_stats_per_device) == sum(len(w) for w in opt._window_plan(n)) and opt.last_stats["evals"][1] == len(opt.last_stats_per_device)
+
+
+def test_windowed_path_surfaces_a_failing_helper_without_hanging(monkeypatch):
+    """A helper that fails while making its share resident aborts the barrier the others wait at; its exception is the one raised."""
+    import threading
+
+    from slam_decomposition_amd import optimizer as O, runtime
+
+    monkeypatch.setattr(runtime, "get_context", lambda device, slot=0: _FakeWindowCtx(slot, fail_slot=2))
+    opt = O.TemplateOptimizer(CircuitTemplate(base_gates=[CXGate()], maximum_span_guess=3), BasicCost(), training_restarts=4, seed=1, windows_in_flight=4)
+    opt.WINDOW_TARGETS = 64
+    opt._want_span_losses = False
+    targets = np.zeros((600, 4, 4), dtype=np.complex128)
+    targets[:, 0, 0] = np.arange(600)
+    result = {}
+
+    def call():
+        try:
+            opt._run_batch_windows(600, targets, [1, 2, 3], [[0], [0, 0], [0, 0, 0]], opt._opt_params())
+        except Exception as exc:
+            result["exc"] = exc
+
+    t = threading.Thread(target=call, daemon=True)
+    t.start()
+    t.join(timeout=20)
+    assert not t.is_alive(), "the helpers deadlocked at the barrier"
+    assert isinstance(result.get("exc"), RuntimeError) and "helper 2" in str(result["exc"])
