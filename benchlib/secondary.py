@@ -10,7 +10,7 @@ import numpy as np
 from .workloads import OPT_SEED, PEAK_FP64_VALU_TFLOPS, SUCCESS_LOSS, TARGET_SEED0, f_eval, f_eval_v2, gate_table
 
 
-def run_v2(rank: int, local_rank: int, steps: int = 512, warmup: int = 32, n_targets: int = 4096, restarts: int = 16, n_streams: int = 8, group: int = 32,
+def run_v2(rank: int, local_rank: int, steps: int = 1024, warmup: int = 32, n_targets: int = 4096, restarts: int = 16, n_streams: int = 8, group: int = 32,
            base_gate=None, gate_desc: str = "RiSwapGate"):
     """secondary.v2: CircuitTemplateV2(base_gates=[RiSwapGate]) -- every gate instance with its own free alpha -- SquareCost,
     spans 1..3, `n_targets` Haar targets x `restarts` restarts per step.  The span loop is the one TemplateOptimizer runs for a
@@ -20,7 +20,8 @@ def run_v2(rank: int, local_rank: int, steps: int = 512, warmup: int = 32, n_tar
     contexts / streams (measured, MI355X: one step per call 2.5e6 decompositions/s / 0.19 of peak, 8 per call 6.4e6 / 0.31; round 4,
     tools/r4_v2_sweep.sh: 64 steps at 8 per call x 4 in flight 6.2e6 / 0.31, 128 steps at 16 x 4 7.6e6 / 0.36, 8 x 8
     6.8e6 / 0.33, 32 x 2 7.3e6 / 0.34, 256 steps at 32 x 4 7.7e6 / 0.345; tools/r4_v2_sweep2.sh: 512 steps at 16 x 8 8.1e6 / 0.37, at 32 x 8
-    8.3e6 / 0.37 (the default now: a 0.25 s region with eight calls per stream instead of two))."""
+    8.3e6 / 0.37 (a 0.25 s region with eight calls per stream instead of two); round 5, tools/r5_v2_shapes.sh, one box: 512 steps 0.347-0.357,
+    1024 steps (the default now: four calls per stream, a 0.5 s region) 0.372; 64 per call x 8 0.353, 32 x 12 0.359, 2048 steps at 64 x 8 0.347)."""
     from slam_decomposition_amd import _ffi
     from slam_decomposition_amd.basisv2 import CircuitTemplateV2
     from slam_decomposition_amd.gates import RiSwapGate

@@ -356,6 +356,17 @@ int slam_set_cost(slam_ctx* ctx, int cost);
 /* Block until all work queued on the context's stream has finished. */
 int slam_synchronize(slam_ctx* ctx);
 
+/* Page-locked host memory for result arrays (round 5).  The fetch entry points (slam_decompose_range_fetch, slam_fetch_results_range,
+ * slam_v2_decompose_range ...) copy straight into the caller's arrays; when those are ordinary pageable memory the runtime pins and
+ * unpins them around every copy, and FREEING such arrays later (munmap / heap trimming of tens of MB) was measured to stall every queue
+ * of the process for 13-18 ms at the start of the next call (profiles/r5_api_timeline.txt).  Arrays from slam_host_alloc are visible to
+ * every device, are copied into by DMA without staging, and are meant to be recycled by the caller (the Python binding keeps a pool).
+ * Use them for ONE blocking call at a time (18.2 -> 16.9 ms for 65 536 x 32 sqrt(iSWAP) through the Python API); with several calls in
+ * flight the device-side copy waits for wave slots behind the other calls' kernels and pageable arrays are faster (14.4 vs 14.9 ms per step).
+ * Replaces nothing in the reference (its results are Python lists built on the host, src/slam/optimizer.py:113-119). */
+int slam_host_alloc(size_t bytes, void** ptr);
+int slam_host_free(void* ptr);
+
 /* Accumulated kernel statistics since the last reset. */
 int slam_get_stats(slam_ctx* ctx, slam_stats* out);
 int slam_reset_stats(slam_ctx* ctx);
@@ -496,9 +507,10 @@ const char* slam_version(void);
  *      header must check the revision before calling);
  *   5  round 4: slam_decompose_multi, slam_predict_spans, 32-byte item records;
  *   6  round 5: SLAM_MAX_SPAN_EVAL / SLAM_MAX_SPAN_MINIMIZE 5 -> 16 -- the per-span arrays of slam_stats and the rows of
- *      slam_fetch_span_losses grow with them --, SLAM_FLAG_NO_EXTERIOR, kernel_ms_span[0].
+ *      slam_fetch_span_losses grow with them --, SLAM_FLAG_NO_EXTERIOR, kernel_ms_span[0];
+ *   7  round 5: slam_host_alloc / slam_host_free (new symbols only).
  * The Python binding refuses a library whose revision differs from the one it was written for. */
-#define SLAM_ABI_VERSION 6
+#define SLAM_ABI_VERSION 7
 int slam_abi_version(void);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLAM_HIP_LIB selects another build of the same library (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslamhip.so")
 
-ABI_VERSION = 6  # include/slam_hip.h: SLAM_ABI_VERSION
+ABI_VERSION = 7  # include/slam_hip.h: SLAM_ABI_VERSION
 MAX_SPAN_QUAD = 5  # SLAM_MAX_SPAN_QUAD: the register-resident kernels (and per-iteration traces)
 MAX_SPAN_EVAL = 16
 MAX_SPAN_MINIMIZE = 16
@@ -73,6 +73,8 @@ EXPORTED_SYMBOLS = (
     "slam_v2_decompose_range",
     "slam_set_cost",
     "slam_synchronize",
+    "slam_host_alloc",
+    "slam_host_free",
     "slam_get_stats",
     "slam_reset_stats",
     "slam_best_loss_device_ptr",
@@ -210,6 +212,9 @@ def load_library() -> C.CDLL:
             lib.slam_v2_minimize_stage_trace.argtypes = [P, C.c_int, P, P, C.c_int64, P, P, P, P, P, C.POINTER(OptParams), C.c_double, C.c_int32] + [P] * 8
     lib.slam_set_cost.argtypes = [P, C.c_int]
     lib.slam_synchronize.argtypes = [P]
+    if hasattr(lib, "slam_host_alloc"):
+        lib.slam_host_alloc.argtypes = [C.c_size_t, C.POINTER(P)]
+        lib.slam_host_free.argtypes = [P]
     lib.slam_get_stats.argtypes = [P, C.POINTER(Stats)]
     lib.slam_reset_stats.argtypes = [P]
     lib.slam_best_loss_device_ptr.argtypes = [P, C.POINTER(P), C.POINTER(C.c_int64)]
@@ -243,6 +248,80 @@ def _check(rc: int) -> None:
 
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------------
+# Result arrays in page-locked memory, recycled (slam_host_alloc, include/slam_hip.h): a result array of a big window (12.6 MB for
+# 65 536 x 24 parameters) is a view of a pinned block that goes back to the pool when the last view of it dies -- the device copies
+# into it by DMA, and the call's results are never handed back to the C allocator (measured: freeing 12.6 MB arrays that the runtime
+# had pinned around a copy stalled the next call's first launches for 13-18 ms).  For ONE blocking call alone on the device
+# (``pinned=True``; TemplateOptimizer's single-call path): 18.2 -> 16.9 ms for 65 536 x 32 sqrt(iSWAP).  NOT for several calls in
+# flight: the copy into pinned memory is a device-side copy that needs wave slots behind the other calls' persistent kernels, while
+# the pageable path's staging runs on the calling host thread beside them (profiles/r5_pinned_results_ab.txt: the driver's command 14.4 -> 14.9 ms
+# per step, 327 680 targets through the API 79 -> 82 ms with everything pinned).
+# ------------------------------------------------------------------------------------------------
+class _PinnedBlock:
+    __slots__ = ("ptr", "cap", "_pool", "__weakref__")
+
+    def __init__(self, pool, ptr, cap):
+        self.ptr, self.cap, self._pool = ptr, cap, pool
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (self.cap,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self._pool._release(self.ptr, self.cap)
+        except Exception:  # (interpreter shutdown)
+            pass
+
+
+class PinnedPool:
+    MIN_BYTES = 1 << 18           # smaller arrays stay ordinary NumPy arrays (the library stages small fetches itself)
+    GRANULE = 1 << 20
+    MAX_IDLE_BYTES = 2 << 30      # idle blocks beyond this go back to the driver
+
+    def __init__(self):
+        import threading
+
+        self._lock = threading.Lock()
+        self._free = {}
+        self._idle = 0
+        self.allocated = 0        # blocks obtained from the driver so far (tests / diagnostics)
+
+    def empty(self, shape, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        lib = load_library()
+        if nbytes < self.MIN_BYTES or not hasattr(lib, "slam_host_alloc"):
+            return np.empty(shape, dtype=dtype)
+        cap = -(-nbytes // self.GRANULE) * self.GRANULE
+        ptr = None
+        with self._lock:
+            lst = self._free.get(cap)
+            if lst:
+                ptr = lst.pop()
+                self._idle -= cap
+        if ptr is None:
+            out = C.c_void_p()
+            if lib.slam_host_alloc(cap, C.byref(out)) != 0 or not out.value:
+                return np.empty(shape, dtype=dtype)  # (no page-locked memory left: pageable results are slower, not wrong)
+            ptr = int(out.value)
+            self.allocated += 1
+        block = _PinnedBlock(self, ptr, cap)
+        return np.asarray(block)[:nbytes].view(dtype).reshape(shape)
+
+    def _release(self, ptr, cap):
+        with self._lock:
+            if self._idle + cap <= self.MAX_IDLE_BYTES:
+                self._free.setdefault(cap, []).append(ptr)
+                self._idle += cap
+                return
+        load_library().slam_host_free(C.c_void_p(ptr))
+
+
+result_pool = PinnedPool()
 
 
 def _mat_to_ri(mats: np.ndarray) -> np.ndarray:
@@ -473,15 +552,16 @@ class Context:
         _check(self._lib.slam_fetch_results(self._h, k_max, _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
         return best_loss, best_x, best_cycles
 
-    def decompose_range(self, first, count, k_min, k_max, gate_seqs, params: OptParams, success_threshold: float, fetch=True):
+    def decompose_range(self, first, count, k_min, k_max, gate_seqs, params: OptParams, success_threshold: float, fetch=True, pinned=False):
         flat = self._flat_gate_seqs(gate_seqs, k_min, k_max)
         if not fetch or not hasattr(self._lib, "slam_decompose_range_fetch"):
             _check(self._lib.slam_decompose_range(self._h, int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params), float(success_threshold)))
-            return self.fetch_results_range(k_max, first, count) if fetch else None
+            return self.fetch_results_range(k_max, first, count, pinned=pinned) if fetch else None
         nmax = 6 * (k_max + 1)
-        best_loss = np.empty(count, dtype=np.float64)
-        best_x = np.zeros((count, nmax), dtype=np.float64)
-        best_cycles = np.empty(count, dtype=np.int32)
+        new = result_pool.empty if pinned else (lambda shape, dtype: np.empty(shape, dtype=dtype))
+        best_loss = new(count, np.float64)
+        best_x = new((count, nmax), np.float64)  # (every row is written: the resident rows are zero-padded)
+        best_cycles = new(count, np.int32)
         _check(self._lib.slam_decompose_range_fetch(self._h, int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params),
                                                      float(success_threshold), _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
         return best_loss, best_x, best_cycles
@@ -515,11 +595,12 @@ class Context:
                                                   _ptr(flat), C.byref(params), float(success_threshold), C.byref(n_loc), C.byref(n_unr)))
         return int(n_loc.value), int(n_unr.value)
 
-    def fetch_results_range(self, k_max: int, first: int, count: int):
+    def fetch_results_range(self, k_max: int, first: int, count: int, pinned: bool = False):
         nmax = 6 * (k_max + 1)
-        best_loss = np.empty(count, dtype=np.float64)
-        best_x = np.zeros((count, nmax), dtype=np.float64)
-        best_cycles = np.empty(count, dtype=np.int32)
+        new = result_pool.empty if pinned else (lambda shape, dtype: np.empty(shape, dtype=dtype))
+        best_loss = new(count, np.float64)
+        best_x = new((count, nmax), np.float64)
+        best_cycles = new(count, np.int32)
         _check(self._lib.slam_fetch_results_range(self._h, k_max, int(first), int(count), _ptr(best_loss), _ptr(best_x), _ptr(best_cycles)))
         return best_loss, best_x, best_cycles
 

@@ -1982,6 +1982,20 @@ int slam_synchronize(slam_ctx* ctx) {
     return SLAM_OK;
 }
 
+int slam_host_alloc(size_t bytes, void** ptr) {
+    if (!ptr) return fail(SLAM_ERR_INVALID, "ptr is NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return fail(SLAM_ERR_INVALID, "bytes == 0");
+    HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocPortable));
+    return SLAM_OK;
+}
+
+int slam_host_free(void* ptr) {
+    if (!ptr) return SLAM_OK;
+    HIP_TRY(hipHostFree(ptr));
+    return SLAM_OK;
+}
+
 int slam_get_stats(slam_ctx* ctx, slam_stats* out) {
     if (!ctx || !out) return fail(SLAM_ERR_INVALID, "NULL argument");
     *out = ctx->stats;

@@ -244,7 +244,8 @@ class TemplateOptimizer:
                 sp = _ffi.OptParams(restarts=prm.restarts, maxiter=prm.maxiter, gtol=prm.gtol, stop_loss=prm.stop_loss, seed=prm.seed,
                                     flags=flags, gtol_far=prm.gtol_far, far_loss=prm.far_loss, items_per_quad=prm.items_per_quad,
                                     target_base=first)
-                out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold)
+                # (one blocking call alone on the device: results into recycled page-locked blocks, _ffi.result_pool)
+                out = ctx.decompose_range(0, count, ks[0], ks[-1], gate_seqs, sp, self.success_threshold, pinned=single)
                 # the running best loss per span feeds the "Cycle (k =...)" log lines only (optimizer.py:297)
                 sl = ctx.fetch_span_losses(0, count) if self._want_span_losses else None
                 return out + (sl,), ctx.stats()

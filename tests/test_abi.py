@@ -44,7 +44,7 @@ def test_version_and_struct_layout():
     w = _ffi.MAX_SPAN_EVAL + 1  # per-span arrays: index k = 0 .. SLAM_MAX_SPAN_EVAL (ABI 6: 16)
     assert _ffi.MAX_SPAN_EVAL == 16 and _ffi.MAX_SPAN_MINIMIZE == 16 and _ffi.MAX_SPAN_QUAD == 5
     assert ctypes.sizeof(_ffi.Stats) == 8 + 8 + w * 8 + w * 8 + 8 + w * 8 + w * 8 + w * 8 + w * 8
-    assert lib.slam_abi_version() == _ffi.ABI_VERSION == 6
+    assert lib.slam_abi_version() == _ffi.ABI_VERSION == 7
 
 
 def test_no_gpu_fails_loudly():
@@ -77,3 +77,55 @@ def test_product_package_does_not_import_the_oracle():
         "assert 'torch' not in sys.modules, 'torch imported'"
     )
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_result_pool_falls_back_to_pageable_arrays_without_a_gpu_and_recycles_blocks():
+    """``_ffi.PinnedPool``: small arrays are ordinary NumPy arrays; big ones come from slam_host_alloc, and where that fails (no GPU
+    here) the pool hands out pageable arrays instead of failing (slower, not wrong).  Recycling is exercised with a stand-in allocator."""
+    import ctypes as C
+
+    import numpy as np
+
+    pool = _ffi.PinnedPool()
+    a = pool.empty((10, 3), np.float64)
+    assert a.shape == (10, 3) and a.dtype == np.float64 and a.base is None
+    b = pool.empty((1 << 16, 24), np.float64)  # 12.6 MB: asks the library, which has no device here
+    assert b.shape == (1 << 16, 24) and b.flags["C_CONTIGUOUS"] and b.flags["WRITEABLE"]
+    b[:] = 1.0
+
+    class FakeLib:
+        def __init__(self):
+            self.bufs, self.freed = {}, []
+
+        def slam_host_alloc(self, n, out):
+            buf = C.create_string_buffer(n)
+            self.bufs[C.addressof(buf)] = buf
+            C.cast(out, C.POINTER(C.c_void_p))[0] = C.addressof(buf)
+            return 0
+
+        def slam_host_free(self, p):
+            self.freed.append(p.value)
+            return 0
+
+    fake = FakeLib()
+    orig = _ffi.load_library
+    _ffi.load_library = lambda: fake
+    try:
+        pool = _ffi.PinnedPool()
+        x = pool.empty((1 << 15, 24), np.float64)
+        x[:] = 3.0
+        view = x[5:7]
+        addr = x.ctypes.data
+        del x
+        assert pool.allocated == 1 and pool._idle == 0 and float(view[0, 0]) == 3.0  # a view keeps the block out of the pool
+        del view
+        assert pool._idle > 0
+        y = pool.empty((1 << 15, 24), np.float64)
+        assert y.ctypes.data == addr and pool.allocated == 1  # the same block again
+        z = pool.empty(1 << 20, np.int32)
+        assert pool.allocated == 2 and z.dtype == np.int32 and z.shape == (1 << 20,)
+        pool.MAX_IDLE_BYTES = 0
+        del y, z
+        assert len(fake.freed) == 2  # beyond the idle cap blocks go back to the driver
+    finally:
+        _ffi.load_library = orig

@@ -389,3 +389,39 @@ def test_v2_template_with_polytopes_runs_at_the_predicted_size():
         weak.add_bound(name, max=0.25, min=0.25)
     with pytest.raises(ValueError, match="Monodromy did not find"):
         weak.get_spanning_range(G.SwapGate().to_matrix())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# result arrays of big windows: page-locked blocks, recycled (slam_host_alloc / _ffi.result_pool)
+# ------------------------------------------------------------------------------------------------------------------
+def test_big_result_arrays_come_from_the_pinned_pool_and_are_recycled():
+    """``pinned=True`` (what TemplateOptimizer passes for one blocking call alone on the device): the fetch of a big window writes into
+    page-locked blocks of ``_ffi.result_pool`` (DMA, no staging; nothing handed back to the C allocator between calls); the values are those of a second fetch of the resident results; a block goes back to the pool when the last
+    view of it dies and is handed out again."""
+    ctx = _ffi.Context(0)
+    try:
+        n = 20000
+        ctx.sample_haar(991, n)
+        ctx.set_gates(np.stack([SQ]))
+        ctx.set_cost(0)
+        prm = _ffi.OptParams(restarts=6, seed=3, flags=_ffi.FLAG_EARLY_EXIT | _ffi.FLAG_ORDERED)
+        seqs = [[0], [0, 0], [0, 0, 0]]
+        before = _ffi.result_pool.allocated
+        loss, x, cyc = ctx.decompose_range(0, n, 1, 3, seqs, prm, 1e-10, pinned=True)
+        assert x.shape == (n, 24) and x.base is not None and _ffi.result_pool.allocated > before  # 3.8 MB: from the pool
+        assert loss.base is None or loss.nbytes >= _ffi.PinnedPool.MIN_BYTES
+        l2, x2, c2 = ctx.fetch_results_range(3, 0, n)  # pageable arrays
+        assert x2.base is None and np.array_equal(loss, l2) and np.array_equal(x, x2) and np.array_equal(cyc, c2)
+        assert np.mean(loss < 1e-8) > 0.99
+        assert np.all(x[cyc == 2][:, 18:] == 0.0)  # rows are zero-padded behind 6 (cycles + 1) parameters
+        addr, row = x.ctypes.data, x[7].copy()
+        keep = x[7:8]
+        del x
+        l3, x3, c3 = ctx.fetch_results_range(3, 0, n, pinned=True)
+        assert x3.ctypes.data != addr and np.array_equal(keep[0], row)  # the block is still out: a view is alive
+        del keep
+        count = _ffi.result_pool.allocated
+        l4, x4, c4 = ctx.fetch_results_range(3, 0, n, pinned=True)
+        assert _ffi.result_pool.allocated == count and np.array_equal(x4, x2)  # served from the pool's idle blocks
+    finally:
+        ctx.close()

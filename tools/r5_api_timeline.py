@@ -11,7 +11,9 @@ from slam_decomposition_amd.optimizer import TemplateOptimizer
 from slam_decomposition_amd.sampler import DeviceHaarBatch
 
 N = 327680
-FL = [int(a) for a in sys.argv[1:]] or [4]  # helpers per repetition, cycled
+FL = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4]  # helpers per repetition, cycled
+KEEP = "keep" in sys.argv  # hold on to every call's results (nothing is freed between the calls)
+kept = []
 basis = CircuitTemplate(base_gates=[RiSwapGate(0.5)], maximum_span_guess=3)
 log = []
 t0 = [0.0]
@@ -46,12 +48,14 @@ def fill(self, ctx, first, count):
 DeviceHaarBatch.fill = fill
 for fetch in (True,):
     mode["fetch"] = fetch
-    for r in range(13):
+    for r in range(25):
         log.clear(); fills.clear()
         opt = TemplateOptimizer(basis, BasicCost(), training_restarts=32, seed=20261003, override_fail=True, windows_in_flight=FL[r % len(FL)])
         t0[0] = time.perf_counter()
         loss, _, data = opt.approximate_from_distribution(DeviceHaarBatch(seed=20260000 + 9_500_000 + r, n_samples=N))
         dt = time.perf_counter() - t0[0]
+        if KEEP:
+            kept.append((loss, data, opt))
         time.sleep(0.01)
         if r:
-            print(f"helpers {FL[r % len(FL)]} fetch {fetch}: total {1e3 * dt:.2f} ms; run_batch_windows {marks}; fills {sorted(fills)}; windows (base, decompose start, end): {sorted(log)}", flush=True)
+            print(f"helpers {FL[r % len(FL)]} keep {KEEP}: total {1e3 * dt:.2f} ms; fills done at {max(f[2] for f in fills):.2f}; last window ends {max(l[2] for l in log):.2f}", flush=True)
