@@ -258,13 +258,15 @@ def _ptr(a: Optional[np.ndarray]):
 # (``pinned=True``; TemplateOptimizer's single-call path): 18.2 -> 16.9 ms for 65 536 x 32 sqrt(iSWAP).  NOT for several calls in
 # flight: the copy into pinned memory is a device-side copy that needs wave slots behind the other calls' persistent kernels, while
 # the pageable path's staging runs on the calling host thread beside them (profiles/r5_pinned_results_ab.txt: the driver's command 14.4 -> 14.9 ms
-# per step, 327 680 targets through the API 79 -> 82 ms with everything pinned).
+# per step, 327 680 targets through the API 79 -> 82 ms with everything pinned).  Pageable result arrays are recycled the same way
+# (``pageable_pool``): with glibc told never to return memory the 327 680-target call went 86-88 -> 79 ms on a box where the default
+# allocator had it in its slow mode (tools/r5_malloc_ab.sh); the pool gets that without touching the process's allocator settings.
 # ------------------------------------------------------------------------------------------------
-class _PinnedBlock:
-    __slots__ = ("ptr", "cap", "_pool", "__weakref__")
+class _PoolBlock:
+    __slots__ = ("ptr", "cap", "buf", "_pool", "__weakref__")
 
-    def __init__(self, pool, ptr, cap):
-        self.ptr, self.cap, self._pool = ptr, cap, pool
+    def __init__(self, pool, ptr, cap, buf):
+        self.ptr, self.cap, self.buf, self._pool = ptr, cap, buf, pool
 
     @property
     def __array_interface__(self):
@@ -272,56 +274,67 @@ class _PinnedBlock:
 
     def __del__(self):
         try:
-            self._pool._release(self.ptr, self.cap)
+            self._pool._release(self.ptr, self.cap, self.buf)
         except Exception:  # (interpreter shutdown)
             pass
 
 
-class PinnedPool:
+class ResultPool:
+    """Big result arrays as views of recycled blocks: page-locked ones from ``slam_host_alloc`` (``pinned=True``) or ordinary NumPy
+    buffers.  A block goes back to the pool when the last view of it dies."""
+
     MIN_BYTES = 1 << 18           # smaller arrays stay ordinary NumPy arrays (the library stages small fetches itself)
     GRANULE = 1 << 20
-    MAX_IDLE_BYTES = 2 << 30      # idle blocks beyond this go back to the driver
+    MAX_IDLE_BYTES = 2 << 30      # idle blocks beyond this are given up
 
-    def __init__(self):
+    def __init__(self, pinned: bool):
         import threading
 
+        self.pinned = bool(pinned)
         self._lock = threading.Lock()
         self._free = {}
         self._idle = 0
-        self.allocated = 0        # blocks obtained from the driver so far (tests / diagnostics)
+        self.allocated = 0        # blocks obtained so far (tests / diagnostics)
 
     def empty(self, shape, dtype) -> np.ndarray:
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-        lib = load_library()
-        if nbytes < self.MIN_BYTES or not hasattr(lib, "slam_host_alloc"):
+        if nbytes < self.MIN_BYTES:
             return np.empty(shape, dtype=dtype)
         cap = -(-nbytes // self.GRANULE) * self.GRANULE
-        ptr = None
+        entry = None
         with self._lock:
             lst = self._free.get(cap)
             if lst:
-                ptr = lst.pop()
+                entry = lst.pop()
                 self._idle -= cap
-        if ptr is None:
-            out = C.c_void_p()
-            if lib.slam_host_alloc(cap, C.byref(out)) != 0 or not out.value:
-                return np.empty(shape, dtype=dtype)  # (no page-locked memory left: pageable results are slower, not wrong)
-            ptr = int(out.value)
+        if entry is None:
+            if self.pinned:
+                lib = load_library()
+                out = C.c_void_p()
+                if not hasattr(lib, "slam_host_alloc") or lib.slam_host_alloc(cap, C.byref(out)) != 0 or not out.value:
+                    return np.empty(shape, dtype=dtype)  # (no page-locked memory: pageable results are slower, not wrong)
+                entry = (int(out.value), None)
+            else:
+                buf = np.empty(cap, dtype=np.uint8)
+                entry = (buf.ctypes.data, buf)
             self.allocated += 1
-        block = _PinnedBlock(self, ptr, cap)
+        block = _PoolBlock(self, entry[0], cap, entry[1])
         return np.asarray(block)[:nbytes].view(dtype).reshape(shape)
 
-    def _release(self, ptr, cap):
+    def _release(self, ptr, cap, buf):
         with self._lock:
             if self._idle + cap <= self.MAX_IDLE_BYTES:
-                self._free.setdefault(cap, []).append(ptr)
+                self._free.setdefault(cap, []).append((ptr, buf))
                 self._idle += cap
                 return
-        load_library().slam_host_free(C.c_void_p(ptr))
+        if buf is None:
+            load_library().slam_host_free(C.c_void_p(ptr))
 
 
-result_pool = PinnedPool()
+PinnedPool = ResultPool  # (name of the first version, tests)
+result_pool = ResultPool(pinned=True)      # ONE blocking call alone on the device (``pinned=True`` below)
+pageable_pool = ResultPool(pinned=False)   # everything else
 
 
 def _mat_to_ri(mats: np.ndarray) -> np.ndarray:
@@ -558,7 +571,7 @@ class Context:
             _check(self._lib.slam_decompose_range(self._h, int(first), int(count), k_min, k_max, _ptr(flat), C.byref(params), float(success_threshold)))
             return self.fetch_results_range(k_max, first, count, pinned=pinned) if fetch else None
         nmax = 6 * (k_max + 1)
-        new = result_pool.empty if pinned else (lambda shape, dtype: np.empty(shape, dtype=dtype))
+        new = result_pool.empty if pinned else pageable_pool.empty
         best_loss = new(count, np.float64)
         best_x = new((count, nmax), np.float64)  # (every row is written: the resident rows are zero-padded)
         best_cycles = new(count, np.int32)
@@ -597,7 +610,7 @@ class Context:
 
     def fetch_results_range(self, k_max: int, first: int, count: int, pinned: bool = False):
         nmax = 6 * (k_max + 1)
-        new = result_pool.empty if pinned else (lambda shape, dtype: np.empty(shape, dtype=dtype))
+        new = result_pool.empty if pinned else pageable_pool.empty
         best_loss = new(count, np.float64)
         best_x = new((count, nmax), np.float64)
         best_cycles = new(count, np.int32)
@@ -729,9 +742,9 @@ class Context:
         n_tot = sum(6 * (k + 1) + qn * k for k in range(k_min, k_max + 1))
         if len(gs) != sum(range(k_min, k_max + 1)) or any(len(v) != n_tot for v in cat):
             raise ValueError("gate_seqs / layouts do not match the span range")
-        best_loss = np.empty(count, dtype=np.float64)
-        best_x = np.empty((count, nmax), dtype=np.float64)
-        best_cycles = np.empty(count, dtype=np.int32)
+        best_loss = pageable_pool.empty(count, np.float64)
+        best_x = pageable_pool.empty((count, nmax), np.float64)
+        best_cycles = pageable_pool.empty(count, np.int32)
         _check(self._lib.slam_v2_decompose_range(self._h, int(first), int(count), int(k_min), int(k_max), _ptr(gs), _ptr(cat[0]), _ptr(cat[1]),
                                                  _ptr(cat[2]), _ptr(cat[3]), C.byref(params), float(threshold), _ptr(best_loss), _ptr(best_x),
                                                  _ptr(best_cycles)))

@@ -86,7 +86,7 @@ def test_result_pool_falls_back_to_pageable_arrays_without_a_gpu_and_recycles_bl
 
     import numpy as np
 
-    pool = _ffi.PinnedPool()
+    pool = _ffi.ResultPool(pinned=True)
     a = pool.empty((10, 3), np.float64)
     assert a.shape == (10, 3) and a.dtype == np.float64 and a.base is None
     b = pool.empty((1 << 16, 24), np.float64)  # 12.6 MB: asks the library, which has no device here
@@ -111,7 +111,7 @@ def test_result_pool_falls_back_to_pageable_arrays_without_a_gpu_and_recycles_bl
     orig = _ffi.load_library
     _ffi.load_library = lambda: fake
     try:
-        pool = _ffi.PinnedPool()
+        pool = _ffi.ResultPool(pinned=True)
         x = pool.empty((1 << 15, 24), np.float64)
         x[:] = 3.0
         view = x[5:7]
@@ -129,3 +129,14 @@ def test_result_pool_falls_back_to_pageable_arrays_without_a_gpu_and_recycles_bl
         assert len(fake.freed) == 2  # beyond the idle cap blocks go back to the driver
     finally:
         _ffi.load_library = orig
+    # the pageable pool: ordinary NumPy buffers, recycled the same way (nothing goes back to the C allocator between calls)
+    pool = _ffi.ResultPool(pinned=False)
+    p1 = pool.empty((1 << 15, 24), np.float64)
+    p1[:] = 2.0
+    addr = p1.ctypes.data
+    tail = p1[-1]
+    del p1
+    assert pool._idle == 0 and float(tail[3]) == 2.0
+    del tail
+    p2 = pool.empty((1 << 15, 24), np.float64)
+    assert p2.ctypes.data == addr and pool.allocated == 1

@@ -409,9 +409,10 @@ def test_big_result_arrays_come_from_the_pinned_pool_and_are_recycled():
         before = _ffi.result_pool.allocated
         loss, x, cyc = ctx.decompose_range(0, n, 1, 3, seqs, prm, 1e-10, pinned=True)
         assert x.shape == (n, 24) and x.base is not None and _ffi.result_pool.allocated > before  # 3.8 MB: from the pool
-        assert loss.base is None or loss.nbytes >= _ffi.PinnedPool.MIN_BYTES
-        l2, x2, c2 = ctx.fetch_results_range(3, 0, n)  # pageable arrays
-        assert x2.base is None and np.array_equal(loss, l2) and np.array_equal(x, x2) and np.array_equal(cyc, c2)
+        assert loss.base is None or loss.nbytes >= _ffi.ResultPool.MIN_BYTES
+        pinned_blocks = _ffi.result_pool.allocated
+        l2, x2, c2 = ctx.fetch_results_range(3, 0, n)  # pageable arrays (recycled too: _ffi.pageable_pool)
+        assert _ffi.result_pool.allocated == pinned_blocks and np.array_equal(loss, l2) and np.array_equal(x, x2) and np.array_equal(cyc, c2)
         assert np.mean(loss < 1e-8) > 0.99
         assert np.all(x[cyc == 2][:, 18:] == 0.0)  # rows are zero-padded behind 6 (cycles + 1) parameters
         addr, row = x.ctypes.data, x[7].copy()
