@@ -25,6 +25,7 @@
 #ifndef SLAM_HIP_H
 #define SLAM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -42,7 +43,7 @@ extern "C" {
                                     the reference's default maximum_span_guess, src/slam/basis.py:59 */
 #define SLAM_MAX_SPAN_EVAL 16     /* spans of slam_eval_*: beyond SLAM_MAX_SPAN_QUAD one wavefront per item (csrc/slam_long.hpp) */
 #define SLAM_MAX_SPAN_MINIMIZE 16 /* spans of slam_minimize_stage / slam_decompose*: beyond SLAM_MAX_SPAN_QUAD a wavefront per item
-                                    with a limited-memory quasi-Newton state (the templates MixedOrderBasisCircuitTemplate builds from
+                                    with its quasi-Newton metric (fp32) in device memory (the templates MixedOrderBasisCircuitTemplate builds from
                                     weak gates, src/slam/basis.py:213-359) */
 #define SLAM_MAX_GATES 256
 #define SLAM_MAX_MAXITER 4000    /* per-restart iteration cap accepted by the kernels (reference: 2500) */
