@@ -101,6 +101,20 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     flags = _ffi.FLAG_EARLY_EXIT | (0 if args.fast_exit else _ffi.FLAG_ORDERED)
     if n_streams > 1:
         flags |= _ffi.FLAG_NO_OVERLAP  # several calls in flight fill the chip: no speculative stages beside them
+    elif not args.fast_exit and not sweep and not span_rules_mode and not args.staged:
+        # ONE call at a time alone on the device: TemplateOptimizer's rule (optimizer.py:_overlap_pays) -- the spans side by side
+        # for all targets of the call (SLAM_FLAG_OVERLAP, same results bit for bit) when the exact coverage regions say that a good
+        # share of the batch needs the last span anyway (CNOT: every Haar target; sqrt(iSWAP): a fifth; B: none).  Measured:
+        # `--workload cfg2 --steps 20` 0.327 -> 0.347, `--streams 1` on the default workload 18.7 -> 17.6 ms per step.
+        from slam_decomposition_amd.optimizer import TemplateOptimizer
+        from slam_decomposition_amd.weyl import c1c2c3 as _c1c2c3
+
+        try:
+            spans3 = ctxs[0].predict_spans([_c1c2c3(table[i]) for i in gate_seqs[2]], 3, 0, min(n_per_step, 65536))
+            if float(np.mean(spans3 >= 3)) >= TemplateOptimizer.OVERLAP_MIN_TOP_SHARE:
+                flags |= _ffi.FLAG_OVERLAP
+        except (NotImplementedError, ValueError):
+            pass
     prm = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED, flags=flags, items_per_quad=ipq)
     threshold = 1e-10  # reference SUCCESS_THRESHOLD (optimizer.py:18); the metric counts loss < 1e-8
 
@@ -307,13 +321,16 @@ def run_workload(args, workload, rank, world, local_rank, comm, steps, warmup, n
     per_span = None
     if main and rank == 0 and not span_rules_mode and args.per_span_steps > 0:
         c = ctxs[0]
+        # (span by span whatever the timed region asked for: every launch alone on the chip)
+        prm_solo = _ffi.OptParams(restarts=restarts, maxiter=2500, gtol=1e-9, stop_loss=1e-13, seed=OPT_SEED,
+                                  flags=(flags & ~_ffi.FLAG_OVERLAP) | _ffi.FLAG_NO_OVERLAP, items_per_quad=ipq)
 
         def solo_step(s):
             if sweep:
                 c.set_gates(np.stack([sweep_gate(basis_of(s))]))
-                c.decompose_range(0, n_per_step, 1, 3, gate_seqs, prm, threshold, fetch=False)
+                c.decompose_range(0, n_per_step, 1, 3, gate_seqs, prm_solo, threshold, fetch=False)
             else:
-                c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm, threshold, fetch=False)
+                c.decompose_range(s * n_per_step, n_per_step, 1, 3, gate_seqs, prm_solo, threshold, fetch=False)
 
         for s in range(PER_SPAN_WARM_STEPS):  # untimed: the chip's clocks settle under this load (the first launches after an idle
             solo_step(s % total_steps)        # period run 2-3 % slower: profiles/r4_solo_probe.txt)
@@ -417,6 +434,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU gets its own full-size batches; strong: one GPU's batch per step is split over the --gpus ranks")
     ap.add_argument("--no-multi", action="store_true", help="cfg5: one library call per basis, 16 in flight (round 3) instead of slam_decompose_multi")
+    ap.add_argument("--staged", action="store_true", help="one call in flight: never ask for the spans side by side (SLAM_FLAG_OVERLAP is asked for where the batch's coverage says it pays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="targets of the CPU baseline sample (default 4 x host cores)")
     ap.add_argument("--per-span-steps", type=int, default=5, help="steps of the single-stream per-span roofline pass after the timed region (0 = skip)")

@@ -25,6 +25,10 @@ class StubContext:
     def sample_haar(self, seed0, n, first_index=0):
         self._seed0, self.n_targets = int(seed0), int(n)
 
+    def predict_spans(self, gate_coords_seq, k_max, first=0, count=None, tol=2e-8):
+        n = self.n_targets - first if count is None else count
+        return np.full(n, k_max, dtype=np.int32)  # (every stand-in target "needs" the last span)
+
     def reset_stats(self):
         self._st = {"kernel_ms": 0.0, "kernel_launches": 0, "evals": [0] * 6, "items": [0] * 6, "evals_accepted": [0] * 6,
                     "evals_preempted": [0] * 6, "kernel_ms_span": [0.0] * 6, "wave_rounds": [0] * 6}
