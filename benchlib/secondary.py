@@ -227,7 +227,9 @@ def run_medium_call(local_rank: int, n_targets: int = 4096, restarts: int = 16, 
 def run_long(local_rank: int, k: int = 8, n_targets: int = 4096, restarts: int = 8, reps: int = 3):
     """secondary.long: one stage of a LONG template -- k = 8 applications of ConversionGainGate(gain pi/16), the kind of circuit the
     reference's MixedOrderBasisCircuitTemplate builds from weak gates (src/slam/basis.py:213-359) -- through the wavefront-per-item
-    kernels (csrc/slam_long.hpp: layers over the quads, prefix / suffix scans, L-BFGS in LDS).  Throughput only: no roofline bar yet."""
+    kernels (csrc/slam_long.hpp: layers over the quads, prefix / suffix scans, the quasi-Newton metric in device memory).  Throughput,
+    the fraction of the fp64 peak, and the bytes the metric's pass moves (8 n^2 per evaluation: measured as HBM traffic at 12-16 gates,
+    profiles/r5_long_pmc.txt) -- no roofline bar was asked for this family yet."""
     from slam_decomposition_amd import _ffi
     from slam_decomposition_amd.gates import ConversionGainGate
 
@@ -250,4 +252,7 @@ def run_long(local_rank: int, k: int = 8, n_targets: int = 4096, restarts: int =
             "wall_ms": round(1e3 * med, 3), "kernel_ms": round(st["kernel_ms"], 3), "items": st["items"][k], "evals": st["evals"][k],
             "evals_per_s": st["evals"][k] / med, "targets_per_s": n_targets / med, "solved_fraction": float((out["best_loss"] < SUCCESS_LOSS).mean()),
             "roofline_frac": flops / med / 1e12 / PEAK_FP64_VALU_TFLOPS, "flops_per_eval": f_eval(k),
-            "note": "throughput of the new kernel family, reported without a roofline bar (VERDICT r4 item 5)"}
+            "metric_pass_bytes_per_eval": 8 * (6 * (k + 1)) ** 2, "metric_pass_tbps": st["evals"][k] * 8 * (6 * (k + 1)) ** 2 / med / 1e12,
+            "note": "throughput of the new kernel family, reported without a roofline bar (VERDICT r4 item 5); metric_pass_tbps = evaluations x 8 n^2 "
+                    "bytes (the fp32 metric read and written once per accepted step) / wall time: all of it HBM traffic at 12-16 gates "
+                    "(rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/r5_long_pmc.txt: 4.2 / 5.2 TB/s in steady state), L2 hits below"}
