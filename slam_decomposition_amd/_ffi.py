@@ -291,7 +291,7 @@ class ResultPool:
         import threading
 
         self.pinned = bool(pinned)
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()  # (re-entrant: a block's __del__ may run -- garbage collection -- while this thread holds it)
         self._free = {}
         self._idle = 0
         self.allocated = 0        # blocks obtained so far (tests / diagnostics)
