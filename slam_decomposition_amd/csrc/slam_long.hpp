@@ -34,7 +34,7 @@ constexpr int kLongN = 6 * kLongMaxLayers;        // 102 parameters at most
 constexpr int kLongNP = 128;                      // vector length in LDS: component i = 2 lane + a, a = 0, 1
 constexpr int kLongSlots = 2;                     // parameter slots per lane (an adjacent pair: one Philox block, one float2 of a metric row)
 constexpr int kLongHStride = kLongNP;             // floats per row of the inverse Hessian in device memory
-constexpr int kLongRowBatch = 12;                 // rows of it requested together (mat-vec / update passes)
+constexpr int kLongRowBatch = 16;                 // rows of it requested together (mat-vec / update passes)
 
 // LDS of one wavefront, in doubles
 constexpr int kLongOffTbl = 0;                                  // sincos table (64 double2)
