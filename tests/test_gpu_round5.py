@@ -426,3 +426,25 @@ def test_big_result_arrays_come_from_the_pinned_pool_and_are_recycled():
         assert _ffi.result_pool.allocated == count and np.array_equal(x4, x2)  # served from the pool's idle blocks
     finally:
         ctx.close()
+
+
+def test_results_of_an_earlier_call_survive_later_calls():
+    """Result arrays are views of recycled blocks: a block must stay out of the pools for as long as anything of the call's results is
+    alive -- ``target_data`` of a first call (single-call path: page-locked blocks; windowed path: pageable ones) reads the same after
+    later calls of the same sizes have come and gone."""
+    basis = CircuitTemplate(base_gates=[G.RiSwapGate(0.5)], maximum_span_guess=3)
+    for n, window in ((12000, 1 << 30), (12000, 2048)):
+        first = TemplateOptimizer(basis, BasicCost(), training_restarts=6, seed=11, override_fail=True)
+        first.WINDOW_TARGETS = window
+        loss1, _, data1 = first.approximate_from_distribution(DeviceHaarBatch(seed=500, n_samples=n))
+        picks = list(range(0, n, 499)) + [n - 1]
+        saved = [(data1[i].loss_result, data1[i].cycles, np.array(data1[i].Xk, copy=True)) for i in picks]
+        loss1_copy = np.array(loss1, copy=True)
+        for s in (501, 502, 503):
+            again = TemplateOptimizer(basis, BasicCost(), training_restarts=6, seed=12, override_fail=True)
+            again.WINDOW_TARGETS = window
+            loss_s, _, data_s = again.approximate_from_distribution(DeviceHaarBatch(seed=s, n_samples=n))
+            del loss_s, data_s, again  # (their blocks go back to the pools and are handed out again by the next call)
+        assert np.array_equal(np.asarray(loss1), loss1_copy)
+        for i, (l, c, x) in zip(picks, saved):
+            assert data1[i].loss_result == l and data1[i].cycles == c and np.array_equal(np.asarray(data1[i].Xk), x)
