@@ -336,7 +336,7 @@ int slam_fetch_span_losses(slam_ctx* ctx, int64_t first, int64_t count, double* 
  *   exit_loss   with SLAM_FLAG_EARLY_EXIT | SLAM_FLAG_ORDERED: a restart that ends below it stops the restarts of
  *               HIGHER index only, so every restart up to the first successful one runs to its end -- what the
  *               reference's sequential loop records (the span loop's success threshold, optimizer.py:287)
- * Meant for a few targets at a time (the trace must fit 4 GiB).
+ * Meant for a few targets at a time (the trace must fit 4 GiB).  Spans 1..SLAM_MAX_SPAN_MINIMIZE (both kernel families, round 5).
  */
 int slam_minimize_stage_trace(slam_ctx* ctx, int k, const int32_t* gate_seq, const int32_t* active, int64_t n_active,
                               const double* x0, const slam_opt_params* params, double exit_loss, int32_t trace_cap,

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslamhip.so")
 
 ABI_VERSION = 7  # include/slam_hip.h: SLAM_ABI_VERSION
-MAX_SPAN_QUAD = 5  # SLAM_MAX_SPAN_QUAD: the register-resident kernels (and per-iteration traces)
+MAX_SPAN_QUAD = 5  # SLAM_MAX_SPAN_QUAD: the register-resident kernels
 MAX_SPAN_EVAL = 16
 MAX_SPAN_MINIMIZE = 16
 

@@ -421,7 +421,9 @@ int launch_minimize_long(slam_ctx* c, const StageLaunch& sl, int k) {
     a.item_rec = c->item_rec.as<ItemRec>();
     a.item_x = c->item_x.as<double>();
     a.k = k;
-    if (c->trace_cap > 0) return fail(SLAM_ERR_UNSUPPORTED, "per-iteration traces are recorded for spans 1..%d (got %d)", SLAM_MAX_SPAN_QUAD, k);
+    a.trace_cap = c->trace_cap;
+    a.trace_loss = c->trace_cap > 0 ? c->trace_loss.as<double>() : nullptr;
+    a.trace_x = c->trace_cap > 0 ? c->trace_x.as<double>() : nullptr;
     { int rc = stage_gates(c, k, sl.gate_seq, &a.gates); if (rc) return rc; }
     int64_t blocks = sl.n_items_max;  // one item per wavefront at a time
     if (blocks > c->resident_waves_long) blocks = c->resident_waves_long;
@@ -1940,7 +1942,7 @@ int slam_minimize_stage_trace(slam_ctx* ctx, int k, const int32_t* gate_seq, con
     if (!ctx) return fail(SLAM_ERR_INVALID, "ctx is NULL");
     if (!params) return fail(SLAM_ERR_INVALID, "params is NULL");
     if (trace_cap <= 0 || !trace_loss || !trace_x) return fail(SLAM_ERR_INVALID, "trace buffers and trace_cap > 0 are required");
-    if (k < 1 || k > SLAM_MAX_SPAN_QUAD) return fail(SLAM_ERR_UNSUPPORTED, "per-iteration traces are recorded for spans 1..%d (got %d)", SLAM_MAX_SPAN_QUAD, k);
+    if (k < 1 || k > SLAM_MAX_SPAN_MINIMIZE) return fail(SLAM_ERR_UNSUPPORTED, "per-iteration traces are recorded for spans 1..%d (got %d)", SLAM_MAX_SPAN_MINIMIZE, k);
     if (!active) n_active = ctx->n_targets;
     if (n_active <= 0 || params->restarts <= 0) return fail(SLAM_ERR_INVALID, "nothing to trace");
     const int n = 6 * (k + 1);

@@ -67,6 +67,11 @@ struct LongArgs {
     const double* gates;      // [k][32]
     int32_t k;
     float* hmem;              // [gridDim.x][n][kLongHStride]: the wavefronts' inverse Hessian approximations
+    // optional per-iteration trace (use_callback, optimizer.py:217-224), as in MinimizeArgs: after accepted step number it >= 1 of item m,
+    // trace_loss[m][it - 1] = loss and trace_x[m][it - 1][:] = parameters; nullptr = off
+    double* trace_loss;       // [M][trace_cap]
+    double* trace_x;          // [M][trace_cap][n]
+    int32_t trace_cap;
 };
 
 struct LongEvalArgs {
@@ -670,6 +675,13 @@ __global__ void __launch_bounds__(kWave, 2) minimize_long_kernel(LongArgs args) 
                     p[s] = -(qv[s] + sa[s] * wg + va[s] * sg);
                     d1 = fma(g[s], p[s], d1);
                     d2 = fma(p[s], p[s], d2);
+                }
+                if (args.trace_loss && iters <= args.trace_cap) {  // (wave-uniform; nothing when off)
+                    const int64_t row = (int64_t)item * args.trace_cap + (iters - 1);
+                    if (lane == 0) args.trace_loss[row] = f;
+#pragma unroll
+                    for (int s = 0; s < kLongSlots; ++s)
+                        if (valid[s]) args.trace_x[row * n + 2 * lane + s] = x[s];
                 }
                 gnorm = wave_max_abs(gm);
                 gp = wave_sum(d1);

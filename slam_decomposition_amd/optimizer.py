@@ -714,7 +714,7 @@ class TemplateOptimizer:
         for k in all_ks:
             if k <= 0:
                 raise ValueError()  # CircuitTemplate.build(n_repetitions <= 0), basis.py:127-128
-            k_lim = _ffi.V2_MAX_SPAN if self._v2 else _ffi.MAX_SPAN_QUAD  # per-iteration traces: the register-resident kernels only
+            k_lim = _ffi.V2_MAX_SPAN if self._v2 else _ffi.MAX_SPAN_MINIMIZE  # (per-iteration traces: both kernel families)
             if k > k_lim:
                 raise NotImplementedError(f"template spans up to {k_lim} are implemented on the HIP path (got {k})")
             act = np.array([t for t in range(n) if k in spans_per_target[t] and not (best[t] is not None and best[t] < self.success_threshold)],

@@ -248,3 +248,38 @@ def test_long_template_runs_follow_the_cpu_port(hip_ctx, k, gate):
             same += int(out["item_evals"][t, r] == nev)
             assert abs(int(out["item_evals"][t, r]) - nev) <= max(10, nev // 3), (k, t, r, out["item_evals"][t, r], nev)
     assert same >= (n_t * R) // 3, same
+
+
+def test_per_iteration_traces_of_a_long_template(hip_ctx):
+    """use_callback for templates beyond five gates (src/slam/optimizer.py:217-224): the wavefront-per-item kernels record loss and point
+    after every accepted step like the quad kernels -- the recorded losses are the oracle's at the recorded points, decrease, end at the
+    item's result; through the API the reference's training_loss layout [-1, k, losses ...] comes out for a 6-gate template."""
+    k, R, cap = 6, 2, 400
+    T = o.haar_batch(3, seed0=4600)
+    hip_ctx.set_targets(T)
+    hip_ctx.set_gates(SQ[None])
+    prm = _ffi.OptParams(restarts=R, seed=9)
+    out = hip_ctx.minimize_stage_trace([0] * k, prm, 1e-10, cap)
+    ref = hip_ctx.minimize_stage([0] * k, prm)  # the same launch without a trace
+    assert np.array_equal(out["item_loss"], ref["item_loss"]) and np.array_equal(out["item_iters"], ref["item_iters"])
+    n = 6 * (k + 1)
+    for t in range(3):
+        for r in range(R):
+            it = int(out["item_iters"][t, r])
+            assert 0 < it <= cap
+            tl = out["trace_loss"][t, r]
+            assert np.all(np.isfinite(tl[:it])) and np.all(np.isnan(tl[it:]))
+            assert np.all(np.diff(tl[:it]) <= 1e-15)  # accepted steps only: Armijo decrease
+            assert tl[it - 1] == out["item_loss"][t, r]
+            for j in (0, it // 2, it - 1):
+                x = out["trace_x"][t, r, j]
+                assert x.shape == (n,) and abs(o.basic_cost(o.template_eval(x, [SQ] * k), T[t]) - tl[j]) < 1e-12
+            assert np.all(np.isnan(out["trace_x"][t, r, it:]))
+    # the API: one target, the callback's bookkeeping
+    basis = CircuitTemplate(base_gates=[RiSwapGate(0.25)], maximum_span_guess=6)
+    basis.spanning_range = range(6, 7)
+    optm = TemplateOptimizer(basis, BasicCost(), use_callback=True, override_fail=True, training_restarts=2, seed=3)
+    data = optm.approximate_target_U(o.haar_unitary(77))
+    loss = list(optm.training_loss[0])  # (one list per target, optimizer.py:307-311)
+    assert loss[0] == -1 and loss[1] == 6 and len(loss) > 10 and data.cycles == 6
+    assert len(optm.coordinate_list) > 0
